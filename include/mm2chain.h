@@ -1,0 +1,140 @@
+/*
+ * mm2chain.h -- C ABI of the MI355X (gfx950) chaining library, libmm2chain_hip.so.
+ *
+ * Drop-in boundary for ONE hot path of kisarur/minimap2-fpga: the predecessor-scan DP that fills f[] / p[]
+ * inside mm_chain_dp (chain.c:184-238), which the reference offloads through run_chaining_on_hw
+ * (chain_hardware.h:68, chain_hardware.cpp:27-197, kernel device/minimap2_opencl.cl:24-182).
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  All entry points return 0 on success and a
+ * negative MM2C_E_* code on failure unless stated otherwise; mm2c_last_error() gives the message.  There is
+ * NO CPU fallback anywhere behind this header: if no HIP device is usable every compute entry fails.
+ *
+ * Preconditions shared by every compute entry (they are the reference caller's guarantees):
+ *   - anchors of one task are sorted ascending by x (map.c:245)
+ *   - x = strand<<63 | rid<<32 | rpos with rpos < 2^31 (map.c:228-241), so anchors within max_dist_x of
+ *     each other share the high 32 bits of x
+ *   - 0 <= max_dist_x, and every task has n < 2^31 - 64 anchors (chain.c:30 "TODO" holds here too)
+ */
+#ifndef MM2CHAIN_H
+#define MM2CHAIN_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same layout as mm128_t (minimap.h:53): 16 bytes, x then y */
+typedef struct { uint64_t x, y; } mm2c_anchor_t;
+
+enum {
+	MM2C_OK = 0,
+	MM2C_E_NODEVICE = -1,  /* no usable HIP device / mm2c_init not called (cf. hardware_init false, main.c:367) */
+	MM2C_E_ARG = -2,       /* bad argument (negative n, NULL pointer, negative max_dist_x, ...) */
+	MM2C_E_TOOBIG = -3,    /* task larger than the supported maximum (cf. chain_hardware.cpp:34-37) */
+	MM2C_E_HIP = -4        /* HIP runtime error (cf. checkError, chain_hardware.cpp:208-235) */
+};
+
+/* flags for mm2c_params_t.flags */
+#define MM2C_F_IGNORE_SEG  0x1  /* treat all anchors as one segment (what the FPGA kernel does, .cl:116-127) */
+#define MM2C_F_FORCE_GENERAL 0x2 /* always run the general (segment / cDNA aware) kernel variant */
+
+/*
+ * Scalars of one mm_chain_dp call (mmpriv.h:65 arguments 1-5, 8-10).  q_span_override >= 0 replaces the
+ * per-anchor span (a[i].y>>32 & 0xff, chain.c:189) by one value, which is what the reference's device
+ * interface carries (chain_hardware.h:68 argument q_span, chain.c:91-96).
+ */
+typedef struct {
+	int32_t max_dist_x, max_dist_y, bw;
+	int32_t max_skip, max_iter;
+	float   gap_scale;
+	int32_t is_cdna, n_segs;
+	int32_t q_span_override;   /* -1: per-anchor span */
+	int32_t flags;             /* MM2C_F_* */
+} mm2c_params_t;
+
+/* ---- lifecycle: replaces hardware_init(BUFFER_N, XCLBIN_FILE) / cleanup() (chain_hardware.h:70-71, main.c:367,430) ---- */
+int  mm2c_init(int device_ordinal);           /* -1: current device.  Idempotent. */
+void mm2c_shutdown(void);
+const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
+int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
+/* tuning knobs (key, value): "ring_class" 0/1/2 = 256/512/1024 anchors of LDS ring per task (default 0, or env
+ * MM2C_RING_CLASS).  Results never depend on a knob. */
+int  mm2c_tune(const char *key, int value);
+
+/* defaults of `minimap2 -x map-ont` (options.c:24-31,93-99; map.c:305-316) */
+void mm2c_params_map_ont(mm2c_params_t *p);
+/* V2 = what the FPGA kernel computes for a run_chaining_on_hw call */
+void mm2c_params_fpga_v2(mm2c_params_t *p, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t q_span);
+
+/* ---- batched, HBM-resident path ------------------------------------------------------------------------------ */
+/*
+ * A plan describes one batch of independent chaining tasks in CSR form: task k owns anchors
+ * [offsets[k], offsets[k+1]) of the concatenated arrays.  Creating a plan uploads offsets and the
+ * longest-first launch order and reserves the device workspace; it can be run many times.
+ */
+typedef struct mm2c_plan mm2c_plan_t;
+mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets);
+void mm2c_plan_destroy(mm2c_plan_t *plan);
+int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
+
+/*
+ * Enqueue the DP for every task of the plan on `stream` (a hipStream_t passed as void*, NULL = the library's
+ * own stream).  All pointers are DEVICE pointers: d_anchors[total] (16 B each), d_f[total], d_p[total].
+ * d_avg_qspan is either NULL (the kernel computes avg_qspan_scaled per task exactly as chain.c:48-49) or
+ * n_tasks floats.  p[] is task-relative, -1 = no predecessor, exactly as chain.c:236.  Asynchronous.
+ */
+int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *d_avg_qspan,
+                         int32_t *d_f, int32_t *d_p, void *stream);
+
+/* milliseconds between HIP events recorded (on the run's stream) around the DP kernel launches of the most
+ * recent mm2c_plan_run_device; synchronises on the end event. */
+int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
+
+/* ---- host-buffer paths (PCIe included) ---------------------------------------------------------------------- */
+/* whole batch from pageable host memory: staging, H2D, DP, D2H, sync */
+int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets,
+                          const mm2c_anchor_t *h_anchors, const float *h_avg_qspan /* or NULL */,
+                          int32_t *h_f, int32_t *h_p);
+
+/*
+ * One task, synchronous, V1 (stock CPU) semantics: the EXTENDED form of run_chaining_on_hw
+ * (chain_hardware.h:68) that also carries max_skip / max_iter / gap_scale / is_cdna / n_segs, which the
+ * reference interface cannot express.  Re-entrant from many host threads (map.c:561); `tid` as chain.c:103.
+ * Always returns 0 (= "computed on device", chain_hardware.cpp:195) or a negative error; never 1.
+ */
+int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
+                         int32_t *f, int32_t *p, int tid);
+
+/* ---- host mirror of the reference function around the path ------------------------------------------------------ */
+/*
+ * mm_chain_dp with the reference's exact signature and ownership rules (mmpriv.h:65, chain.c:29-423): frees `a`
+ * with kfree(km, a); returns b[] and *_u allocated with kmalloc(km, ...).  The DP (f[], p[]) runs on the GPU
+ * through mm2c_chain_task_host; v[] and the backtrack run on the calling thread.  Needs the host program's
+ * kmalloc/kfree (kalloc.h:14,17) at link/load time.  Declared here with mm2c_anchor_t == mm128_t.
+ */
+mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt,
+                           int min_sc, float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a,
+                           int *n_u_, uint64_t **_u, void *km, int tid);
+
+/* statistics since mm2c_init: tasks, anchors, and kernel launches issued through any entry point */
+typedef struct { uint64_t tasks, anchors, launches; } mm2c_stats_t;
+void mm2c_get_stats(mm2c_stats_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+/*
+ * C++-linkage symbols with the reference's exact prototypes are defined in csrc/mm2chain_dropin.cpp
+ * (chain_hardware.h:68-71; the reference compiles every .c with $(CXX), Makefile:184-185, so its objects import
+ * _Z18run_chaining_on_hwliiiifP7mm128_tPiS1_Phliff, _Z13hardware_initlPc, _Z7cleanupv):
+ *   int  run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_span, float avg_qspan, mm128_t *a,
+ *                           int *f, int *p, unsigned char *num_subparts, long total_subparts, int tid,
+ *                           float hw_time_pred, float sw_time_pred);   // computes V2 = what the FPGA kernel computes
+ *   bool hardware_init(long, char *);
+ *   void cleanup();
+ */
+
+#endif /* MM2CHAIN_H */

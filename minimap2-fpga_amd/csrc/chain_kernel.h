@@ -1,0 +1,39 @@
+// chain_kernel.h -- internal interface between the C-ABI shim (mm2chain_api.cpp) and the HIP kernels.
+#ifndef MM2C_CHAIN_KERNEL_H
+#define MM2C_CHAIN_KERNEL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mm2c {
+
+enum { KF_IGNORE_SEG = 0x1, KF_FORCE_GENERAL = 0x2 };
+
+// scalars of one mm_chain_dp call (mmpriv.h:65), passed by value to the kernel
+struct KParams {
+	int32_t max_dist_x, max_dist_y, bw;
+	int32_t max_skip, max_iter;
+	int32_t is_cdna, n_segs;
+	int32_t span_override;   // >= 0: one q_span for every anchor (chain_hardware.h:68 `q_span`)
+	int32_t max_dq;          // min(max_dist_y, max_dist_x)
+	int32_t flags;           // KF_*
+	float gap_scale;
+};
+
+struct LaunchArgs {
+	KParams P;
+	int64_t n_tasks;
+	const int64_t *d_offsets;   // n_tasks+1, CSR
+	const int32_t *d_order;     // launch order (longest task first) or nullptr
+	const void *d_anchors;      // 16 B per anchor
+	const float *d_avg;         // per task or nullptr (computed in kernel, chain.c:48-49)
+	int32_t *d_f, *d_p;
+	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
+	int32_t *d_status;          // per task, must be zero on entry
+	int ring_class;             // 0: 256, 1: 512, 2: 1024 anchors of LDS ring per task
+};
+
+int chain_ring_anchors(int ring_class);
+hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches);
+
+} // namespace mm2c
+#endif

@@ -1,0 +1,365 @@
+// mm2chain_api.cpp -- the C-ABI shim over HIP (include/mm2chain.h).
+//
+// Replaces the reference's XRT/OpenCL enqueue path: hardware_init (chain_hardware.cpp:278-400: platform, xclbin,
+// kernel object, four cl_mem buffers), the body of run_chaining_on_hw (chain_hardware.cpp:104-189: two
+// clEnqueueWriteBuffer, clEnqueueTask, two clEnqueueReadBuffer, clFinish) and cleanup (chain_hardware.cpp:403-441).
+// Differences by design: no busy/queue time model and no "declined, do it on the CPU" return (chain_hardware.cpp:54-93)
+// -- every accepted call is computed on the GPU; many tasks are in flight at once (one wave each) instead of one
+// task per kernel; callers on different host threads get their own stream and staging buffers instead of a mutex.
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <vector>
+#include "mm2chain.h"
+#include "chain_kernel.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	return fail(MM2C_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct ThreadCtx;
+
+struct Global {
+	std::mutex mu;
+	bool ready = false;
+	int device = -1;
+	int ring_class = 0;
+	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
+	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
+	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0};
+	uint64_t epoch = 0;                     // bumped by shutdown so stale thread-local pointers are dropped
+} G;
+
+// per host thread: stream + grow-only device buffers (the reference keeps one buffer set per FPGA kernel,
+// chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex)
+struct ThreadCtx {
+	hipStream_t st = nullptr;
+	void *d_a = nullptr; int32_t *d_f = nullptr, *d_p = nullptr, *d_t = nullptr;
+	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr; float *d_avg = nullptr;
+	size_t cap_anchors = 0, cap_tasks = 0;
+	void release()
+	{
+		if (d_a) (void)hipFree(d_a); if (d_f) (void)hipFree(d_f); if (d_p) (void)hipFree(d_p); if (d_t) (void)hipFree(d_t);
+		if (d_off) (void)hipFree(d_off); if (d_order) (void)hipFree(d_order); if (d_status) (void)hipFree(d_status); if (d_avg) (void)hipFree(d_avg);
+		if (st) (void)hipStreamDestroy(st);
+		*this = ThreadCtx();
+	}
+};
+
+thread_local ThreadCtx *tl_ctx = nullptr;
+thread_local uint64_t tl_epoch = 0;
+
+int get_thread_ctx(ThreadCtx **out)
+{
+	std::lock_guard<std::mutex> lk(G.mu);
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (tl_ctx && tl_epoch == G.epoch) { *out = tl_ctx; return 0; }
+	HIP_TRY(hipSetDevice(G.device));
+	ThreadCtx *c = new ThreadCtx();
+	hipError_t e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete c; return fail(MM2C_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+	G.thread_ctxs.push_back(c);
+	tl_ctx = c; tl_epoch = G.epoch;
+	*out = c;
+	return 0;
+}
+
+int ensure_capacity(ThreadCtx *c, size_t n_anchors, size_t n_tasks)
+{
+	if (n_anchors > c->cap_anchors) {
+		size_t cap = std::max(n_anchors, c->cap_anchors * 2);
+		if (c->d_a) (void)hipFree(c->d_a); if (c->d_f) (void)hipFree(c->d_f); if (c->d_p) (void)hipFree(c->d_p); if (c->d_t) (void)hipFree(c->d_t);
+		c->d_a = nullptr; c->d_f = c->d_p = c->d_t = nullptr; c->cap_anchors = 0;
+		HIP_TRY(hipMalloc(&c->d_a, cap * 16));
+		HIP_TRY(hipMalloc((void **)&c->d_f, cap * 4));
+		HIP_TRY(hipMalloc((void **)&c->d_p, cap * 4));
+		HIP_TRY(hipMalloc((void **)&c->d_t, cap * 4));
+		c->cap_anchors = cap;
+	}
+	if (n_tasks > c->cap_tasks) {
+		size_t cap = std::max(n_tasks, c->cap_tasks * 2);
+		if (c->d_off) (void)hipFree(c->d_off); if (c->d_order) (void)hipFree(c->d_order); if (c->d_status) (void)hipFree(c->d_status); if (c->d_avg) (void)hipFree(c->d_avg);
+		c->d_off = nullptr; c->d_order = c->d_status = nullptr; c->d_avg = nullptr; c->cap_tasks = 0;
+		HIP_TRY(hipMalloc((void **)&c->d_off, (cap + 1) * 8));
+		HIP_TRY(hipMalloc((void **)&c->d_order, cap * 4));
+		HIP_TRY(hipMalloc((void **)&c->d_status, cap * 4));
+		HIP_TRY(hipMalloc((void **)&c->d_avg, cap * 4));
+		c->cap_tasks = cap;
+	}
+	return 0;
+}
+
+int check_params(const mm2c_params_t *p)
+{
+	if (!p) return fail(MM2C_E_ARG, "params is NULL");
+	if (p->max_dist_x < 0) return fail(MM2C_E_ARG, "max_dist_x must be >= 0 (got %d)", p->max_dist_x);
+	return 0;
+}
+
+mm2c::KParams to_kparams(const mm2c_params_t *p)
+{
+	mm2c::KParams k;
+	k.max_dist_x = p->max_dist_x; k.max_dist_y = p->max_dist_y; k.bw = p->bw;
+	k.max_skip = p->max_skip; k.max_iter = p->max_iter;
+	k.is_cdna = p->is_cdna; k.n_segs = p->n_segs;
+	k.span_override = p->q_span_override;
+	k.max_dq = std::min(p->max_dist_y, p->max_dist_x);
+	k.flags = 0;
+	if (p->flags & MM2C_F_IGNORE_SEG) k.flags |= mm2c::KF_IGNORE_SEG;
+	if (p->flags & MM2C_F_FORCE_GENERAL) k.flags |= mm2c::KF_FORCE_GENERAL;
+	k.gap_scale = p->gap_scale;
+	return k;
+}
+
+// offsets sanity + longest-first launch order (so the tail of the grid is made of short tasks)
+int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order)
+{
+	if (n_tasks < 0 || n_tasks > INT32_MAX) return fail(MM2C_E_ARG, "n_tasks out of range");
+	if (n_tasks > 0 && !off) return fail(MM2C_E_ARG, "offsets is NULL");
+	for (int64_t k = 0; k < n_tasks; ++k) {
+		const int64_t n = off[k + 1] - off[k];
+		if (n < 0) return fail(MM2C_E_ARG, "offsets not monotone at task %lld", (long long)k);
+		if (n >= (int64_t)INT32_MAX - 64)
+			return fail(MM2C_E_TOOBIG, "task %lld has %lld anchors; the limit is 2^31-65 (cf. chain_hardware.cpp:34)", (long long)k, (long long)n);
+	}
+	order.resize((size_t)n_tasks);
+	std::iota(order.begin(), order.end(), 0);
+	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+	return 0;
+}
+
+} // namespace
+
+struct mm2c_plan {
+	mm2c_params_t par;
+	int64_t n_tasks = 0, total = 0;
+	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool ran = false;
+};
+
+extern "C" {
+
+const char *mm2c_last_error(void) { return g_err; }
+
+int mm2c_init(int device_ordinal)
+{
+	std::lock_guard<std::mutex> lk(G.mu);
+	if (G.ready) return 0;
+	int n_dev = 0;
+	hipError_t e = hipGetDeviceCount(&n_dev);
+	if (e != hipSuccess || n_dev <= 0)
+		return fail(MM2C_E_NODEVICE, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+	int dev = device_ordinal;
+	if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+	if (dev >= n_dev) return fail(MM2C_E_NODEVICE, "device ordinal %d out of range (%d devices)", dev, n_dev);
+	HIP_TRY(hipSetDevice(dev));
+	HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+	G.device = dev;
+	const char *rc = getenv("MM2C_RING_CLASS");
+	G.ring_class = rc ? std::max(0, std::min(2, atoi(rc))) : 0;
+	G.ready = true;
+	return 0;
+}
+
+void mm2c_shutdown(void)
+{
+	std::lock_guard<std::mutex> lk(G.mu);
+	if (!G.ready) return;
+	(void)hipSetDevice(G.device);
+	(void)hipDeviceSynchronize();
+	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
+	G.thread_ctxs.clear();
+	if (G.stream) (void)hipStreamDestroy(G.stream);
+	G.stream = nullptr;
+	G.ready = false;
+	++G.epoch;
+}
+
+int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes)
+{
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, G.device));
+	if (name && name_len) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+	if (cu_count) *cu_count = prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+	return 0;
+}
+
+int mm2c_tune(const char *key, int value)
+{
+	if (!key) return fail(MM2C_E_ARG, "key is NULL");
+	if (strcmp(key, "ring_class") == 0) {
+		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "ring_class must be 0, 1 or 2");
+		G.ring_class = value;
+		return 0;
+	}
+	return fail(MM2C_E_ARG, "unknown tuning key '%s'", key);
+}
+
+void mm2c_params_map_ont(mm2c_params_t *p)
+{
+	// options.c:24-31 (mm_mapopt_init) + :93-99 (map-ont keeps them); map.c:305-316 passes max_gap as both max_dist
+	p->max_dist_x = 5000; p->max_dist_y = 5000; p->bw = 500;
+	p->max_skip = 25; p->max_iter = 5000; p->gap_scale = 1.0f;
+	p->is_cdna = 0; p->n_segs = 1; p->q_span_override = -1; p->flags = 0;
+}
+
+void mm2c_params_fpga_v2(mm2c_params_t *p, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t q_span)
+{
+	// device/minimap2_opencl.cl:116-127: no max_skip, look-back <= 128*8 (chain_hardware.h:58-60), one q_span,
+	// segment ids ignored, gap_scale 1
+	p->max_dist_x = max_dist_x; p->max_dist_y = max_dist_y; p->bw = bw;
+	p->max_skip = INT32_MAX; p->max_iter = 1024; p->gap_scale = 1.0f;
+	p->is_cdna = 0; p->n_segs = 1; p->q_span_override = q_span; p->flags = MM2C_F_IGNORE_SEG;
+}
+
+void mm2c_get_stats(mm2c_stats_t *out)
+{
+	if (!out) return;
+	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load();
+}
+
+// ------------------------------------------------------------------------------------------------ plans
+mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets)
+{
+	if (check_params(par)) return nullptr;
+	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	std::vector<int32_t> order;
+	if (build_order(n_tasks, h_offsets, order)) return nullptr;
+	mm2c_plan *pl = new mm2c_plan();
+	pl->par = *par; pl->n_tasks = n_tasks;
+	pl->total = n_tasks > 0 ? h_offsets[n_tasks] - h_offsets[0] : 0;
+	hipError_t e = hipSetDevice(G.device);
+	const size_t nt = (size_t)std::max<int64_t>(n_tasks, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
+	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_off, (nt + 1) * 8);
+	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_order, nt * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_status, nt * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_t, tot * 4);
+	if (e == hipSuccess && n_tasks > 0) {
+		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
+		std::vector<int64_t> off((size_t)n_tasks + 1);
+		for (int64_t k = 0; k <= n_tasks; ++k) off[(size_t)k] = h_offsets[k] - h_offsets[0];
+		e = hipMemcpy(pl->d_off, off.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(pl->d_order, order.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
+	if (e != hipSuccess) {
+		fail(MM2C_E_HIP, "mm2c_plan_create: %s", hipGetErrorString(e));
+		mm2c_plan_destroy(pl);
+		return nullptr;
+	}
+	return pl;
+}
+
+void mm2c_plan_destroy(mm2c_plan_t *pl)
+{
+	if (!pl) return;
+	if (pl->d_off) (void)hipFree(pl->d_off); if (pl->d_order) (void)hipFree(pl->d_order);
+	if (pl->d_status) (void)hipFree(pl->d_status); if (pl->d_t) (void)hipFree(pl->d_t);
+	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+	delete pl;
+}
+
+int64_t mm2c_plan_total_anchors(const mm2c_plan_t *pl) { return pl ? pl->total : 0; }
+
+int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_avg_qspan, int32_t *d_f, int32_t *d_p, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (pl->n_tasks == 0 || pl->total == 0) return 0;
+	if (!d_anchors || !d_f || !d_p) return fail(MM2C_E_ARG, "device pointer is NULL");
+	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	mm2c::LaunchArgs L;
+	L.P = to_kparams(&pl->par);
+	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
+	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_status = pl->d_status;
+	L.ring_class = G.ring_class;
+	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
+	HIP_TRY(hipEventRecord(pl->ev0, st));
+	int nl = 0;
+	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl));
+	HIP_TRY(hipEventRecord(pl->ev1, st));
+	pl->ran = true;
+	G.tasks += (uint64_t)pl->n_tasks; G.anchors += (uint64_t)pl->total; G.launches += (uint64_t)nl;
+	return 0;
+}
+
+int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
+{
+	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
+	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
+	HIP_TRY(hipEventSynchronize(pl->ev1));
+	HIP_TRY(hipEventElapsedTime(ms, pl->ev0, pl->ev1));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ host-buffer paths
+int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+{
+	int rc;
+	if ((rc = check_params(par))) return rc;
+	std::vector<int32_t> order;
+	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;
+	if (n_tasks == 0) return 0;
+	const int64_t base = h_offsets[0], total = h_offsets[n_tasks] - base;
+	if (total == 0) return 0;
+	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
+	ThreadCtx *c;
+	if ((rc = get_thread_ctx(&c))) return rc;
+	HIP_TRY(hipSetDevice(G.device));
+	if ((rc = ensure_capacity(c, (size_t)total, (size_t)n_tasks))) return rc;
+	std::vector<int64_t> off((size_t)n_tasks + 1);
+	for (int64_t k = 0; k <= n_tasks; ++k) off[(size_t)k] = h_offsets[k] - base;
+	HIP_TRY(hipMemcpyAsync(c->d_off, off.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice, c->st));
+	HIP_TRY(hipMemcpyAsync(c->d_order, order.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->st));
+	HIP_TRY(hipMemcpyAsync(c->d_a, h_anchors + base, (size_t)total * 16, hipMemcpyHostToDevice, c->st)); // cf. chain_hardware.cpp:110
+	if (h_avg_qspan) HIP_TRY(hipMemcpyAsync(c->d_avg, h_avg_qspan, (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->st));
+	HIP_TRY(hipMemsetAsync(c->d_status, 0, (size_t)n_tasks * 4, c->st));
+	mm2c::LaunchArgs L;
+	L.P = to_kparams(par);
+	L.n_tasks = n_tasks; L.d_offsets = c->d_off; L.d_order = c->d_order; L.d_anchors = c->d_a;
+	L.d_avg = h_avg_qspan ? c->d_avg : nullptr; L.d_f = c->d_f; L.d_p = c->d_p; L.d_t = c->d_t; L.d_status = c->d_status;
+	L.ring_class = G.ring_class;
+	int nl = 0;
+	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl));                                                          // cf. chain_hardware.cpp:156
+	HIP_TRY(hipMemcpyAsync(h_f + base, c->d_f, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:167
+	HIP_TRY(hipMemcpyAsync(h_p + base, c->d_p, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:170
+	HIP_TRY(hipStreamSynchronize(c->st));                                                                   // cf. chain_hardware.cpp:175
+	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl;
+	return 0;
+}
+
+int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
+                         int32_t *f, int32_t *p, int tid)
+{
+	(void)tid;  // the reference uses tid for its FIFO (chain_hardware.cpp:65,83); each host thread owns a stream here
+	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
+	if (n < 0) return fail(MM2C_E_ARG, "n < 0");
+	const int64_t off[2] = { 0, n };
+	return mm2c_chain_batch_host(par, 1, off, a, &avg_qspan_scaled, f, p);
+}
+
+} // extern "C"

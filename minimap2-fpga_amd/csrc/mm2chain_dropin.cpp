@@ -1,0 +1,43 @@
+// mm2chain_dropin.cpp -- the reference's dispatch surface, symbol for symbol (chain_hardware.h:68-71).
+//
+// The reference builds every .c with $(CXX) (Makefile:184-185), so chain.o / main.o import C++-mangled
+//   _Z18run_chaining_on_hwliiiifP7mm128_tPiS1_Phliff   _Z13hardware_initlPc   _Z7cleanupv
+// This TU defines exactly those, over the C ABI of include/mm2chain.h, so an unmodified reference chain.o /
+// main.o links against libmm2chain_hip.so instead of chain_hardware.o + XRT.  run_chaining_on_hw keeps the
+// contract of chain_hardware.cpp:27-197 (fills f[0..n), p[0..n) before returning 0) and computes what the
+// FPGA kernel computes (V2, device/minimap2_opencl.cl): its signature cannot carry max_skip / max_iter /
+// gap_scale / n_segs, see mm2c_chain_task_host for the extended entry used by our own mm_chain_dp.
+#include <cstdio>
+#include <cstdlib>
+#include "mm2chain.h"
+
+typedef struct { uint64_t x, y; } mm128_t;   // minimap.h:53
+
+int run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_span, float avg_qspan,
+                       mm128_t *a, int *f, int *p, unsigned char *num_subparts, long total_subparts, int tid,
+                       float hw_time_pred, float sw_time_pred)
+{
+	(void)num_subparts; (void)total_subparts;   // FPGA pipeline bookkeeping (chain.c:62-78), not needed on a GPU
+	(void)hw_time_pred; (void)sw_time_pred;     // the busy/queue model of chain_hardware.cpp:54-93 is gone: never declines
+	if (n == 0) return 0;                       // chain_hardware.cpp:30-32
+	mm2c_params_t par;
+	mm2c_params_fpga_v2(&par, max_dist_x, max_dist_y, bw, q_span);
+	int rc = mm2c_chain_task_host(&par, n, (const mm2c_anchor_t *)a, avg_qspan, f, p, tid);
+	if (rc != 0) {                              // chain_hardware.cpp:34-37, 208-235: message + exit
+		fprintf(stderr, "Error: GPU chaining failed (n = %ld): %s\n", n, mm2c_last_error());
+		exit(EXIT_FAILURE);
+	}
+	return 0;                                   // chain_hardware.cpp:195
+}
+
+bool hardware_init(long buf_size, char *binary_name)
+{
+	(void)buf_size; (void)binary_name;          // BUFFER_N / xclbin path (main.c:367): buffers grow on demand, no bitstream
+	if (mm2c_init(-1) != 0) {
+		fprintf(stderr, "ERROR: %s\n", mm2c_last_error());
+		return false;                           // main.c:367-369 returns -1 on false
+	}
+	return true;
+}
+
+void cleanup() { mm2c_shutdown(); }             // main.c:430

@@ -1,0 +1,174 @@
+/*
+ * mm_chain_dp_host.c -- host mirror of mm_chain_dp (kisarur/minimap2-fpga chain.c:29-423, prototype mmpriv.h:65).
+ *
+ * Same signature, same ownership (frees `a`, returns km-owned b[] and u[]), so a minimap2 host links this
+ * object in place of chain.o.  The f[]/p[] DP -- the hot loop, chain.c:184-238 -- ALWAYS runs on the GPU via
+ * mm2c_chain_task_host (stock CPU semantics incl. max_skip); there is no software DP in this file and no
+ * HW/SW time model (chain.c:53-81 is an FPGA artefact).  The O(n) epilogue (v[], chain ends, backtrack, chain
+ * order; chain.c:106-111, 348-422) runs on the calling thread.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mm2chain.h"
+
+/* the host program's arena allocator (kalloc.h:14,17).  Weak: when the library is loaded without a minimap2
+ * host (tests, bench) only km == NULL is accepted, which kalloc.c itself maps to malloc/free. */
+extern void *kmalloc(void *km, size_t size) __attribute__((weak));
+extern void kfree(void *km, void *ptr) __attribute__((weak));
+
+static void *xalloc(void *km, size_t sz)
+{
+	if (kmalloc) return kmalloc(km, sz);
+	if (km) { fprintf(stderr, "[mm2chain] km != NULL but the host's kmalloc is not linked\n"); exit(EXIT_FAILURE); }
+	return malloc(sz ? sz : 1);
+}
+static void xfree(void *km, void *p)
+{
+	if (kfree) kfree(km, p);
+	else free(p);
+}
+
+/* ---- in-place MSD byte radix sort with the klib pass structure (ksort.h:101-151; misc.c:155-159) ----
+ * Order among equal keys is part of mm_chain_dp's observable output (chain.c:411), so the passes follow the
+ * same rules: n <= 64 insertion sort; else cycle-leader distribution on the current byte, top byte first;
+ * sub-buckets > 64 recurse on the next byte, 2..64 are insertion sorted. */
+typedef struct { mm2c_anchor_t *lo, *hi; } span128_t;
+
+static void ins128(mm2c_anchor_t *lo, mm2c_anchor_t *hi)
+{
+	mm2c_anchor_t *q, *r, key;
+	for (q = lo + 1; q < hi; ++q) {
+		if (q->x >= (q - 1)->x) continue;
+		key = *q;
+		for (r = q; r > lo && key.x < (r - 1)->x; --r) *r = *(r - 1);
+		*r = key;
+	}
+}
+
+static void msd128(mm2c_anchor_t *lo, mm2c_anchor_t *hi, int shift)
+{
+	span128_t bk[256];
+	size_t hist[256] = {0};
+	mm2c_anchor_t *q;
+	int d;
+	for (q = lo; q != hi; ++q) ++hist[(q->x >> shift) & 255];
+	for (d = 0, q = lo; d < 256; ++d) { bk[d].lo = q; q += hist[d]; bk[d].hi = q; }
+	for (d = 0; d < 256; ) {
+		int dst;
+		if (bk[d].lo == bk[d].hi) { ++d; continue; }
+		dst = (int)((bk[d].lo->x >> shift) & 255);
+		if (dst == d) { ++bk[d].lo; continue; }
+		{
+			mm2c_anchor_t hand = *bk[d].lo, next;
+			do {
+				next = *bk[dst].lo; *bk[dst].lo++ = hand; hand = next;
+				dst = (int)((hand.x >> shift) & 255);
+			} while (dst != d);
+			*bk[d].lo++ = hand;
+		}
+	}
+	if (shift == 0) return;
+	shift = shift > 8 ? shift - 8 : 0;
+	for (d = 0, q = lo; d < 256; ++d) {
+		mm2c_anchor_t *e = bk[d].hi;
+		if (e - q > 64) msd128(q, e, shift);
+		else if (e - q > 1) ins128(q, e);
+		q = e;
+	}
+}
+
+static void sort128x(mm2c_anchor_t *a, size_t n) { if (n <= 64) ins128(a, a + n); else msd128(a, a + n, 56); }
+
+/* keys of u[] are distinct (low word = anchor index), so any correct ascending sort equals radix_sort_64 */
+static int cmp_u64(const void *x, const void *y)
+{
+	uint64_t a = *(const uint64_t *)x, b = *(const uint64_t *)y;
+	return a < b ? -1 : a > b;
+}
+
+mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
+                           float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a, int *n_u_, uint64_t **_u,
+                           void *km, int tid)
+{
+	int32_t *f, *p, *t, *v, n_u, n_v, k;
+	int64_t i, j;
+	uint64_t *u, *u2, sum_qspan = 0;
+	float avg_qspan_scaled;
+	mm2c_anchor_t *b, *w;
+	mm2c_params_t par;
+
+	if (_u) *_u = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) { xfree(km, a); return 0; }                       /* chain.c:37-41 */
+	f = (int32_t *)xalloc(km, (size_t)n * 4); p = (int32_t *)xalloc(km, (size_t)n * 4);
+	t = (int32_t *)xalloc(km, (size_t)n * 4); v = (int32_t *)xalloc(km, (size_t)n * 4);
+
+	for (i = 0; i < n; ++i) sum_qspan += a[i].y >> 32 & 0xff;                /* chain.c:48-49 */
+	avg_qspan_scaled = (float)(.01 * (float)sum_qspan / n);
+
+	par.max_dist_x = max_dist_x; par.max_dist_y = max_dist_y; par.bw = bw;
+	par.max_skip = max_skip; par.max_iter = max_iter; par.gap_scale = gap_scale;
+	par.is_cdna = is_cdna; par.n_segs = n_segs; par.q_span_override = -1; par.flags = 0;
+	if (mm2c_chain_task_host(&par, n, a, avg_qspan_scaled, f, p, tid) != 0) { /* chain.c:103; errors as chain_hardware.cpp:208-235 */
+		fprintf(stderr, "Error: GPU chaining failed (n = %ld): %s\n", (long)n, mm2c_last_error());
+		exit(EXIT_FAILURE);
+	}
+	for (i = 0; i < n; ++i)                                                  /* chain.c:106-111 */
+		v[i] = (p[i] >= 0 && v[p[i]] > f[i]) ? v[p[i]] : f[i];
+
+	/* chain ends (chain.c:349-367) */
+	memset(t, 0, (size_t)n * 4);
+	for (i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
+	for (i = 0, n_u = 0; i < n; ++i) if (t[i] == 0 && v[i] >= min_sc) ++n_u;
+	if (n_u == 0) {
+		xfree(km, a); xfree(km, f); xfree(km, p); xfree(km, t); xfree(km, v);
+		return 0;
+	}
+	u = (uint64_t *)xalloc(km, (size_t)n_u * 8);
+	for (i = 0, n_u = 0; i < n; ++i) {
+		if (t[i] != 0 || v[i] < min_sc) continue;
+		for (j = i; j >= 0 && f[j] < v[j]; ) j = p[j];
+		if (j < 0) j = i;
+		u[n_u++] = (uint64_t)f[j] << 32 | (uint64_t)j;
+	}
+	qsort(u, (size_t)n_u, 8, cmp_u64);                                       /* chain.c:368 */
+	for (i = 0; i < n_u >> 1; ++i) { uint64_t s = u[i]; u[i] = u[n_u - i - 1]; u[n_u - i - 1] = s; }
+
+	/* backtrack (chain.c:375-390) */
+	memset(t, 0, (size_t)n * 4);
+	for (i = 0, n_v = 0, k = 0; i < n_u; ++i) {
+		const int32_t n_v0 = n_v, k0 = k, peak = (int32_t)(u[i] >> 32);
+		int32_t len;
+		j = (int32_t)u[i];
+		do { v[n_v++] = (int32_t)j; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+		len = n_v - n_v0;
+		if (j < 0) { if (len >= min_cnt) u[k++] = (uint64_t)peak << 32 | (uint32_t)len; }
+		else if (peak - f[j] >= min_sc) { if (len >= min_cnt) u[k++] = (uint64_t)(peak - f[j]) << 32 | (uint32_t)len; }
+		if (k0 == k) n_v = n_v0;
+	}
+	*n_u_ = n_u = k, *_u = u;
+	xfree(km, f); xfree(km, p); xfree(km, t);
+
+	/* emit (chain.c:397-402) and order chains by first x (chain.c:406-420) */
+	b = (mm2c_anchor_t *)xalloc(km, (size_t)n_v * sizeof(mm2c_anchor_t));
+	for (i = 0, k = 0; i < n_u; ++i) {
+		const int32_t k0 = k, ni = (int32_t)u[i];
+		for (j = 0; j < ni; ++j) b[k++] = a[v[k0 + (ni - j - 1)]];
+	}
+	xfree(km, v);
+	w = (mm2c_anchor_t *)xalloc(km, (size_t)n_u * sizeof(mm2c_anchor_t));
+	for (i = 0, k = 0; i < n_u; ++i) { w[i].x = b[k].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
+	sort128x(w, (size_t)n_u);
+	u2 = (uint64_t *)xalloc(km, (size_t)n_u * 8);
+	for (i = 0, k = 0; i < n_u; ++i) {
+		const int32_t src = (int32_t)w[i].y, cnt = (int32_t)u[src];
+		u2[i] = u[src];
+		memcpy(&a[k], &b[w[i].y >> 32], (size_t)cnt * sizeof(mm2c_anchor_t));
+		k += cnt;
+	}
+	if (n_u) memcpy(u, u2, (size_t)n_u * 8);
+	if (k) memcpy(b, a, (size_t)k * sizeof(mm2c_anchor_t));
+	xfree(km, a); xfree(km, w); xfree(km, u2);
+	return b;
+}

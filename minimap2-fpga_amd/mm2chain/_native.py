@@ -1,0 +1,79 @@
+"""ctypes binding of libmm2chain_hip.so (include/mm2chain.h).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmm2chain_hip.so")
+
+MM2C_F_IGNORE_SEG = 0x1
+MM2C_F_FORCE_GENERAL = 0x2
+
+
+class Params(C.Structure):
+    """mm2c_params_t"""
+    _fields_ = [("max_dist_x", C.c_int32), ("max_dist_y", C.c_int32), ("bw", C.c_int32),
+                ("max_skip", C.c_int32), ("max_iter", C.c_int32), ("gap_scale", C.c_float),
+                ("is_cdna", C.c_int32), ("n_segs", C.c_int32), ("q_span_override", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64)]
+
+
+# every symbol include/mm2chain.h declares with C linkage: name -> (restype, argtypes)
+C_SYMBOLS = {
+    "mm2c_init": (C.c_int, [C.c_int]),
+    "mm2c_shutdown": (None, []),
+    "mm2c_last_error": (C.c_char_p, []),
+    "mm2c_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "mm2c_tune": (C.c_int, [C.c_char_p, C.c_int]),
+    "mm2c_params_map_ont": (None, [C.POINTER(Params)]),
+    "mm2c_params_fpga_v2": (None, [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mm2c_plan_create": (C.c_void_p, [C.POINTER(Params), C.c_int64, C.c_void_p]),
+    "mm2c_plan_destroy": (None, [C.c_void_p]),
+    "mm2c_plan_total_anchors": (C.c_int64, [C.c_void_p]),
+    "mm2c_plan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mm2c_chain_batch_host": (C.c_int, [C.POINTER(Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_chain_task_host": (C.c_int, [C.POINTER(Params), C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
+    "mm_chain_dp": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                 C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
+    "mm2c_get_stats": (None, [C.POINTER(Stats)]),
+}
+# C++-linkage drop-in symbols the reference objects import (chain_hardware.h:68-71)
+CXX_SYMBOLS = {
+    "_Z18run_chaining_on_hwliiiifP7mm128_tPiS1_Phliff": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                                                   C.c_int, C.c_float, C.c_float]),
+    "_Z13hardware_initlPc": (C.c_bool, [C.c_long, C.c_char_p]),
+    "_Z7cleanupv": (None, []),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and type every entry point; raises if it is absent (no CPU path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `make -C minimap2-fpga_amd` (or __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in {**C_SYMBOLS, **CXX_SYMBOLS}.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Mm2cError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mm2c_last_error()
+        raise Mm2cError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's dispatch surface for the chaining DP, over the C ABI.
+
+ChainPlan   : a CSR batch of tasks resident in HBM (the throughput path; north-star "many reads in flight").
+chain_task  : one task from host memory, the extended run_chaining_on_hw (chain_hardware.h:68 + the five scalars).
+run_chaining_on_hw / hardware_init / cleanup : the reference's own entry points, called through their C++ symbols.
+mm_chain_dp : the whole reference function (mmpriv.h:65), DP on the GPU, epilogue on the host.
+torch is plumbing only: device memory, streams.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _native as N
+from .params import Params
+
+_inited = False
+
+
+def init(device=None):
+    """hardware_init equivalent (main.c:367).  Raises when no HIP device is usable."""
+    global _inited
+    lib = N.load()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    N.check(lib.mm2c_init(int(device)), "mm2c_init")
+    _inited = True
+
+
+def shutdown():
+    """cleanup() equivalent (main.c:430)"""
+    global _inited
+    if _inited:
+        N.load().mm2c_shutdown()
+        _inited = False
+
+
+def tune(key, value):
+    N.check(N.load().mm2c_tune(key.encode(), int(value)), "mm2c_tune")
+
+
+def device_info():
+    lib = N.load()
+    name = C.create_string_buffer(256)
+    cu, mem = C.c_int(0), C.c_size_t(0)
+    N.check(lib.mm2c_device_info(name, 256, C.byref(cu), C.byref(mem)), "mm2c_device_info")
+    return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ChainPlan:
+    """mm2c_plan_t: offsets + longest-first order + workspace on the device; run() enqueues the DP."""
+
+    def __init__(self, params: Params, offsets):
+        self.lib = N.load()
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+        self.n_tasks = off.size - 1
+        self.params = params
+        self.handle = self.lib.mm2c_plan_create(C.byref(params), self.n_tasks, _np_ptr(off))
+        if not self.handle:
+            N.check(-1, "mm2c_plan_create")
+        self.total = self.lib.mm2c_plan_total_anchors(self.handle)
+
+    def run(self, anchors: torch.Tensor, f: torch.Tensor, p: torch.Tensor, avg: torch.Tensor = None, stream=None):
+        """anchors: int64 [total, 2] on the GPU; f, p: int32 [total] on the GPU.  Asynchronous on `stream`
+        (default: torch's current stream, so torch.cuda.Event timing and torch.cuda.synchronize see it)."""
+        assert anchors.is_cuda and f.is_cuda and p.is_cuda, "HBM-resident path needs device tensors"
+        assert anchors.dtype == torch.int64 and anchors.is_contiguous() and anchors.numel() == 2 * self.total
+        assert f.dtype == torch.int32 and p.dtype == torch.int32 and f.numel() == self.total and p.numel() == self.total
+        if avg is not None:
+            assert avg.is_cuda and avg.dtype == torch.float32 and avg.numel() == self.n_tasks
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.mm2c_plan_run_device(self.handle, anchors.data_ptr(), avg.data_ptr() if avg is not None else None,
+                                              f.data_ptr(), p.data_ptr(), st), "mm2c_plan_run_device")
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            self.lib.mm2c_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def chain_batch_host(params: Params, offsets, anchors, avg=None):
+    """Whole batch from host numpy arrays (uint64 [total,2]); returns (f, p) int32 arrays.  PCIe included."""
+    lib = N.load()
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    total = int(off[-1] - off[0]) if off.size else 0
+    f = np.empty(int(off[-1]) if off.size else 0, dtype=np.int32)
+    p = np.empty_like(f)
+    avg_p = None
+    if avg is not None:
+        avg = np.ascontiguousarray(avg, dtype=np.float32)
+        avg_p = _np_ptr(avg)
+    N.check(lib.mm2c_chain_batch_host(C.byref(params), off.size - 1, _np_ptr(off), _np_ptr(a), avg_p, _np_ptr(f), _np_ptr(p)),
+            "mm2c_chain_batch_host")
+    del total
+    return f, p
+
+
+def chain_task(params: Params, anchors, avg_qspan_scaled, tid=0):
+    """One task, synchronous, stock-CPU (V1) semantics: the extended run_chaining_on_hw."""
+    lib = N.load()
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    n = a.shape[0]
+    f = np.empty(n, dtype=np.int32)
+    p = np.empty(n, dtype=np.int32)
+    N.check(lib.mm2c_chain_task_host(C.byref(params), n, _np_ptr(a), float(avg_qspan_scaled), _np_ptr(f), _np_ptr(p), tid),
+            "mm2c_chain_task_host")
+    return f, p
+
+
+def hardware_init(buf_size=0, binary_name=b""):
+    """the reference symbol bool hardware_init(long, char*) (chain_hardware.h:70)"""
+    return bool(getattr(N.load(), "_Z13hardware_initlPc")(buf_size, binary_name))
+
+
+def cleanup():
+    """the reference symbol void cleanup() (chain_hardware.h:71)"""
+    getattr(N.load(), "_Z7cleanupv")()
+
+
+def run_chaining_on_hw(n, max_dist_x, max_dist_y, bw, q_span, avg_qspan, anchors, num_subparts=None, total_subparts=0, tid=0,
+                       hw_time_pred=0.0, sw_time_pred=0.0):
+    """the reference symbol (chain_hardware.h:68), same argument order; returns (ret, f, p)"""
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    f = np.empty(n, dtype=np.int32)
+    p = np.empty(n, dtype=np.int32)
+    ns = _np_ptr(np.ascontiguousarray(num_subparts, dtype=np.uint8)) if num_subparts is not None else None
+    ret = getattr(N.load(), "_Z18run_chaining_on_hwliiiifP7mm128_tPiS1_Phliff")(
+        n, max_dist_x, max_dist_y, bw, q_span, avg_qspan, _np_ptr(a), _np_ptr(f), _np_ptr(p), ns, total_subparts, tid,
+        hw_time_pred, sw_time_pred)
+    return ret, f, p
+
+
+def mm_chain_dp(max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale, is_cdna, n_segs, anchors, tid=0):
+    """mm_chain_dp (mmpriv.h:65) through the library's host mirror.  km = NULL (malloc arena, as kalloc.c does).
+    Returns (u uint64 [n_u], b uint64 [sum cnt, 2])."""
+    lib = N.load()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    n = a.shape[0]
+    a_own = libc.malloc(max(n, 1) * 16)       # mm_chain_dp frees its input (chain.c:39,421)
+    C.memmove(a_own, a.ctypes.data, n * 16)
+    n_u = C.c_int(0)
+    u = C.c_void_p(0)
+    b = lib.mm_chain_dp(max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, gap_scale, is_cdna, n_segs,
+                        n, a_own if n else None, C.byref(n_u), C.byref(u), None, tid)
+    if n == 0:
+        libc.free(a_own)
+    if not b or n_u.value == 0:
+        if b:
+            libc.free(b)
+        if u.value:
+            libc.free(u)
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    u_np = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+    nb = int((u_np & 0xFFFFFFFF).sum())
+    b_np = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nb, 2)).copy()
+    libc.free(b)
+    libc.free(u)
+    return u_np, b_np

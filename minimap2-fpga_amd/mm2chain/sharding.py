@@ -1,0 +1,46 @@
+"""Read sharding across the GPUs of one node: tasks are independent (chain.c:42-45 touches
+only its own a/f/p), so each rank takes a subset, no data-path collective; one all-reduce of three counters at
+the end (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_tasks(task_sizes, world_size, rank):
+    """Greedy longest-processing-time partition on anchors per task; deterministic, identical on every rank.
+    Returns the sorted task indices of `rank`."""
+    sizes = np.asarray(task_sizes, dtype=np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(world_size, dtype=np.int64)
+    owner = np.empty(sizes.size, dtype=np.int32)
+    if sizes.size and np.all(sizes == sizes[0]):
+        owner[:] = np.arange(sizes.size) % world_size     # equal tasks: round robin (same result, O(n))
+    else:
+        for t in order:
+            r = int(np.argmin(load))
+            owner[t] = r
+            load[r] += sizes[t]
+    return np.nonzero(owner == rank)[0]
+
+
+def sub_batch(offsets, task_ids):
+    """CSR offsets of the chosen tasks plus the index ranges to gather their anchors."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n = offsets[1:] - offsets[:-1]
+    sel_n = n[task_ids]
+    new_off = np.zeros(len(task_ids) + 1, dtype=np.int64)
+    new_off[1:] = np.cumsum(sel_n)
+    return new_off, offsets[:-1][task_ids], sel_n
+
+
+def allreduce_counters(anchors, pairs, elapsed_ns, device=None):
+    """Sum {anchors chained, pairs evaluated (0 if untracked), elapsed ns} over ranks; max of elapsed too.
+    Returns (sum_anchors, sum_pairs, max_elapsed_ns)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(anchors), int(pairs), int(elapsed_ns)
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([int(anchors), int(pairs)], dtype=torch.int64, device=dev)
+    m = torch.tensor([int(elapsed_ns)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return int(t[0]), int(t[1]), int(m[0])

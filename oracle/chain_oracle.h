@@ -1,0 +1,71 @@
+/*
+ * chain_oracle.h -- CPU ORACLE for the minimap2 chaining hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a from-scratch plain-C restatement of the reference algorithm (kisarur/minimap2-fpga,
+ * minimap2 v2.18 + FPGA fork): chain.c (mm_chain_dp) and device/minimap2_opencl.cl.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or load it.  The shipped library
+ * (minimap2-fpga_amd/csrc) never calls into this file.
+ *
+ * PARITY PINNING STATUS: see DESIGN.md "Oracle pinning".  The reference's own chain.c cannot be built in
+ * this image (chain.c -> chain_hardware.h:6 -> xcl2.hpp:34 includes <CL/cl_ext_xilinx.h>, a Xilinx XRT
+ * vendor header that is absent), the reference tree holds no f[]/p[] known-answer vectors, so the DP
+ * restatement is pinned (a) by hand-derived known-answer cases from the recurrence, (b) by an independent
+ * literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree with the CPU restatement
+ * under V2 parameters, and (c) end-to-end through the reference's own non-path host sources + test FASTA
+ * (oracle/ref_host, PAF lines recorded in SURVEY.md section 4) when that harness is built.
+ */
+#ifndef MM2_CHAIN_ORACLE_H
+#define MM2_CHAIN_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same layout as mm128_t (minimap.h:53) */
+typedef struct { uint64_t x, y; } mm2o_anchor_t;
+
+typedef struct {
+	int32_t max_dist_x, max_dist_y, bw;  /* mm_chain_dp args 1-3 (mmpriv.h:65) */
+	int32_t max_skip, max_iter;          /* args 4-5 */
+	float   gap_scale;                   /* arg 8 */
+	int32_t is_cdna, n_segs;             /* args 9-10 */
+} mm2o_params_t;
+
+/* chain.c:48-49 */
+float mm2o_avg_qspan_scaled(int64_t n, const mm2o_anchor_t *a);
+
+/* chain.c:184-238 (twin at :113-163): V1 "stock SW" DP.  t[] is scratch (n ints), v may be NULL. */
+void mm2o_chain_fpv(const mm2o_params_t *par, int64_t n, const mm2o_anchor_t *a, float avg_qspan_scaled,
+                    int32_t *f, int32_t *p, int32_t *v, int32_t *t);
+
+/* chain.c:53-78: HW/SW prediction pass.  Returns total_subparts; *total_trip gets total_trip_count. */
+int64_t mm2o_predict(int64_t n, const mm2o_anchor_t *a, int32_t max_dist_x, uint8_t *num_subparts, int64_t *total_trip);
+
+/* chain.c:106-111: v[] from f[]/p[] after a device run */
+void mm2o_fill_v(int64_t n, const int32_t *f, const int32_t *p, int32_t *v);
+
+/* device/minimap2_opencl.cl:24-172: literal scalar emulation of the FPGA kernel control flow (V2). */
+void mm2o_chain_hw_literal(int64_t n, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t q_span,
+                           float avg_qspan_scaled, const mm2o_anchor_t *a, const uint8_t *num_subparts,
+                           int32_t *f, int32_t *p);
+
+/* chain.c:348-422 + ksort.h:101-151: chain ends, backtrack, chain emission.  Consumes f,p,v,t (t scratch).
+ * Returns number of chains n_u; *u_out (malloc'd, n_u entries, score<<32|cnt), *b_out (malloc'd, sum(cnt)
+ * anchors).  Caller frees both with free(). */
+int32_t mm2o_backtrack(int64_t n, const mm2o_anchor_t *a, int32_t min_cnt, int32_t min_sc,
+                       const int32_t *f, const int32_t *p, int32_t *v, int32_t *t,
+                       uint64_t **u_out, mm2o_anchor_t **b_out, int64_t *n_b_out);
+
+/* whole mm_chain_dp (chain.c:29-423), CPU only (the SW branch), malloc-backed.  Does NOT free a. */
+int32_t mm2o_mm_chain_dp(const mm2o_params_t *par, int32_t min_cnt, int32_t min_sc, int64_t n,
+                         const mm2o_anchor_t *a, uint64_t **u_out, mm2o_anchor_t **b_out, int64_t *n_b_out);
+
+/* timing helper for bench.py cpu_baseline: runs mm2o_chain_fpv over a CSR batch with n_threads pthreads
+ * (static round-robin over tasks, in the style of kt_for kthread.c:54).  Returns wall seconds. */
+double mm2o_bench_batch(const mm2o_params_t *par, int64_t n_tasks, const int64_t *offsets,
+                        const mm2o_anchor_t *a, int32_t *f, int32_t *p, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

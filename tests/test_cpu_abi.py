@@ -1,0 +1,72 @@
+"""CPU tests of the drop-in boundary: libmm2chain_hip.so loads, exports every symbol include/mm2chain.h declares plus
+the reference's three C++ symbols, and fails loudly (no CPU fallback) when there is no GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_c_functions():
+    src = open(os.path.join(ROOT, "include", "mm2chain.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(mm2c_[a-z0-9_]+|mm_chain_dp)\s*\(", src))
+    return names - {"mm2c_anchor_t", "mm2c_params_t", "mm2c_plan_t", "mm2c_stats_t"}
+
+
+def test_library_exports_every_declared_symbol():
+    from mm2chain import _native as N
+    lib = N.load()
+    declared = _declared_c_functions()
+    assert declared, "header parse failed"
+    assert declared == set(N.C_SYMBOLS), f"binding table and header differ: {declared ^ set(N.C_SYMBOLS)}"
+    for name in list(declared) + list(N.CXX_SYMBOLS):
+        assert getattr(lib, name) is not None
+    out = subprocess.check_output(["nm", "-D", "--defined-only", N.LIB_PATH], text=True)
+    for name in list(declared) + list(N.CXX_SYMBOLS):
+        assert re.search(rf"\bT {re.escape(name)}\b", out), f"{name} not exported"
+
+
+def test_presets_match_reference_options():
+    """options.c:24-31 (defaults), :83-86 (ava-ont); chain_hardware.h:58-60 (V2 look-back 128*8)"""
+    import ctypes as C
+    from mm2chain import _native as N, params
+    lib = N.load()
+    p = N.Params()
+    lib.mm2c_params_map_ont(C.byref(p))
+    assert (p.max_dist_x, p.max_dist_y, p.bw, p.max_skip, p.max_iter, p.gap_scale, p.is_cdna, p.n_segs) == (5000, 5000, 500, 25, 5000, 1.0, 0, 1)
+    assert params.as_dict(params.map_ont()) == params.as_dict(p)
+    lib.mm2c_params_fpga_v2(C.byref(p), 5000, 4000, 500, 19)
+    assert (p.max_skip, p.max_iter, p.q_span_override, p.flags & N.MM2C_F_IGNORE_SEG, p.max_dist_y) == (2**31 - 1, 1024, 19, 1, 4000)
+    a = params.ava_ont()
+    assert (a.max_dist_x, a.bw) == (10000, 2000)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    import mm2chain
+    from mm2chain import params
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.init()
+    a = np.zeros((4, 2), np.uint64)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.chain_task(params.map_ont(), a, 0.15)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.chain_batch_host(params.map_ont(), [0, 4], a)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.ChainPlan(params.map_ont(), [0, 4])
+    assert mm2chain.hardware_init() is False          # main.c:367-369 then returns -1
+
+
+def test_argument_validation_happens_before_any_device_work():
+    import mm2chain
+    from mm2chain import params
+    bad = params.make_params(max_dist_x=-1)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.ChainPlan(bad, [0, 4])
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.chain_batch_host(params.map_ont(), [0, 4, 2], np.zeros((4, 2), np.uint64))

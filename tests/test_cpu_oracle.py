@@ -1,0 +1,204 @@
+"""CPU tests (-m "not gpu"): the oracle against hand-derived known answers, an independent pure-Python restatement,
+the literal FPGA-kernel emulation, the wave-parallel formulation model, and the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from helpers import mk_anchor, pack
+from wave_model import chain_wave_model
+
+INT32_MAX = 2**31 - 1
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class P:  # plain parameter holder with the oracle's field names
+    def __init__(self, **kw):
+        d = dict(max_dist_x=5000, max_dist_y=5000, bw=500, max_skip=25, max_iter=5000, gap_scale=1.0, is_cdna=0, n_segs=1)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+def py_chain(par, a, avg):
+    """independent literal restatement in Python, written from the recurrence in tex/minimap2.tex:105-150 and
+    chain.c:184-238 (small inputs only)"""
+    import math
+    n = a.shape[0]
+    f = [0] * n; p = [-1] * n; t = [0] * n
+    st = 0
+    f32 = np.float32
+    for i in range(n):
+        xi = int(a[i, 0]); yi = int(a[i, 1])
+        qi = (yi & 0xFFFFFFFF); qi = qi - (1 << 32) if qi >= (1 << 31) else qi
+        span = (yi >> 32) & 0xff; segi = (yi >> 48) & 0xff
+        while st < i and xi > int(a[st, 0]) + par.max_dist_x:
+            st += 1
+        if i - st > par.max_iter:
+            st = i - par.max_iter
+        best, bj, nskip = span, -1, 0
+        for j in range(i - 1, st - 1, -1):
+            xj = int(a[j, 0]); yj = int(a[j, 1])
+            qj = (yj & 0xFFFFFFFF); qj = qj - (1 << 32) if qj >= (1 << 31) else qj
+            segj = (yj >> 48) & 0xff
+            dr = xi - xj; dq = qi - qj; same = segi == segj
+            if (same and dr == 0) or dq <= 0: continue
+            if (same and dq > par.max_dist_y) or dq > par.max_dist_x: continue
+            dd = abs(dr - dq)
+            if same and dd > par.bw: continue
+            if par.n_segs > 1 and not par.is_cdna and same and dr > par.max_dist_y: continue
+            sc = min(dq, dr, span)
+            lg = dd.bit_length() - 1 if dd else 0
+            lin = int(f32(dd) * f32(avg))
+            if par.is_cdna or not same:
+                if not same and dr == 0: sc += 1; gap = 0
+                elif dr > dq or not same: gap = min(lin, lg)
+                else: gap = lin + (lg >> 1)
+            else:
+                gap = lin + (lg >> 1)
+            sc -= int(float(gap) * float(f32(par.gap_scale)) + .499)
+            sc += f[j]
+            if sc > best:
+                best, bj = sc, j
+                if nskip > 0: nskip -= 1
+            elif t[j] == i + 1:
+                nskip += 1
+                if nskip > par.max_skip: break
+            if p[j] >= 0: t[p[j]] = i + 1
+        f[i], p[i] = best, bj
+    return np.array(f, np.int32), np.array(p, np.int32)
+
+
+def test_known_answers_by_hand():
+    """three colinear anchors, span 15, avg = .15: worked by hand from chain.c:207-220.
+    a0 (r=1000,q=100): f=15.  a1 (r=1010,q=110): dr=dq=10, dd=0 -> sc=10+15=25, p=0.
+    a2 (r=1040,q=138): vs a1 dr=30,dq=28,dd=2: min(28,30,15)=15, cost=(int)(2*.15)+(1>>1)=0 -> 15+25=40;
+                       vs a0 dr=40,dq=38,dd=2 -> 15+15=30.  f=40,p=1."""
+    a = pack([mk_anchor(0, 0, 1000, 100), mk_anchor(0, 0, 1010, 110), mk_anchor(0, 0, 1040, 138)])
+    assert abs(ob.avg_qspan(a) - 0.15) < 1e-7
+    f, p, v = ob.chain_fpv(P(), a)
+    assert f.tolist() == [15, 25, 40] and p.tolist() == [-1, 0, 1] and v.tolist() == [15, 25, 40]
+    # a gap: a3 (r=1300,q=300): vs a2 dr=260,dq=162,dd=98: sc=15, cost=(int)(98*.15)=14 + (6>>1)=3 -> 15-17+40=38, p=2
+    a = pack([mk_anchor(0, 0, 1000, 100), mk_anchor(0, 0, 1010, 110), mk_anchor(0, 0, 1040, 138), mk_anchor(0, 0, 1300, 300)])
+    f, p, v = ob.chain_fpv(P(), a)
+    assert f.tolist() == [15, 25, 40, 38] and p.tolist() == [-1, 0, 1, 2] and v.tolist() == [15, 25, 40, 40]
+
+
+def test_hazards_by_hand():
+    # dq <= 0 and dr == 0 are skipped (chain.c:202); dd > bw skipped (:205); other strand / reference never chains
+    a = pack([mk_anchor(0, 0, 1000, 100), mk_anchor(0, 0, 1000, 120), mk_anchor(0, 0, 1020, 100),
+              mk_anchor(0, 0, 2000, 400), mk_anchor(1, 0, 1010, 110), mk_anchor(0, 1, 1010, 110)])
+    f, p, _ = ob.chain_fpv(P(), a)
+    # sorted order: (0,0,1000,100) (0,0,1000,120) (0,0,1020,100) (0,0,2000,400) (0,1,1010,110) (1,0,1010,110)
+    assert p[1] == -1 and p[2] == -1 and p[4] == -1 and p[5] == -1
+    assert p[3] == -1 and f[3] == 15          # dr=980..1000, dq=280..300: dd=700 > bw
+    # tie: two predecessors with the same score -> the nearer (larger j) wins (chain.c:226 strict >)
+    a = pack([mk_anchor(0, 0, 1000, 100), mk_anchor(0, 0, 1001, 101), mk_anchor(0, 0, 1100, 200)])
+    f, p, _ = ob.chain_fpv(P(max_skip=INT32_MAX), a)
+    assert f[1] == 16 and p[1] == 0
+    # candidates for a2: via a1 -> 15 - cost(dd=0) + 16 = 31 ; via a0 -> 15 + 15 = 30
+    assert f[2] == 31 and p[2] == 1
+    # sc == q_span must not set p (strict >): one predecessor whose extension scores exactly span
+    a = pack([mk_anchor(0, 0, 1000, 100), mk_anchor(0, 0, 1400, 420)])   # dd=80: cost=(int)(80*.15)=12 + (6>>1)=3 = 15 -> 15-15+15 = 15
+    f, p, _ = ob.chain_fpv(P(), a)
+    assert f.tolist() == [15, 15] and p.tolist() == [-1, -1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_equals_python_restatement(seed):
+    rng = np.random.default_rng(seed)
+    par = P(max_skip=int(rng.choice([0, 2, 25, INT32_MAX])), max_iter=int(rng.choice([20, 100, 5000])),
+            gap_scale=float(rng.choice([1.0, 0.8, 1.3])), bw=int(rng.choice([100, 500])),
+            is_cdna=int(rng.integers(0, 2)), n_segs=int(rng.integers(1, 3)), max_dist_x=int(rng.choice([300, 5000])),
+            max_dist_y=int(rng.choice([300, 5000])))
+    rows, pos, q = [], 5000, 200
+    for _ in range(400):
+        pos += int(rng.integers(0, 25)); q += int(rng.integers(-15, 35))
+        rows.append(mk_anchor(int(rng.integers(0, 2)) if rng.random() < .02 else 0, 1, pos, max(q, 1),
+                              span=int(rng.integers(10, 25)), seg=int(rng.integers(0, par.n_segs))))
+    a = pack(rows)
+    avg = ob.avg_qspan(a)
+    f, p, _ = ob.chain_fpv(par, a, avg)
+    f2, p2 = py_chain(par, a, avg)
+    assert np.array_equal(f, f2) and np.array_equal(p, p2)
+
+
+def _stream(profile, n_reads, n_per, seed, **kw):
+    from mm2chain import synth
+    off, a = synth.make_stream(profile, n_reads, n_per, seed=seed, **kw)
+    return off.numpy(), a.numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("profile", ["sparse", "mixed", "dense", "colinear"])
+def test_wave_formulation_model_equals_oracle(profile):
+    """the chunked / prefix-scan formulation the HIP kernel implements, incl. ring aliasing and the far path"""
+    off, a = _stream(profile, 2, 900, seed=4)
+    for par, R in ((P(), 128), (P(max_skip=2, max_iter=300), 256), (P(max_skip=INT32_MAX, max_iter=150), 128)):
+        for k in range(2):
+            t = a[off[k]:off[k + 1]]
+            avg = ob.avg_qspan(t)
+            f, p, _ = ob.chain_fpv(par, t, avg)
+            fm, pm = chain_wave_model(par, t, avg, R=R)
+            assert np.array_equal(f, fm) and np.array_equal(p, pm)
+
+
+def test_fpga_literal_equals_v1_with_v2_parameters():
+    """device/minimap2_opencl.cl emulated literally == chain.c loop with max_skip=inf, max_iter=1024"""
+    off, a = _stream("dense", 2, 2500, seed=8, locus=9000)
+    for k in range(2):
+        t = a[off[k]:off[k + 1]]
+        avg = ob.avg_qspan(t)
+        f_lit, p_lit = ob.chain_hw_literal(5000, 5000, 500, 15, avg, t)
+        f, p, _ = ob.chain_fpv(P(max_skip=INT32_MAX, max_iter=1024), t, avg)
+        assert np.array_equal(f, f_lit) and np.array_equal(p, p_lit)
+        ns, tot, trip = ob.predict(t, 5000)
+        assert tot == int(ns.sum()) and ns.min() >= 1 and ns.max() <= 8 and trip <= 1024 * t.shape[0]
+
+
+def test_radix_sort_restatement():
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    lib = ob.load()
+    for n in (0, 1, 5, 64, 65, 1000, 70000):
+        u = rng.integers(0, 2**63, n, dtype=np.uint64)
+        v = u.copy()
+        lib.mm2o_radix_sort_64(v.ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(v, np.sort(u))
+        w = np.stack((rng.integers(0, 50, n).astype(np.uint64) << np.uint64(20), np.arange(n, dtype=np.uint64)), 1)
+        w = np.ascontiguousarray(w); w0 = w.copy()
+        lib.mm2o_radix_sort_128x(w.ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(w[:, 0], np.sort(w0[:, 0])) and np.array_equal(np.sort(w[:, 1]), np.arange(n, dtype=np.uint64))
+        if n <= 64:   # insertion sort is stable
+            assert np.array_equal(w, w0[np.argsort(w0[:, 0], kind="stable")])
+
+
+def test_mm_chain_dp_oracle_properties():
+    off, a = _stream("mixed", 3, 2500, seed=12)
+    for k in range(3):
+        t = a[off[k]:off[k + 1]]
+        u, b = ob.mm_chain_dp(P(), 3, 40, t)
+        cnt = (u & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        assert b.shape[0] == cnt.sum() and (cnt >= 3).all() and ((u >> np.uint64(32)) >= 40).all()
+        # chains are emitted in ascending x of their first anchor, anchors inside a chain ascending in x and q
+        starts = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+        assert (np.diff(b[starts, 0].astype(object)) >= 0).all()
+        for s, c in zip(starts, cnt):
+            seg = b[s:s + c]
+            assert (np.diff(seg[:, 0].astype(object)) >= 0).all()
+            assert (np.diff((seg[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)) > 0).all()
+        # every chained anchor is an input anchor
+        keys = set(map(tuple, t.tolist()))
+        assert all(tuple(r) in keys for r in b.tolist())
+
+
+def test_golden_fixtures():
+    """committed vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle; see the README there)"""
+    files = sorted(x for x in os.listdir(GOLDEN) if x.endswith(".npz"))
+    assert files, "no golden fixtures"
+    for name in files:
+        z = np.load(os.path.join(GOLDEN, name))
+        par = P(**{k: (float(z["par_" + k]) if k == "gap_scale" else int(z["par_" + k])) for k in
+                   ("max_dist_x", "max_dist_y", "bw", "max_skip", "max_iter", "gap_scale", "is_cdna", "n_segs")})
+        off, a = z["offsets"], z["anchors"]
+        f, p, _ = ob.chain_batch(par, off, a, 2)
+        assert np.array_equal(f, z["f"]) and np.array_equal(p, z["p"]), name

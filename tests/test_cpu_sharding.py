@@ -1,0 +1,72 @@
+"""Read sharding over ranks: partition properties, and a world_size-2 gloo run of the counter
+all-reduce with per-rank work done by the oracle standing in for the GPU."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shard_tasks_partition_and_balance():
+    from mm2chain import sharding
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(100, 9000, 1000)
+    for ws in (1, 2, 4, 8):
+        parts = [sharding.shard_tasks(sizes, ws, r) for r in range(ws)]
+        allt = np.sort(np.concatenate(parts))
+        assert np.array_equal(allt, np.arange(1000))
+        loads = np.array([sizes[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= sizes.max()
+    eq = np.full(1000, 5000)
+    parts = [sharding.shard_tasks(eq, 8, r) for r in range(8)]
+    assert all(len(p) == 125 for p in parts)
+    off = np.concatenate(([0], np.cumsum(sizes)))
+    new_off, starts, ns = sharding.sub_batch(off, parts[3][:10])
+    assert new_off[-1] == ns.sum() and np.array_equal(starts, off[:-1][parts[3][:10]])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "minimap2-fpga_amd")); sys.path.insert(0, os.path.join(root, "tests"))
+    from mm2chain import sharding, synth, params
+    import oracle_binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, a = synth.make_stream("mixed", 24, (200, 900), seed=3)     # same stream on every rank (deterministic)
+    off = off.numpy(); a = a.numpy().view(np.uint64)
+    mine = sharding.shard_tasks(off[1:] - off[:-1], world, rank)
+    new_off, starts, ns = sharding.sub_batch(off, mine)
+    idx = np.concatenate([np.arange(s, s + n) for s, n in zip(starts, ns)]) if len(mine) else np.zeros(0, np.int64)
+    f, p, secs = ob.chain_batch(params.map_ont(), new_off, a[idx], 1)
+    tot, _, mx = sharding.allreduce_counters(int(ns.sum()), 0, int(secs * 1e9))
+    q.put((rank, mine.tolist(), int(f.astype(np.int64).sum()), tot, mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_cover_the_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs: p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    res.sort()
+    from mm2chain import synth, params
+    import oracle_binding as ob
+    off, a = synth.make_stream("mixed", 24, (200, 900), seed=3)
+    f, _, _ = ob.chain_batch(params.map_ont(), off.numpy(), a.numpy().view(np.uint64), 1)
+    assert sorted(res[0][1] + res[1][1]) == list(range(24))
+    assert res[0][3] == res[1][3] == int(off[-1])                      # all-reduced anchor count = whole batch
+    assert res[0][2] + res[1][2] == int(f.astype(np.int64).sum())      # the two shards together reproduce the whole
+    assert res[0][4] == res[1][4] > 0

@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP kernel, called through the C ABI, must equal the CPU oracle bit for bit (f[] and p[]).
+Reference path: chain.c:184-238 (V1) and device/minimap2_opencl.cl (V2)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_binding as ob
+from helpers import mk_anchor, pack, oracle_batch, gpu_batch, assert_same
+
+pytestmark = pytest.mark.gpu
+
+INT32_MAX = 2**31 - 1
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    import mm2chain
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    mm2chain.init()
+    yield
+    mm2chain.shutdown()
+
+
+def _stream(profile, n_reads, n_per, seed, **kw):
+    from mm2chain import synth
+    off, a = synth.make_stream(profile, n_reads, n_per, seed=seed, **kw)
+    return off.numpy(), a.numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("profile", ["sparse", "mixed", "dense", "colinear"])
+def test_profiles_map_ont(profile):
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream(profile, 96, 3000, seed=11)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, profile)
+
+
+def test_ragged_and_tiny_tasks():
+    from mm2chain import params, synth
+    P = params.map_ont()
+    parts = []
+    sizes = [0, 1, 2, 63, 64, 65, 127, 128, 129, 0, 500, 1, 0]
+    for k, n in enumerate(sizes):
+        if n:
+            _, a = synth.make_stream("dense", 1, n, seed=100 + k)
+            parts.append(a.numpy().view(np.uint64))
+    a = np.concatenate(parts)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "ragged")
+
+
+@pytest.mark.parametrize("max_skip,max_iter,gap_scale,bw", [
+    (0, 5000, 1.0, 500), (3, 5000, 1.0, 500), (25, 200, 1.0, 500), (25, 50, 0.8, 500), (INT32_MAX, 1024, 1.0, 500),
+    (25, 5000, 1.37, 100), (1, 64, 1.0, 2000), (25, 63, 1.0, 500), (25, 65, 1.0, 500), (INT32_MAX, 5000, 0.8, 500)])
+def test_parameter_corners(max_skip, max_iter, gap_scale, bw):
+    from mm2chain import params
+    P = params.make_params(max_skip=max_skip, max_iter=max_iter, gap_scale=gap_scale, bw=bw)
+    off, a = _stream("dense", 24, (300, 2500), seed=5)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, f"corner {max_skip},{max_iter},{gap_scale},{bw}")
+
+
+@pytest.mark.parametrize("ring_class", [0, 1, 2])
+def test_ring_classes_and_far_lookback(ring_class):
+    """look-back far beyond the LDS ring: a very dense locus (window ~ max_iter) with the early exit mostly disabled"""
+    import mm2chain
+    from mm2chain import params
+    mm2chain.tune("ring_class", ring_class)
+    try:
+        for P in (params.make_params(max_skip=400, max_iter=3000), params.map_ont(), params.make_params(max_skip=INT32_MAX, max_iter=1500)):
+            off, a = _stream("dense", 6, 4000, seed=21, locus=6000)
+            f_ref, p_ref = oracle_batch(P, off, a)
+            f, p = gpu_batch(P, off, a)
+            assert_same(f, p, f_ref, p_ref, off, f"ring {ring_class}")
+    finally:
+        mm2chain.tune("ring_class", 0)
+
+
+def test_ava_ont_and_asm20_shapes():
+    from mm2chain import params
+    for P, span in ((params.ava_ont(), 15), (params.asm20(), 19)):
+        off, a = _stream("mixed", 16, (2000, 6000), seed=9, q_span=span)
+        f_ref, p_ref = oracle_batch(P, off, a)
+        f, p = gpu_batch(P, off, a)
+        assert_same(f, p, f_ref, p_ref, off, f"span {span}")
+
+
+def _multiseg_task(rng, n, n_segs):
+    rows = []
+    pos = 1 << 20
+    q = 100
+    for _ in range(n):
+        pos += int(rng.integers(0, 40))          # includes dr == 0 between segments
+        q += int(rng.integers(-30, 60))
+        rows.append(mk_anchor(0, 3, pos, max(q, 1), span=int(rng.integers(10, 30)), seg=int(rng.integers(0, n_segs))))
+    return pack(rows)
+
+
+@pytest.mark.parametrize("is_cdna,n_segs", [(0, 2), (1, 1), (1, 2), (0, 3)])
+def test_general_variant_segments_and_cdna(is_cdna, n_segs):
+    """chain.c:206,211-217: multi-segment (sr) and cDNA branches, non-uniform spans"""
+    from mm2chain import params
+    rng = np.random.default_rng(7 + is_cdna * 10 + n_segs)
+    P = params.make_params(max_dist_x=800, max_dist_y=800, bw=300, is_cdna=is_cdna, n_segs=n_segs, max_skip=5)
+    tasks = [_multiseg_task(rng, int(rng.integers(50, 900)), n_segs) for _ in range(12)]
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "general")
+
+
+def test_simple_variant_detects_foreign_segment_ids():
+    """n_segs == 1 but anchors carry different segment ids: the simple kernel flags the task, the general one redoes it"""
+    from mm2chain import params
+    rng = np.random.default_rng(3)
+    P = params.make_params(max_dist_x=800, max_dist_y=800, bw=300)
+    tasks = [_multiseg_task(rng, 400, 1), _multiseg_task(rng, 700, 2), _multiseg_task(rng, 300, 1)]
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "seg detect")
+
+
+def test_strand_and_reference_boundaries_inside_a_task():
+    from mm2chain import params
+    rows = []
+    for strand in (0, 1):
+        for rid in (0, 1, 5):
+            for k in range(150):
+                rows.append(mk_anchor(strand, rid, 1000 + 11 * k, 50 + 11 * k + (k % 3)))
+    # anchors at the very start of a reference and identical x
+    rows += [mk_anchor(0, 7, 0, 20), mk_anchor(0, 7, 0, 40), mk_anchor(0, 7, 5, 60), mk_anchor(0, 7, 5, 60)]
+    a = pack(rows)
+    off = np.array([0, a.shape[0]], dtype=np.int64)
+    P = params.map_ont()
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "boundaries")
+
+
+def test_avg_qspan_in_kernel_matches_host_value():
+    """spans non-uniform and a sum above 2^24 so that the u64 -> f32 rounding of chain.c:49 matters"""
+    from mm2chain import params
+    rng = np.random.default_rng(1)
+    n = 120000
+    pos = np.cumsum(rng.integers(1, 30, n)) + (1 << 20)
+    q = np.cumsum(rng.integers(1, 30, n)) + 50
+    span = rng.integers(100, 256, n)
+    x = (np.uint64(2) << np.uint64(32)) | pos.astype(np.uint64)
+    y = (span.astype(np.uint64) << np.uint64(32)) | q.astype(np.uint64)
+    a = np.stack((x, y), 1)
+    off = np.array([0, n], dtype=np.int64)
+    P = params.map_ont()
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f1, p1 = gpu_batch(P, off, a)                                        # avg computed in the kernel
+    f2, p2 = gpu_batch(P, off, a, avg=[ob.avg_qspan(a)])                # avg handed in
+    assert_same(f1, p1, f_ref, p_ref, off, "avg in kernel")
+    assert_same(f2, p2, f_ref, p_ref, off, "avg from host")
+
+
+def test_fpga_v2_through_the_reference_symbol():
+    """run_chaining_on_hw (chain_hardware.h:68) == literal emulation of the .cl kernel == oracle V1(max_skip=inf, max_iter=1024)"""
+    import mm2chain
+    from mm2chain import params
+    off, a = _stream("dense", 3, 3000, seed=17, locus=9000)
+    for k in range(3):
+        t = a[off[k]:off[k + 1]]
+        avg = ob.avg_qspan(t)
+        ns, tot, _ = ob.predict(t, 5000)
+        ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, ns, tot, tid=k)
+        assert ret == 0
+        f_lit, p_lit = ob.chain_hw_literal(5000, 5000, 500, 15, avg, t)
+        assert_same(f, p, f_lit, p_lit, None, "v2 literal")
+        f_v1, p_v1, _ = ob.chain_fpv(params.make_params(max_skip=INT32_MAX, max_iter=1024), t, avg)
+        assert_same(f, p, f_v1, p_v1, None, "v2 as v1")
+
+
+def test_host_paths_and_mm_chain_dp():
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 5, (500, 3000), seed=31)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = mm2chain.chain_batch_host(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "batch host")
+    for k in range(5):
+        t = a[off[k]:off[k + 1]]
+        f1, p1 = mm2chain.chain_task(P, t, ob.avg_qspan(t), tid=k)
+        assert_same(f1, p1, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, "task host")
+        u, b = mm2chain.mm_chain_dp(5000, 5000, 500, 25, 5000, 3, 40, 1.0, 0, 1, t)
+        u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, t)
+        assert np.array_equal(u, u_ref) and np.array_equal(b, b_ref), "mm_chain_dp chains differ"
+    u, b = mm2chain.mm_chain_dp(5000, 5000, 500, 25, 5000, 3, 40, 1.0, 0, 1, np.zeros((0, 2), np.uint64))
+    assert u.size == 0 and b.size == 0
+
+
+def test_full_size_properties():
+    """BASELINE config-2 size (5000 anchors per read, many reads): properties that need no oracle at full size, plus a
+    sampled oracle check.  f[i] >= span, -1 <= p[i] < i, f[i] - f[p[i]] <= span, replicated tasks give replicated output."""
+    from mm2chain import params, synth
+    P = params.map_ont()
+    off1, a1 = synth.make_stream("mixed", 512, 5000, seed=2, device="cuda")
+    off, a = synth.replicate(off1, a1, 8)
+    import mm2chain
+    total = a.shape[0]
+    d_f = torch.empty(total, dtype=torch.int32, device="cuda"); d_p = torch.empty_like(d_f)
+    plan = mm2chain.ChainPlan(P, off.numpy())
+    plan.run(a, d_f, d_p)
+    torch.cuda.synchronize()
+    f = d_f.view(8, -1); p = d_p.view(8, -1)
+    assert bool((f == f[0]).all()) and bool((p == p[0]).all()), "replicas differ"
+    f0 = d_f[: total // 8].cpu().numpy(); p0 = d_p[: total // 8].cpu().numpy()
+    idx = np.arange(f0.size) % 5000
+    assert (f0 >= 15).all() and (p0 >= -1).all() and (p0 < idx).all()
+    has = p0 >= 0
+    base = (np.arange(f0.size) // 5000) * 5000
+    assert (f0[has] - f0[(base + p0)[has]] <= 15).all()
+    a_np = a1.cpu().numpy().view(np.uint64); off_np = off1.numpy()
+    sel = slice(0, int(off_np[16]))
+    f_ref, p_ref = oracle_batch(P, off_np[:17], a_np[sel])
+    assert_same(f0[sel], p0[sel], f_ref, p_ref, off_np[:17], "full-size sample")
