@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- anchors/s chained on synthetic ONT anchor streams (BASELINE.json config 2), HBM-resident.
+
+One "step" = one pass of the chaining DP (f[], p[] for every anchor) over one CSR batch of synthetic reads that is
+already resident in HBM.  N GPUs = N processes (torch.distributed / RCCL), reads sharded with no data-path
+collective (weak scaling: the per-GPU batch is fixed); one all-reduce of counters at the end.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` prices the dominant kernel against HBM with
+24 algorithmic bytes per anchor (16 B mm128_t read + 4 B f + 4 B p written); `cpu_baseline` times the
+CPU oracle (a port of chain.c's loop) on the host cores over a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALGO_BYTES_PER_ANCHOR = 24          # 16 B read + 4 B f + 4 B p
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--profile", default="mixed", choices=["sparse", "mixed", "dense", "colinear"])
+    ap.add_argument("--reads", type=int, default=65536, help="reads (tasks) per GPU per step")
+    ap.add_argument("--distinct", type=int, default=8192, help="distinct synthetic reads generated; tiled up to --reads")
+    ap.add_argument("--anchors-per-read", type=int, default=5000)
+    ap.add_argument("--seed", type=int, default=20240)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--ring-class", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+
+    import mm2chain
+    from mm2chain import synth, params, sharding
+    mm2chain.init(torch.cuda.current_device())
+    if args.ring_class is not None:
+        mm2chain.tune("ring_class", args.ring_class)
+    P = params.map_ont()                                       # max_iter = 5000, max_skip = 25 (options.c:29-30)
+
+    # ---- synthetic batch of this rank, generated on the device (deterministic: splitmix64 of seed + rank)
+    distinct = min(args.distinct, args.reads)
+    times = max(1, args.reads // distinct)
+    off1, a1 = synth.make_stream(args.profile, distinct, args.anchors_per_read, seed=args.seed + rank, device="cuda")
+    off, anchors = synth.replicate(off1, a1, times)
+    n_tasks = off.numel() - 1
+    total = int(off[-1])
+    d_f = torch.empty(total, dtype=torch.int32, device="cuda")
+    d_p = torch.empty_like(d_f)
+    plan = mm2chain.ChainPlan(P, off.numpy())
+    torch.cuda.synchronize()
+
+    def step():
+        plan.run(anchors, d_f, d_p)                             # on torch's current stream
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(plan.last_kernel_ms())                 # HIP events on the launch stream, recorded by the library
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    tot_anchors, _, max_ns = sharding.allreduce_counters(total * args.steps, 0, int(elapsed * 1e9))
+    wall = max_ns / 1e9
+
+    # ---- correctness of what was just timed: a sample of tasks against the oracle (outside the timed region)
+    import oracle_binding as ob
+    n_check = min(64, distinct)
+    end = int(off1[n_check])
+    f_ref, p_ref, _ = ob.chain_batch(P, off1[: n_check + 1].numpy(), a1[:end].cpu().numpy().view(np.uint64), min(8, os.cpu_count() or 1))
+    verified = bool(np.array_equal(d_f[:end].cpu().numpy(), f_ref) and np.array_equal(d_p[:end].cpu().numpy(), p_ref))
+    last = total - int(off1[-1])                                # the last replica must equal the first one
+    verified = verified and bool(torch.equal(d_f[last:], d_f[: int(off1[-1])]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    k_avg_ms = float(np.mean(kernel_ms))
+    achieved = total * ALGO_BYTES_PER_ANCHOR / (k_avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "anchors/sec chained", "value": tot_anchors / wall, "unit": "anchors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": f"synthetic ONT anchor stream ({args.profile}), {args.anchors_per_read} anchors/read, "
+                               f"map-ont chaining params (max_iter=5000, max_skip=25), HBM-resident",
+                   "reads_per_gpu_per_step": n_tasks, "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
+                   "profile": args.profile, "parallelism": f"read-sharded x{world}"},
+        "verified_vs_oracle": verified,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "chain_dp_wave", "kernel_ms_avg": k_avg_ms,
+                     "algorithmic_bytes_per_launch": total * ALGO_BYTES_PER_ANCHOR},
+    }
+
+    # ---- CPU baseline: the oracle (port of chain.c:184-238) on the host cores, bounded sample of the same batch
+    if args.cpu_seconds > 0:
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        off_np = off1.numpy()
+        a_np = a1.cpu().numpy().view(np.uint64)
+        probe = min(distinct, 4 * cores)
+        _, _, s = ob.chain_batch(P, off_np[: probe + 1], a_np[: int(off_np[probe])], cores)
+        rate = int(off_np[probe]) / max(s, 1e-6)
+        n_s = int(max(cores, min(distinct, rate * args.cpu_seconds / args.anchors_per_read)))
+        _, _, s_all = ob.chain_batch(P, off_np[: n_s + 1], a_np[: int(off_np[n_s])], cores)
+        n1 = int(max(1, min(n_s, n_s // cores)))
+        _, _, s_one = ob.chain_batch(P, off_np[: n1 + 1], a_np[: int(off_np[n1])], 1)
+        out["cpu_baseline"] = {"value": int(off_np[n_s]) / s_all, "unit": "anchors/s", "cores": cores, "kind": "port",
+                               "sample": f"first {n_s} reads of the same batch ({int(off_np[n_s])} anchors), one task per thread "
+                                         f"round-robin, {s_all:.1f} s wall",
+                               "value_1thread": int(off_np[n1]) / s_one}
+    print(json.dumps(out))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

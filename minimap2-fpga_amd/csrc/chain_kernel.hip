@@ -16,12 +16,17 @@
 //     DPP wave_shr:1, so the i -> i+1 dependency never goes through memory.
 //   * chunks 1.. read an LDS ring (x, q | f, p as two ds_read_b64 per lane, conflict-free); anchors enter
 //     the ring in coalesced 1 KiB tiles (one global_load_dwordx4 per lane per 64 anchors, next tile
-//     prefetched while the current one is processed).  Only look-back beyond the ring goes to L2/HBM.
-//   * the max_skip rule is order dependent.  Per chunk it is evaluated with two DPP prefix scans:
-//     a prefix max (which lanes raise the running best) and a max-plus scan of the skip counter
-//     (n -> max(n-1,0) on a new best, n -> n+1 on a "predecessor already on a visited chain" event;
-//     both are of the form n -> max(n+a, b) and compose), then the first lane whose counter exceeds
-//     max_skip is the reference's `break`.
+//     prefetched while the current one is processed), f/p enter it once per tile.  Only look-back beyond
+//     the ring goes to L2/HBM, and there f/p/stamps are fetched only when some lane passes the filters.
+//   * the kernel is VALU-issue bound (measured: SQ_ACTIVE_INST_VALU ~ all SIMD cycles, integer VALU = 4
+//     cycles per wave64 instruction), so the instruction stream is kept lean: lane predicates live as
+//     64-bit masks in SGPRs (one v_cmp each, combined on the scalar unit), the window bound j >= lo is a
+//     scalar-built lane mask, a chunk with no lane passing the filters (chain.c:202-206) skips scoring.
+//   * the max_skip rule is order dependent.  Per chunk it is evaluated with a DPP prefix max (which lanes
+//     raise the running best) and, only when a skip event interleaves with a new best, a max-plus scan of
+//     the skip counter (n -> max(n-1,0) on a new best, n -> n+1 on a "predecessor already on a visited
+//     chain" event; both are of the form n -> max(n+a, b) and compose); the first lane whose counter
+//     exceeds max_skip is the reference's `break`.
 //   * f[] and p[] leave in coalesced 256 B stores per 64 anchors.
 //
 // Floating point: (int)(dd * avg_qspan_scaled) is an f32 multiply then truncation (chain.c:213,218) and
@@ -35,6 +40,9 @@
 
 namespace mm2c {
 
+typedef unsigned long long mask_t;       // one bit per lane, lives in an SGPR pair
+#define SENT INT_MIN                     // score of a lane that is not a candidate
+
 // ---------------------------------------------------------------- wave64 primitives (DPP, gfx9 encodings)
 // dpp_ctrl: row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
 __device__ __forceinline__ int wave_shr1(int lane0_value, int v)
@@ -42,119 +50,169 @@ __device__ __forceinline__ int wave_shr1(int lane0_value, int v)
 	return __builtin_amdgcn_update_dpp(lane0_value, v, 0x138, 0xf, 0xf, false);
 }
 
+// shift the chunk-0 window one lane up and put a wave-uniform value into lane 0 (2 VALU)
+__device__ __forceinline__ int window_push(int w, int lane0_value)
+{
+	w = __builtin_amdgcn_update_dpp(w, w, 0x138, 0xf, 0xf, false);
+	asm("v_writelane_b32 %0, %1, 0" : "+v"(w) : "s"(lane0_value));
+	return w;
+}
 // inclusive prefix max over ascending lanes (6 v_max_i32_dpp)
 __device__ __forceinline__ int prefix_max_incl(int v)
 {
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x111, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x112, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x114, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x118, 0xf, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x142, 0xa, 0xf, false));
+	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x143, 0xc, 0xf, false));
 	return v;
 }
 
-__device__ __forceinline__ uint64_t ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
-__device__ __forceinline__ int lanes_below(uint64_t m)   // number of set bits of m in lanes below this one
+#define BALLOT(c) ((mask_t)__builtin_amdgcn_ballot_w64(c))
+__device__ __forceinline__ int lanes_below(mask_t m)   // number of set bits of m in lanes below this one
 {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// per-lane select by a scalar lane mask: bit set -> b, clear -> a
+__device__ __forceinline__ int sel(mask_t m, int a, int b)
+{
+	int r;
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+	return r;
+}
+// |a - b| for unsigned operands (one VALU)
+__device__ __forceinline__ int absdiff(int a, int b)
+{
+	int r;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+// lanes 0..n-1 (the lanes whose predecessor index is still >= the window start)
+__device__ __forceinline__ mask_t first_lanes(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
 
 struct Carry { int best, best_j, n_skip; };
 
-// ---------------------------------------------------------------- score of one (i, j) pair, chain.c:199-219
-// dr = x_i - x_j (in-window, so 0 <= dr <= max_dist_x < 2^31), dq = q_i - q_j.  Returns validity; sc gets the
-// score WITHOUT f[j].
-template <bool GEN, bool GS1>
-__device__ __forceinline__ bool pair_score(const KParams &P, float avg, int dr, int dq, bool same, int span_i, int &sc)
+// ---------------------------------------------------------------- filters of chain.c:202-206 as a lane mask
+// dr = x_i - x_j (low words; exact inside the window), dq = q_i - q_j.  `ok` = lanes inside the window.
+// For a lane inside the window 0 <= dr <= max_dist_x.
+template <bool GEN>
+__device__ __forceinline__ mask_t pair_filter(const KParams &P, mask_t ok, int dr, int dq, int dd, mask_t same)
 {
-	bool ok;
-	const int dd = dr > dq ? dr - dq : dq - dr;                       // chain.c:204
-	if (GEN) {
-		ok = !((same && dr == 0) || dq <= 0);                         // chain.c:202
-		ok = ok && !((same && dq > P.max_dist_y) || dq > P.max_dist_x); // chain.c:203
-		ok = ok && !(same && dd > P.bw);                              // chain.c:205
-		ok = ok && !(P.n_segs > 1 && !P.is_cdna && same && dr > P.max_dist_y); // chain.c:206
-	} else {
-		ok = dr != 0 && dq > 0 && dq <= P.max_dq && dd <= P.bw;       // same segment, not cDNA
+	if (!GEN) {
+		// same segment, genomic: dr != 0, 0 < dq <= min(max_dist_y, max_dist_x), dd <= bw
+		ok &= BALLOT(dr != 0);
+		ok &= BALLOT((unsigned)(dq - 1) < (unsigned)P.max_dq);
+		ok &= BALLOT(dd <= P.bw);
+		return ok;
 	}
-	int s = min(min(dq, dr), span_i);                                 // chain.c:207-208
-	const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;         // chain.c:209 (ilog2_32 == 31-clz, chain.c:15-27)
-	const int lin = (int)((float)dd * avg);                           // f32 multiply, truncate
-	int gap;
-	if (GEN) {
-		if (P.is_cdna || !same) {                                     // chain.c:211-217
-			if (!same && dr == 0) { ++s; gap = 0; }
-			else if (dr > dq || !same) gap = min(lin, lg);
-			else gap = lin + (lg >> 1);
-		} else gap = lin + (lg >> 1);
-	} else gap = lin + (lg >> 1);                                     // chain.c:218
-	if (GS1) s -= gap;                                                // (int)((double)g*1.0+.499) == g for g >= 0
-	else s -= (int)__dadd_rn(__dmul_rn((double)gap, (double)P.gap_scale), .499); // chain.c:219
-	sc = s;
+	const mask_t dr0 = BALLOT(dr == 0);
+	ok &= ~(same & dr0) & BALLOT(dq > 0);                                       // chain.c:202
+	ok &= ~(same & BALLOT(dq > P.max_dist_y)) & BALLOT(dq <= P.max_dist_x);     // chain.c:203
+	ok &= ~(same & BALLOT(dd > P.bw));                                          // chain.c:205
+	if (P.n_segs > 1 && !P.is_cdna) ok &= ~(same & BALLOT(dr > P.max_dist_y));  // chain.c:206
 	return ok;
 }
 
-// ---------------------------------------------------------------- one chunk of 64 predecessors
-// Lane L holds predecessor j = jtop - L.  `inwin` says the lane is inside the look-back window.
-// Returns true when the reference loop would have executed `break` inside this chunk.
-template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
-__device__ __forceinline__ bool eval_chunk(const KParams &P, float avg, int lane, int i, int jtop, int lo, int lds_lo,
-                                           bool inwin, int dr, int dq, bool same, int span_i, int fj, int pj,
-                                           int *s_t, int32_t *t_glob, Carry &c)
+// ---------------------------------------------------------------- score of a pair, chain.c:207-219, WITHOUT f[j]
+template <bool GEN, bool GS1>
+__device__ __forceinline__ int pair_score(const KParams &P, float avg, int dr, int dq, int dd, mask_t same, int span_i)
 {
-	int sc;
-	bool valid = pair_score<GEN, GS1>(P, avg, dr, dq, same, span_i, sc) && inwin;
-	sc += fj;                                                         // chain.c:220
-	const int scv = valid ? sc : INT_MIN;
+	int s = min(min(dq, dr), span_i);                                 // chain.c:207-208
+	const int c = __builtin_clz((unsigned)dd | 1u);                   // chain.c:209: log_dd = dd ? ilog2_32(dd) : 0 = 31 - c
+	const int lin = (int)((float)dd * avg);                           // f32 multiply, truncate
+	int gap;
+	if (GEN) {
+		const int lg = 31 - c;
+		const int g_same = lin + (lg >> 1);                           // chain.c:216,218
+		if (P.is_cdna) {                                              // chain.c:211-217 with is_cdna
+			const int g_cdna = dr > dq ? min(lin, lg) : g_same;
+			const int g_diff = dr == 0 ? 0 : min(lin, lg);
+			gap = sel(same, g_diff, g_cdna);
+		} else {
+			const int g_diff = dr == 0 ? 0 : min(lin, lg);            // sidi != sidj
+			gap = sel(same, g_diff, g_same);
+		}
+		s += sel(same, dr == 0 ? 1 : 0, 0);                           // chain.c:214 `++sc`
+	} else gap = lin + 15 - (c >> 1);                                 // (31 - c) >> 1 == 15 - (c >> 1) for c in 0..31
+	if (GS1) s -= gap;                                                // (int)((double)g*1.0+.499) == g for g >= 0
+	else s -= (int)__dadd_rn(__dmul_rn((double)gap, (double)P.gap_scale), .499); // chain.c:219
+	return s;
+}
+
+// ---------------------------------------------------------------- the order-dependent part of one chunk
+// scv: score per lane (SENT where the lane is not a candidate), marked: lanes with t[j] == i.
+// Updates the carry exactly as chain.c:226-232 would after walking the lanes in ascending order.
+// Returns true when the reference loop executes `break` inside this chunk.
+template <bool SKIP>
+__device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t valid, mask_t marked, int scv, Carry &c)
+{
 	const int incl = prefix_max_incl(scv);
 	int last = 63;                                                    // last lane the reference visits in this chunk
 	bool broke = false;
-
 	if (SKIP) {
-		const int j = jtop - lane;
-		const int stamp = i + 1;                                      // t[] holds i+1, 0 = never stamped (chain.c:46 memset)
-		// chain.c:233: every visited, unfiltered j stamps its own predecessor.  Stamps for targets outside
-		// the window are never read for this i, so they are dropped (keeps ring slots unaliased).
-		const bool do_mark = valid && pj >= lo;
-		bool far_mark = false;
-		if (do_mark) {
-			if (!FAR || pj >= lds_lo) s_t[pj & (R - 1)] = stamp;
-			else { __hip_atomic_store(&t_glob[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); far_mark = true; }
-		}
-		if (FAR && ballot64(far_mark)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		int tj;
-		if (!FAR || j >= lds_lo) tj = s_t[j & (R - 1)];
-		else tj = inwin ? __hip_atomic_load(&t_glob[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-		const bool marked = (tj == stamp);                            // chain.c:229 `t[j] == i`
-
-		const int run = max(c.best, wave_shr1(INT_MIN, incl));        // best before this lane, in scan order
-		const bool nm = valid && sc > run;                            // chain.c:226 takes the branch
-		const bool se = valid && !nm && marked;                       // chain.c:229-230 `++n_skip`
-		const uint64_t nmm = ballot64(nm), sem = ballot64(se);
-		if (sem != 0) {
-			// skip counter after each lane: Lindley recursion n <- max(n + d, 0), d = +1 (se) / -1 (nm)
-			const int S = lanes_below(sem) - lanes_below(nmm) + (se ? 1 : 0) - (nm ? 1 : 0);
-			const int nl = S + max(c.n_skip, prefix_max_incl(-S));
-			const uint64_t brk = ballot64(se && nl > P.max_skip);     // chain.c:230-231
-			if (brk != 0) { last = (int)__builtin_ctzll(brk) - 1; broke = true; }
-			else c.n_skip = rdlane(nl, 63);
-		} else {
-			c.n_skip = max(c.n_skip - (int)__builtin_popcountll(nmm), 0);
+		const mask_t cand = marked & valid;
+		if (cand != 0 || c.n_skip > 0) {
+			const int run = max(c.best, wave_shr1(SENT, incl));       // best before this lane, in scan order
+			const mask_t nm = BALLOT(scv > run);                      // chain.c:226 takes the branch
+			const mask_t se = cand & ~nm;                             // chain.c:229-230 `++n_skip`
+			if (se == 0) {
+				c.n_skip = max(c.n_skip - (int)__builtin_popcountll(nm), 0);
+			} else if (nm == 0 || (63 - (int)__builtin_clzll(nm)) < (int)__builtin_ctzll(se)) {
+				// every new best precedes every skip event: counter = max(n - #nm, 0) + rank of the event
+				const int n1 = max(c.n_skip - (int)__builtin_popcountll(nm), 0);
+				const int64_t need = (int64_t)P.max_skip - n1;         // the event of this 0-based rank breaks
+				if (need < (int64_t)__builtin_popcountll(se)) {
+					const int r = need < 0 ? 0 : (int)need;
+					const mask_t hit = se & BALLOT(lanes_below(se) == r);
+					last = (int)__builtin_ctzll(hit) - 1; broke = true;
+				} else c.n_skip = n1 + (int)__builtin_popcountll(se);
+			} else {
+				// general interleaving: Lindley recursion n <- max(n + d, 0), d = +1 (se) / -1 (nm)
+				const int S = lanes_below(se) - lanes_below(nm) + sel(se, 0, 1) - sel(nm, 0, 1);
+				const int nl = S + max(c.n_skip, prefix_max_incl(-S));
+				const mask_t brk = se & BALLOT(nl > P.max_skip);      // chain.c:230-231
+				if (brk != 0) { last = (int)__builtin_ctzll(brk) - 1; broke = true; }
+				else c.n_skip = rdlane(nl, 63);
+			}
 		}
 	}
 	if (last >= 0) {
 		const int mc = rdlane(incl, last);                            // best over the visited lanes of this chunk
 		if (mc > c.best) {                                            // strict: nearest j wins ties (chain.c:226)
-			const uint64_t eq = ballot64(valid && sc == mc);
 			c.best = mc;
-			c.best_j = jtop - (int)__builtin_ctzll(eq);
+			c.best_j = jtop - (int)__builtin_ctzll(BALLOT(scv == mc));
 		}
 	}
 	return broke;
+}
+
+// ---------------------------------------------------------------- chain.c:233 + :229 for a chunk whose lanes are all ring-resident
+// Every visited, unfiltered j stamps its predecessor p[j] with i+1 (stamps for targets outside the window are never
+// read for this i and are dropped, which keeps ring slots unaliased); then each lane tests its own stamp.
+// Lanes that do not stamp write to the sink slot [R].  A ring-resident j may still point beyond the ring: that
+// stamp goes to the global scratch t[].
+template <int R, bool FAR>
+__device__ __forceinline__ mask_t stamp_and_test(mask_t valid, int pj, int lo, int lds_lo, int stamp, char *t_bytes,
+                                                 int32_t *t_glob, int lane, int own_off4)
+{
+	const mask_t mk = valid & BALLOT(pj >= lo);
+	int tgt = sel(mk, R * 4, (pj & (R - 1)) << 2);
+	if (FAR) {
+		const mask_t fm = mk & BALLOT(pj < lds_lo);
+		if (fm != 0) {
+			int pj2 = pj;
+			asm volatile("" : "+v"(pj2));                             // keep the far addressing out of the hot loop
+			if (fm >> lane & 1) __hip_atomic_store(&t_glob[pj2], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			tgt = sel(fm, tgt, R * 4);
+		}
+	}
+	*(int *)(t_bytes + tgt) = stamp;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const int tj = *(const int *)(t_bytes + own_off4);
+	return BALLOT(tj == stamp);                                       // chain.c:229 `t[j] == i`
 }
 
 // ---------------------------------------------------------------- the kernel: one wave per task
@@ -166,9 +224,9 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
               int32_t *__restrict__ status, int only_flagged)
 {
 	static_assert(R >= 128 && (R & (R - 1)) == 0, "ring must be a power of two >= 128");
-	__shared__ uint2 s_xq[R];     // x low word, query position
-	__shared__ int2 s_fp[R];      // f, p
-	__shared__ int s_t[R];        // stamps (chain.c t[]), i+1
+	__shared__ uint2 s_xq[R];        // x low word, query position
+	__shared__ int2 s_fp[R];         // f, p
+	__shared__ int s_t[R + 1];       // stamps (chain.c t[]) holding i+1; [R] is the write sink of non-marking lanes
 	__shared__ uint8_t s_g[GEN ? R : 64];
 
 	const int lane = threadIdx.x;
@@ -181,7 +239,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const uint4 *a = a_all + base;         // {x lo, x hi, y lo (= query pos), y hi (span | flags | seg)}
 	int32_t *f = f_all + base, *p = p_all + base, *t = FAR ? t_all + base : nullptr;
 
-	for (int s = lane; s < R; s += 64) s_t[s] = 0;
+	for (int s = lane; s <= R; s += 64) s_t[s] = 0;
 
 	// avg_qspan_scaled, chain.c:48-49
 	float avg;
@@ -194,9 +252,12 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	}
 
 	const uint32_t D = (uint32_t)P.max_dist_x;
-	uint32_t wx = 0; int wq = 0, wf = 0, wp = -1, wg = 0;   // chunk-0 window: lane L = anchor i-1-L
-	uint32_t run_hi = 0; int hs = 0;                          // start of the run of anchors sharing x's high word
+	const int nl8 = -8 * lane;                                // ring byte offsets go down with the lane
+	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
+	uint32_t prev_hi = 0; int hs = 0;                         // hs: start of the run of anchors sharing x's high word
 	int seg0 = 0;
+	char *const t_bytes = (char *)s_t;
+	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
 
 	uint4 cur = (lane < n) ? a[lane] : make_uint4(0, 0, 0, 0);
 	for (int i0 = 0; i0 < n; i0 += 64) {
@@ -207,70 +268,136 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (!GEN && !(P.flags & KF_IGNORE_SEG)) {
 			// the simple variant assumes one segment id per task; anything else is redone by the general one
 			if (i0 == 0) seg0 = rdlane(g_l, 0);
-			if (ballot64(lane < cnt && g_l != seg0)) { if (lane == 0) status[task] = 1; return; }
+			if (BALLOT(lane < cnt && g_l != seg0)) { if (lane == 0) status[task] = 1; return; }
 		}
 		// the tile enters the ring (slots of anchors idx-R are recycled)
 		s_xq[idx & (R - 1)] = make_uint2(cur.x, cur.z);
 		if (GEN) s_g[idx & (R - 1)] = (uint8_t)g_l;
 		if (FAR && idx < n) t[idx] = 0;
+		// lanes whose anchor starts a new run of x's high word (reference / strand change)
+		const uint32_t hi_before = (uint32_t)wave_shr1((int)prev_hi, (int)cur.y);
+		const mask_t new_run = BALLOT(cur.y != hi_before) | (i0 == 0 ? 1ull : 0ull);
+		prev_hi = (uint32_t)rdlane((int)cur.y, 63);
 		const int lds_lo = i0 + 64 - R;       // oldest anchor index still in the ring while this tile is processed
-		int tf = 0, tp = -1;
 
 		for (int k = 0; k < cnt; ++k) {
 			const int i = i0 + k;
-			const uint32_t xi = (uint32_t)rdlane((int)cur.x, k), xhi = (uint32_t)rdlane((int)cur.y, k);
-			const int qi = rdlane((int)cur.z, k);
+			const int xi = rdlane((int)cur.x, k), qi = rdlane((int)cur.z, k);
 			const uint32_t yhi = (uint32_t)rdlane((int)cur.w, k);
 			const int span_i = P.span_override >= 0 ? P.span_override : (int)(yhi & 0xff);   // chain.c:189
 			const int seg_i = (yhi >> 16) & 0xff;                                               // chain.c:191
-			if (i == 0 || xhi != run_hi) { run_hi = xhi; hs = i; }
+			if (new_run != 0 && ((new_run >> k) & 1)) hs = i;
 			// chain.c:192-193: st = max(first j with x_i <= x_j + max_dist_x, i - max_iter); the x bound is
-			// applied per lane below (dr <= D), hs keeps the 32-bit difference exact.
-			const int lo = max(hs, (int)max((int64_t)i - (int64_t)P.max_iter, (int64_t)0));
+			// applied per chunk below (dr <= D, monotone in the lane), hs keeps the 32-bit difference exact.
+			const int lo = max(hs, i - P.max_iter);      // max_iter >= 0 (clamped on the host)
 			Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
 			int jtop = i - 1;
 			if (jtop >= lo) {
-				// ---- chunk 0 from registers
-				const int j0 = jtop - lane;
-				uint32_t dr = xi - wx;
-				bool inwin = j0 >= lo && dr <= D;
-				bool more = ballot64(inwin) == ~0ull;
-				bool broke = eval_chunk<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, jtop, lo, lds_lo, inwin, (int)dr, qi - wq,
-				                                                 GEN ? (wg == seg_i) : true, span_i, wf, wp, s_t, t, c);
-				jtop -= 64;
-				// ---- older chunks from the LDS ring (and from L2/HBM beyond it)
-				while (more && !broke && jtop >= lo) {
-					const int j = jtop - lane;
-					uint2 xq = make_uint2(0, 0); int2 fp = make_int2(0, -1); int gj = 0;
-					const bool near_all = !FAR || max(jtop - 63, lo) >= lds_lo;
-					if (near_all || j >= lds_lo) {
-						xq = s_xq[j & (R - 1)]; fp = s_fp[j & (R - 1)];
-						if (GEN) gj = s_g[j & (R - 1)];
-					} else if (j >= lo) {
-						const uint4 aj = a[j];
-						xq = make_uint2(aj.x, aj.z);
-						if (GEN) gj = (aj.w >> 16) & 0xff;
-						fp.x = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						fp.y = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const int stamp = i + 1;          // t[] holds i+1, 0 = never stamped (chain.c:46 memset)
+				// ---------------- chunk 0 from registers
+				bool more, broke = false;
+				{
+					const int dr = xi - wx, dq = qi - wq;
+					// anchors are sorted, so dr grows with the lane: the window ends where dr > D or j < lo
+					mask_t ok = first_lanes(jtop - lo + 1) & BALLOT((uint32_t)dr <= D);
+					more = ok == ~0ull;
+					const int dd = absdiff(dr, dq);
+					const mask_t same = GEN ? BALLOT(wg == seg_i) : ~0ull;
+					const mask_t valid = pair_filter<GEN>(P, ok, dr, dq, dd, same);
+					if (valid != 0) {
+						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
+						mask_t marked = 0;
+						if (SKIP) {
+							// chain.c:233: every visited, unfiltered j stamps its predecessor.  Stamps for targets
+							// outside the window are never read for this i and are dropped (keeps slots unaliased).
+							marked = stamp_and_test<R, FAR>(valid, wp, lo, lds_lo, stamp, t_bytes, t, lane,
+							                                (((jtop << 3) + nl8) & ((R - 1) << 3)) >> 1);
+						}
+						broke = fold_chunk<SKIP>(P, jtop, valid, marked, sel(valid, SENT, sc), c);
 					}
-					dr = xi - xq.x;
-					inwin = j >= lo && dr <= D;
-					more = ballot64(inwin) == ~0ull;
-					broke = eval_chunk<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, jtop, lo, lds_lo, inwin, (int)dr, qi - (int)xq.y,
-					                                            GEN ? (gj == seg_i) : true, span_i, fp.x, fp.y, s_t, t, c);
+					jtop -= 64;
+				}
+				// ---------------- older chunks from the LDS ring (and from L2/HBM beyond it)
+				while (more && !broke && jtop >= lo) {
+					const int n_in = jtop - lo + 1;
+					const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
+					int xj, qj, fj, pj, gj = 0;
+					mask_t far_l = 0;                                     // lanes whose predecessor left the ring
+					if (!FAR || max(jtop - 63, lo) >= lds_lo) {
+						const uint2 xq = *(const uint2 *)(xq_bytes + off8);
+						const int2 fp = *(const int2 *)(fp_bytes + off8);
+						xj = (int)xq.x; qj = (int)xq.y; fj = fp.x; pj = fp.y;
+						if (GEN) gj = s_g[off8 >> 3];
+					} else {
+						int j = jtop - lane;
+						asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
+						far_l = BALLOT(j < lds_lo) & first_lanes(n_in);
+						const uint2 xq = *(const uint2 *)(xq_bytes + off8);
+						const int2 fp = *(const int2 *)(fp_bytes + off8);
+						xj = (int)xq.x; qj = (int)xq.y; fj = fp.x; pj = fp.y;
+						if (GEN) gj = s_g[off8 >> 3];
+						if (j < lds_lo && j >= lo) {
+							const uint4 aj = a[j];
+							xj = (int)aj.x; qj = (int)aj.z;
+							if (GEN) gj = (aj.w >> 16) & 0xff;
+						}
+					}
+					const int dr = xi - xj, dq = qi - qj;
+					mask_t ok = first_lanes(n_in) & BALLOT((uint32_t)dr <= D);
+					more = ok == ~0ull;
+					const int dd = absdiff(dr, dq);
+					const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
+					const mask_t valid = pair_filter<GEN>(P, ok, dr, dq, dd, same);
+					if (valid != 0) {
+						mask_t marked = 0;
+						if (FAR && far_l != 0) {
+							// look-back beyond the ring: f, p and stamps from L2/HBM, only for lanes that passed the filters
+							int j = jtop - lane;
+							asm volatile("" : "+v"(j));
+							const bool fl = (far_l & valid) >> lane & 1;
+							if (fl) {
+								fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							}
+							if (SKIP) {
+								const bool mkv = (valid >> lane & 1) && pj >= lo;
+								bool far_mark = false;
+								if (mkv) {
+									if (pj >= lds_lo) s_t[pj & (R - 1)] = stamp;
+									else { __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); far_mark = true; }
+								}
+								(void)far_mark;
+								asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
+								__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+								__builtin_amdgcn_wave_barrier();
+								int tj = 0;
+								if (fl) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								else tj = s_t[j & (R - 1)];
+								marked = BALLOT(tj == stamp);
+							}
+						} else if (SKIP) {
+							marked = stamp_and_test<R, FAR>(valid, pj, lo, lds_lo, stamp, t_bytes, t, lane, off8 >> 1);
+						}
+						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
+						broke = fold_chunk<SKIP>(P, jtop, valid, marked, sel(valid, SENT, sc), c);
+					}
 					jtop -= 64;
 				}
 			}
-			// ---- commit anchor i (chain.c:236): tile registers, LDS ring, chunk-0 window
-			if (lane == k) { tf = c.best; tp = c.best_j; }
-			if (lane == 0) s_fp[i & (R - 1)] = make_int2(c.best, c.best_j);
-			wx = (uint32_t)wave_shr1((int)xi, (int)wx);
-			wq = wave_shr1(qi, wq);
-			wf = wave_shr1(c.best, wf);
-			wp = wave_shr1(c.best_j, wp);
-			if (GEN) wg = wave_shr1(seg_i, wg);
+			// ---- commit anchor i (chain.c:236) into the chunk-0 window
+			wx = window_push(wx, xi);
+			wq = window_push(wq, qi);
+			wf = window_push(wf, c.best);
+			wp = window_push(wp, c.best_j);
+			if (GEN) wg = window_push(wg, seg_i);
 		}
-		if (idx < n) { f[idx] = tf; p[idx] = tp; }     // coalesced 256 B stores
+		// after the tile, window lane L holds anchor i0+cnt-1-L: f/p of the tile enter the ring (older chunks never
+		// reach into the current tile, so once per tile is enough) and leave in coalesced 256 B stores
+		if (lane < cnt) {
+			const int o = i0 + cnt - 1 - lane;
+			s_fp[o & (R - 1)] = make_int2(wf, wp);
+			f[o] = wf; p[o] = wp;
+		}
 		cur = nxt;
 	}
 }

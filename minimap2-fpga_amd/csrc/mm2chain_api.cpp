@@ -119,10 +119,11 @@ mm2c::KParams to_kparams(const mm2c_params_t *p)
 {
 	mm2c::KParams k;
 	k.max_dist_x = p->max_dist_x; k.max_dist_y = p->max_dist_y; k.bw = p->bw;
-	k.max_skip = p->max_skip; k.max_iter = p->max_iter;
+	k.max_skip = p->max_skip;
+	k.max_iter = std::max(p->max_iter, 0);      // a negative max_iter leaves no predecessor at all (chain.c:193), same as 0
 	k.is_cdna = p->is_cdna; k.n_segs = p->n_segs;
 	k.span_override = p->q_span_override;
-	k.max_dq = std::min(p->max_dist_y, p->max_dist_x);
+	k.max_dq = std::max(std::min(p->max_dist_y, p->max_dist_x), 0);
 	k.flags = 0;
 	if (p->flags & MM2C_F_IGNORE_SEG) k.flags |= mm2c::KF_IGNORE_SEG;
 	if (p->flags & MM2C_F_FORCE_GENERAL) k.flags |= mm2c::KF_FORCE_GENERAL;
