@@ -88,9 +88,11 @@ int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
 int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *d_avg_qspan,
                          int32_t *d_f, int32_t *d_p, void *stream);
 
-/* milliseconds between HIP events recorded (on the run's stream) around the DP kernel launches of the most
- * recent mm2c_plan_run_device; synchronises on the end event. */
+/* milliseconds between HIP events recorded (on the run's stream) around the DP kernel (chain_dp_wave) of the most
+ * recent mm2c_plan_run_device; synchronises on the end event.  _prepass_ms: the same for the window-start kernel
+ * (chain_window_start) that runs just before it. */
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
+int mm2c_plan_last_prepass_ms(mm2c_plan_t *plan, float *ms);
 
 /* ---- host-buffer paths (PCIe included) ---------------------------------------------------------------------- */
 /* whole batch from pageable host memory: staging, H2D, DP, D2H, sync */

@@ -28,12 +28,14 @@ struct LaunchArgs {
 	const float *d_avg;         // per task or nullptr (computed in kernel, chain.c:48-49)
 	int32_t *d_f, *d_p;
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
+	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
 	int ring_class;             // 0: 256, 1: 512, 2: 1024 anchors of LDS ring per task
 };
 
 int chain_ring_anchors(int ring_class);
-hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches);
+// ev_dp_begin (optional) is recorded between the window-start prepass and the DP kernel
+hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin);
 
 } // namespace mm2c
 #endif

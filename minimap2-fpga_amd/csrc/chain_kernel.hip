@@ -90,7 +90,12 @@ __device__ __forceinline__ int absdiff(int a, int b)
 	return r;
 }
 // lanes 0..n-1 (the lanes whose predecessor index is still >= the window start)
-__device__ __forceinline__ mask_t first_lanes(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+__device__ __forceinline__ mask_t first_lanes(int n)   // n >= 1
+{
+	int sh = 64 - n;
+	sh = sh < 0 ? 0 : sh;
+	return ~0ull >> sh;
+}
 
 struct Carry { int best, best_j, n_skip; };
 
@@ -194,7 +199,7 @@ __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t va
 // Lanes that do not stamp write to the sink slot [R].  A ring-resident j may still point beyond the ring: that
 // stamp goes to the global scratch t[].
 template <int R, bool FAR>
-__device__ __forceinline__ mask_t stamp_and_test(mask_t valid, int pj, int lo, int lds_lo, int stamp, char *t_bytes,
+__device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int lds_lo, int stamp, int stamp_v, char *t_bytes,
                                                  int32_t *t_glob, int lane, int own_off4)
 {
 	const mask_t mk = valid & BALLOT(pj >= lo);
@@ -208,18 +213,45 @@ __device__ __forceinline__ mask_t stamp_and_test(mask_t valid, int pj, int lo, i
 			tgt = sel(fm, tgt, R * 4);
 		}
 	}
-	*(int *)(t_bytes + tgt) = stamp;
+	*(int *)(t_bytes + tgt) = stamp_v;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	const int tj = *(const int *)(t_bytes + own_off4);
-	return BALLOT(tj == stamp);                                       // chain.c:229 `t[j] == i`
+	return *(const int *)(t_bytes + own_off4);                        // the caller tests it against i+1 (chain.c:229 `t[j] == i`)
+}
+
+// ---------------------------------------------------------------- prepass: window start of every anchor
+// st[i] = max(first j of the task with x_i <= x_j + max_dist_x, i - max_iter), chain.c:192-193 (the `st` pointer of the
+// reference is monotone, so its value at i is exactly this).  Full 64-bit compares, so inside
+// [st[i], i) every x difference fits 31 bits and the DP kernel works on low words.  One wave per task, 64 anchors
+// per step, each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
+__global__ void __launch_bounds__(64)
+chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+                   const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all)
+{
+	const int lane = threadIdx.x;
+	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
+	if (task >= n_tasks) return;
+	const int64_t base = offsets[task];
+	const int n = (int)(offsets[task + 1] - base);
+	const ulonglong2 *a = a_all + base;
+	int32_t *st = st_all + base;
+	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
+	for (int i = lane; i < n; i += 64) {
+		const uint64_t xi = a[i].x;
+		int lo = max(i - P.max_iter, 0), hi = i;                    // answer in [lo, i]; x_i <= x_i + D always holds
+		while (lo < hi) {
+			const int mid = (lo + hi) >> 1;
+			if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;       // chain.c:192 condition for "++st"
+		}
+		st[i] = lo;
+	}
 }
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __global__ void __launch_bounds__(64)
 chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-              const uint4 *__restrict__ a_all, const float *__restrict__ avg_in,
+              const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ st_all,
               int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
               int32_t *__restrict__ status, int only_flagged)
 {
@@ -237,6 +269,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int n = (int)(offsets[task + 1] - base);
 	if (n <= 0) return;
 	const uint4 *a = a_all + base;         // {x lo, x hi, y lo (= query pos), y hi (span | flags | seg)}
+	const int32_t *st = st_all + base;
 	int32_t *f = f_all + base, *p = p_all + base, *t = FAR ? t_all + base : nullptr;
 
 	for (int s = lane; s <= R; s += 64) s_t[s] = 0;
@@ -251,19 +284,19 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
 	}
 
-	const uint32_t D = (uint32_t)P.max_dist_x;
 	const int nl8 = -8 * lane;                                // ring byte offsets go down with the lane
 	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
-	uint32_t prev_hi = 0; int hs = 0;                         // hs: start of the run of anchors sharing x's high word
 	int seg0 = 0;
 	char *const t_bytes = (char *)s_t;
 	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
 
 	uint4 cur = (lane < n) ? a[lane] : make_uint4(0, 0, 0, 0);
+	int cur_st = (lane < n) ? st[lane] : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int idx = i0 + lane;
 		const int cnt = min(64, n - i0);
-		uint4 nxt = (idx + 64 < n) ? a[idx + 64] : make_uint4(0, 0, 0, 0);   // prefetch the next tile
+		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
+		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64]; }   // prefetch the next tile
 		const int g_l = (cur.w >> 16) & 0xff;                                 // MM_SEED_SEG_MASK mmpriv.h:22-23
 		if (!GEN && !(P.flags & KF_IGNORE_SEG)) {
 			// the simple variant assumes one segment id per task; anything else is redone by the general one
@@ -274,80 +307,64 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		s_xq[idx & (R - 1)] = make_uint2(cur.x, cur.z);
 		if (GEN) s_g[idx & (R - 1)] = (uint8_t)g_l;
 		if (FAR && idx < n) t[idx] = 0;
-		// lanes whose anchor starts a new run of x's high word (reference / strand change)
-		const uint32_t hi_before = (uint32_t)wave_shr1((int)prev_hi, (int)cur.y);
-		const mask_t new_run = BALLOT(cur.y != hi_before) | (i0 == 0 ? 1ull : 0ull);
-		prev_hi = (uint32_t)rdlane((int)cur.y, 63);
+		const int span_l = P.span_override >= 0 ? P.span_override : (int)(cur.w & 0xff);   // chain.c:189
 		const int lds_lo = i0 + 64 - R;       // oldest anchor index still in the ring while this tile is processed
+		int stamp_v = i0;                      // per-lane copy of i (the stamp is i+1: t[] = 0 means never stamped, chain.c:46)
 
 		for (int k = 0; k < cnt; ++k) {
 			const int i = i0 + k;
 			const int xi = rdlane((int)cur.x, k), qi = rdlane((int)cur.z, k);
-			const uint32_t yhi = (uint32_t)rdlane((int)cur.w, k);
-			const int span_i = P.span_override >= 0 ? P.span_override : (int)(yhi & 0xff);   // chain.c:189
-			const int seg_i = (yhi >> 16) & 0xff;                                               // chain.c:191
-			if (new_run != 0 && ((new_run >> k) & 1)) hs = i;
-			// chain.c:192-193: st = max(first j with x_i <= x_j + max_dist_x, i - max_iter); the x bound is
-			// applied per chunk below (dr <= D, monotone in the lane), hs keeps the 32-bit difference exact.
-			const int lo = max(hs, i - P.max_iter);      // max_iter >= 0 (clamped on the host)
+			const int span_i = rdlane(span_l, k);
+			const int seg_i = GEN ? rdlane(g_l, k) : 0;                                         // chain.c:191
+			const int lo = rdlane(cur_st, k);                                                   // chain.c:192-193
 			Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
-			int jtop = i - 1;
-			if (jtop >= lo) {
-				const int stamp = i + 1;          // t[] holds i+1, 0 = never stamped (chain.c:46 memset)
+			stamp_v += 1;
+			int rem = i - lo;                  // predecessors still to visit
+			if (rem > 0) {
+				const int stamp = i + 1;
+				int jtop = i - 1;
+				bool broke = false;
 				// ---------------- chunk 0 from registers
-				bool more, broke = false;
 				{
 					const int dr = xi - wx, dq = qi - wq;
-					// anchors are sorted, so dr grows with the lane: the window ends where dr > D or j < lo
-					mask_t ok = first_lanes(jtop - lo + 1) & BALLOT((uint32_t)dr <= D);
-					more = ok == ~0ull;
 					const int dd = absdiff(dr, dq);
 					const mask_t same = GEN ? BALLOT(wg == seg_i) : ~0ull;
-					const mask_t valid = pair_filter<GEN>(P, ok, dr, dq, dd, same);
+					const mask_t valid = pair_filter<GEN>(P, first_lanes(rem), dr, dq, dd, same);
 					if (valid != 0) {
+						int tj = 0;                    // stamp round trip through LDS overlaps the scoring below
+						if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, stamp_v, t_bytes, t, lane,
+						                                        (((jtop << 3) + nl8) & ((R - 1) << 3)) >> 1);
 						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
-						mask_t marked = 0;
-						if (SKIP) {
-							// chain.c:233: every visited, unfiltered j stamps its predecessor.  Stamps for targets
-							// outside the window are never read for this i and are dropped (keeps slots unaliased).
-							marked = stamp_and_test<R, FAR>(valid, wp, lo, lds_lo, stamp, t_bytes, t, lane,
-							                                (((jtop << 3) + nl8) & ((R - 1) << 3)) >> 1);
-						}
-						broke = fold_chunk<SKIP>(P, jtop, valid, marked, sel(valid, SENT, sc), c);
+						const int scv = sel(valid, SENT, sc);
+						const mask_t marked = SKIP ? BALLOT(tj == stamp) : 0;
+						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
 					}
-					jtop -= 64;
+					jtop -= 64; rem -= 64;
 				}
 				// ---------------- older chunks from the LDS ring (and from L2/HBM beyond it)
-				while (more && !broke && jtop >= lo) {
-					const int n_in = jtop - lo + 1;
+				while (rem > 0 && !broke) {
 					const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
-					int xj, qj, fj, pj, gj = 0;
+					const uint2 xq = *(const uint2 *)(xq_bytes + off8);
+					const int2 fp = *(const int2 *)(fp_bytes + off8);
+					int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
+					if (GEN) gj = s_g[off8 >> 3];
+					const int own_off4 = off8 >> 1;
+					const mask_t in_w = first_lanes(rem);
 					mask_t far_l = 0;                                     // lanes whose predecessor left the ring
-					if (!FAR || max(jtop - 63, lo) >= lds_lo) {
-						const uint2 xq = *(const uint2 *)(xq_bytes + off8);
-						const int2 fp = *(const int2 *)(fp_bytes + off8);
-						xj = (int)xq.x; qj = (int)xq.y; fj = fp.x; pj = fp.y;
-						if (GEN) gj = s_g[off8 >> 3];
-					} else {
+					if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
 						int j = jtop - lane;
 						asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
-						far_l = BALLOT(j < lds_lo) & first_lanes(n_in);
-						const uint2 xq = *(const uint2 *)(xq_bytes + off8);
-						const int2 fp = *(const int2 *)(fp_bytes + off8);
-						xj = (int)xq.x; qj = (int)xq.y; fj = fp.x; pj = fp.y;
-						if (GEN) gj = s_g[off8 >> 3];
-						if (j < lds_lo && j >= lo) {
+						far_l = BALLOT(j < lds_lo) & in_w;
+						if (far_l >> lane & 1) {
 							const uint4 aj = a[j];
 							xj = (int)aj.x; qj = (int)aj.z;
 							if (GEN) gj = (aj.w >> 16) & 0xff;
 						}
 					}
 					const int dr = xi - xj, dq = qi - qj;
-					mask_t ok = first_lanes(n_in) & BALLOT((uint32_t)dr <= D);
-					more = ok == ~0ull;
 					const int dd = absdiff(dr, dq);
 					const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
-					const mask_t valid = pair_filter<GEN>(P, ok, dr, dq, dd, same);
+					const mask_t valid = pair_filter<GEN>(P, in_w, dr, dq, dd, same);
 					if (valid != 0) {
 						mask_t marked = 0;
 						if (FAR && far_l != 0) {
@@ -361,12 +378,10 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 							}
 							if (SKIP) {
 								const bool mkv = (valid >> lane & 1) && pj >= lo;
-								bool far_mark = false;
 								if (mkv) {
 									if (pj >= lds_lo) s_t[pj & (R - 1)] = stamp;
-									else { __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); far_mark = true; }
+									else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								}
-								(void)far_mark;
 								asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
 								__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 								__builtin_amdgcn_wave_barrier();
@@ -375,13 +390,16 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 								else tj = s_t[j & (R - 1)];
 								marked = BALLOT(tj == stamp);
 							}
-						} else if (SKIP) {
-							marked = stamp_and_test<R, FAR>(valid, pj, lo, lds_lo, stamp, t_bytes, t, lane, off8 >> 1);
 						}
+						int tj = 0;
+						const bool near_stamps = SKIP && !(FAR && far_l != 0);
+						if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, stamp_v, t_bytes, t, lane, own_off4);
 						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
-						broke = fold_chunk<SKIP>(P, jtop, valid, marked, sel(valid, SENT, sc), c);
+						const int scv = sel(valid, SENT, sc);
+						if (near_stamps) marked = BALLOT(tj == stamp);
+						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
 					}
-					jtop -= 64;
+					jtop -= 64; rem -= 64;
 				}
 			}
 			// ---- commit anchor i (chain.c:236) into the chunk-0 window
@@ -398,7 +416,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			s_fp[o & (R - 1)] = make_int2(wf, wp);
 			f[o] = wf; p[o] = wp;
 		}
-		cur = nxt;
+		cur = nxt; cur_st = nxt_st;
 	}
 }
 
@@ -407,7 +425,7 @@ template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagged)
 {
 	hipLaunchKernelGGL((chain_dp_wave<R, SKIP, GEN, GS1, FAR>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
-	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, L.d_avg, L.d_f, L.d_p, L.d_t,
+	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, L.d_avg, L.d_st, L.d_f, L.d_p, L.d_t,
 	                   L.d_status, only_flagged);
 	return hipGetLastError();
 }
@@ -428,7 +446,7 @@ static hipError_t launch_r(const LaunchArgs &L, hipStream_t st, bool skip, bool 
 
 int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : 1024; }
 
-hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches)
+hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin)
 {
 	const KParams &P = L.P;
 	if (L.n_tasks <= 0) return hipSuccess;
@@ -438,7 +456,11 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches)
 	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
 	const bool far_ = (int64_t)P.max_iter + 64 > (int64_t)R;
-	hipError_t e = hipSuccess;
+	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(64), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
+	                   (const ulonglong2 *)L.d_anchors, L.d_st);
+	hipError_t e = hipGetLastError();
+	if (n_launches) ++*n_launches;
+	if (e == hipSuccess && ev_dp_begin) e = hipEventRecord(ev_dp_begin, st);
 	for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
 		// pass 0: the variant the parameters ask for; pass 1 (simple variant only, segments not ignored): redo the
 		// tasks that turned out to carry more than one segment id with the general variant.

@@ -53,12 +53,12 @@ struct Global {
 // chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex)
 struct ThreadCtx {
 	hipStream_t st = nullptr;
-	void *d_a = nullptr; int32_t *d_f = nullptr, *d_p = nullptr, *d_t = nullptr;
+	void *d_a = nullptr; int32_t *d_f = nullptr, *d_p = nullptr, *d_t = nullptr, *d_st = nullptr;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr; float *d_avg = nullptr;
 	size_t cap_anchors = 0, cap_tasks = 0;
 	void release()
 	{
-		if (d_a) (void)hipFree(d_a); if (d_f) (void)hipFree(d_f); if (d_p) (void)hipFree(d_p); if (d_t) (void)hipFree(d_t);
+		if (d_a) (void)hipFree(d_a); if (d_f) (void)hipFree(d_f); if (d_p) (void)hipFree(d_p); if (d_t) (void)hipFree(d_t); if (d_st) (void)hipFree(d_st);
 		if (d_off) (void)hipFree(d_off); if (d_order) (void)hipFree(d_order); if (d_status) (void)hipFree(d_status); if (d_avg) (void)hipFree(d_avg);
 		if (st) (void)hipStreamDestroy(st);
 		*this = ThreadCtx();
@@ -87,12 +87,13 @@ int ensure_capacity(ThreadCtx *c, size_t n_anchors, size_t n_tasks)
 {
 	if (n_anchors > c->cap_anchors) {
 		size_t cap = std::max(n_anchors, c->cap_anchors * 2);
-		if (c->d_a) (void)hipFree(c->d_a); if (c->d_f) (void)hipFree(c->d_f); if (c->d_p) (void)hipFree(c->d_p); if (c->d_t) (void)hipFree(c->d_t);
-		c->d_a = nullptr; c->d_f = c->d_p = c->d_t = nullptr; c->cap_anchors = 0;
+		if (c->d_a) (void)hipFree(c->d_a); if (c->d_f) (void)hipFree(c->d_f); if (c->d_p) (void)hipFree(c->d_p); if (c->d_t) (void)hipFree(c->d_t); if (c->d_st) (void)hipFree(c->d_st);
+		c->d_a = nullptr; c->d_f = c->d_p = c->d_t = c->d_st = nullptr; c->cap_anchors = 0;
 		HIP_TRY(hipMalloc(&c->d_a, cap * 16));
 		HIP_TRY(hipMalloc((void **)&c->d_f, cap * 4));
 		HIP_TRY(hipMalloc((void **)&c->d_p, cap * 4));
 		HIP_TRY(hipMalloc((void **)&c->d_t, cap * 4));
+		HIP_TRY(hipMalloc((void **)&c->d_st, cap * 4));
 		c->cap_anchors = cap;
 	}
 	if (n_tasks > c->cap_tasks) {
@@ -153,8 +154,8 @@ int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order
 struct mm2c_plan {
 	mm2c_params_t par;
 	int64_t n_tasks = 0, total = 0;
-	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr;
+	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr;
 	bool ran = false;
 };
 
@@ -257,6 +258,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_order, nt * 4);
 	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_status, nt * 4);
 	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_t, tot * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -264,6 +266,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 		e = hipMemcpy(pl->d_off, off.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(pl->d_order, order.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice);
 	}
+	if (e == hipSuccess) e = hipEventCreate(&pl->ev_pre);
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
 	if (e != hipSuccess) {
@@ -278,7 +281,8 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 {
 	if (!pl) return;
 	if (pl->d_off) (void)hipFree(pl->d_off); if (pl->d_order) (void)hipFree(pl->d_order);
-	if (pl->d_status) (void)hipFree(pl->d_status); if (pl->d_t) (void)hipFree(pl->d_t);
+	if (pl->d_status) (void)hipFree(pl->d_status); if (pl->d_t) (void)hipFree(pl->d_t); if (pl->d_st) (void)hipFree(pl->d_st);
+	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	delete pl;
 }
@@ -295,15 +299,24 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
-	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_status = pl->d_status;
+	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.ring_class = G.ring_class;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
-	HIP_TRY(hipEventRecord(pl->ev0, st));
+	HIP_TRY(hipEventRecord(pl->ev_pre, st));
 	int nl = 0;
-	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl));
+	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, pl->ev0));
 	HIP_TRY(hipEventRecord(pl->ev1, st));
 	pl->ran = true;
 	G.tasks += (uint64_t)pl->n_tasks; G.anchors += (uint64_t)pl->total; G.launches += (uint64_t)nl;
+	return 0;
+}
+
+int mm2c_plan_last_prepass_ms(mm2c_plan_t *pl, float *ms)
+{
+	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
+	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
+	HIP_TRY(hipEventSynchronize(pl->ev0));
+	HIP_TRY(hipEventElapsedTime(ms, pl->ev_pre, pl->ev0));
 	return 0;
 }
 
@@ -342,10 +355,10 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(par);
 	L.n_tasks = n_tasks; L.d_offsets = c->d_off; L.d_order = c->d_order; L.d_anchors = c->d_a;
-	L.d_avg = h_avg_qspan ? c->d_avg : nullptr; L.d_f = c->d_f; L.d_p = c->d_p; L.d_t = c->d_t; L.d_status = c->d_status;
+	L.d_avg = h_avg_qspan ? c->d_avg : nullptr; L.d_f = c->d_f; L.d_p = c->d_p; L.d_t = c->d_t; L.d_st = c->d_st; L.d_status = c->d_status;
 	L.ring_class = G.ring_class;
 	int nl = 0;
-	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl));                                                          // cf. chain_hardware.cpp:156
+	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
 	HIP_TRY(hipMemcpyAsync(h_f + base, c->d_f, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:167
 	HIP_TRY(hipMemcpyAsync(h_p + base, c->d_p, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:170
 	HIP_TRY(hipStreamSynchronize(c->st));                                                                   // cf. chain_hardware.cpp:175

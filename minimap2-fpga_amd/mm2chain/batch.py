@@ -80,6 +80,11 @@ class ChainPlan:
         N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")
         return ms.value
 
+    def last_prepass_ms(self):
+        ms = C.c_float(0)
+        N.check(self.lib.mm2c_plan_last_prepass_ms(self.handle, C.byref(ms)), "mm2c_plan_last_prepass_ms")
+        return ms.value
+
     def close(self):
         if self.handle:
             self.lib.mm2c_plan_destroy(self.handle)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools/quickbench.sh <tag> [profiles...]   -- runs on the GPU box; appends value / kernel ms / verified per profile
-TAG=$1; shift
+# usage: tools/quickbench.sh <tag> "<extra bench args>" [profiles...]   -- runs on the GPU box
+TAG=$1; EXTRA=$2; shift; shift
 PROFS=${@:-mixed dense sparse colinear}
 for prof in $PROFS; do
-  timeout -k 10 300 python bench.py --profile $prof --cpu-seconds 0 --steps 3 --warmup 1 2>&1 | python3 -c "
+  timeout -k 10 300 python bench.py --profile $prof --cpu-seconds 0 --steps 3 --warmup 1 $EXTRA 2>&1 | python3 -c "
 import sys,json
 lines=sys.stdin.read().strip().splitlines()
 try:
