@@ -194,29 +194,30 @@ __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t va
 }
 
 // ---------------------------------------------------------------- chain.c:233 + :229 for a chunk whose lanes are all ring-resident
-// Every visited, unfiltered j stamps its predecessor p[j] with i+1 (stamps for targets outside the window are never
-// read for this i and are dropped, which keeps ring slots unaliased); then each lane tests its own stamp.
-// Lanes that do not stamp write to the sink slot [R].  A ring-resident j may still point beyond the ring: that
-// stamp goes to the global scratch t[].
+// Every visited, unfiltered j stamps its predecessor p[j] (stamps for targets outside the window are never read for
+// this i and are dropped); then each lane fetches its own stamp.  LDS stamps are 16 bit, s16 = 1 + i % 65535 (0 = never
+// stamped, chain.c:46), in a ring of 2R slots that is cleared as anchors enter it, so a value identifies its anchor.
+// Lanes that do not stamp write to the sink slot [2R].  A ring-resident j may still point beyond the ring: that
+// stamp (the full i+1) goes to the global scratch t[].
 template <int R, bool FAR>
-__device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int lds_lo, int stamp, int stamp_v, char *t_bytes,
-                                                 int32_t *t_glob, int lane, int own_off4)
+__device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int lds_lo, int stamp, int s16_v, char *t_bytes,
+                                               int32_t *t_glob, int lane, int own_off2)
 {
 	const mask_t mk = valid & BALLOT(pj >= lo);
-	int tgt = sel(mk, R * 4, (pj & (R - 1)) << 2);
+	int tgt = sel(mk, 2 * R * 2, (pj & (2 * R - 1)) << 1);
 	if (FAR) {
 		const mask_t fm = mk & BALLOT(pj < lds_lo);
 		if (fm != 0) {
 			int pj2 = pj;
 			asm volatile("" : "+v"(pj2));                             // keep the far addressing out of the hot loop
 			if (fm >> lane & 1) __hip_atomic_store(&t_glob[pj2], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			tgt = sel(fm, tgt, R * 4);
+			tgt = sel(fm, tgt, 2 * R * 2);
 		}
 	}
-	*(int *)(t_bytes + tgt) = stamp_v;
+	*(uint16_t *)(t_bytes + tgt) = (uint16_t)s16_v;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	return *(const int *)(t_bytes + own_off4);                        // the caller tests it against i+1 (chain.c:229 `t[j] == i`)
+	return *(const uint16_t *)(t_bytes + own_off2);                   // the caller tests it against s16 (chain.c:229 `t[j] == i`)
 }
 
 // ---------------------------------------------------------------- prepass: window start of every anchor
@@ -258,7 +259,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	static_assert(R >= 128 && (R & (R - 1)) == 0, "ring must be a power of two >= 128");
 	__shared__ uint2 s_xq[R];        // x low word, query position
 	__shared__ int2 s_fp[R];         // f, p
-	__shared__ int s_t[R + 1];       // stamps (chain.c t[]) holding i+1; [R] is the write sink of non-marking lanes
+	__shared__ uint16_t s_t[2 * R + 2]; // 16-bit stamps (chain.c t[]), ring of 2R anchors; [2R] is the write sink of non-marking lanes
 	__shared__ uint8_t s_g[GEN ? R : 64];
 
 	const int lane = threadIdx.x;
@@ -272,7 +273,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int32_t *st = st_all + base;
 	int32_t *f = f_all + base, *p = p_all + base, *t = FAR ? t_all + base : nullptr;
 
-	for (int s = lane; s <= R; s += 64) s_t[s] = 0;
+	for (int s = lane; s < 2 * R + 2; s += 64) s_t[s] = 0;
 
 	// avg_qspan_scaled, chain.c:48-49
 	float avg;
@@ -284,7 +285,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
 	}
 
-	const int nl8 = -8 * lane;                                // ring byte offsets go down with the lane
+	const int nl8 = -8 * lane, nl2 = -2 * lane;               // ring byte offsets go down with the lane
 	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
 	int seg0 = 0;
 	char *const t_bytes = (char *)s_t;
@@ -303,13 +304,12 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (i0 == 0) seg0 = rdlane(g_l, 0);
 			if (BALLOT(lane < cnt && g_l != seg0)) { if (lane == 0) status[task] = 1; return; }
 		}
-		// the tile enters the ring (slots of anchors idx-R are recycled)
-		s_xq[idx & (R - 1)] = make_uint2(cur.x, cur.z);
-		if (GEN) s_g[idx & (R - 1)] = (uint8_t)g_l;
+		// while this tile is processed the ring holds anchors [i0-R, i0): the tile itself lives in `cur` and in the
+		// chunk-0 window and enters the ring when it is finished (older chunks never reach into the current tile)
+		s_t[idx & (2 * R - 1)] = 0;          // stamp slots of the entering anchors (recycled from idx-2R)
 		if (FAR && idx < n) t[idx] = 0;
 		const int span_l = P.span_override >= 0 ? P.span_override : (int)(cur.w & 0xff);   // chain.c:189
-		const int lds_lo = i0 + 64 - R;       // oldest anchor index still in the ring while this tile is processed
-		int stamp_v = i0;                      // per-lane copy of i (the stamp is i+1: t[] = 0 means never stamped, chain.c:46)
+		const int lds_lo = i0 - R;            // oldest anchor index still in the ring while this tile is processed
 
 		for (int k = 0; k < cnt; ++k) {
 			const int i = i0 + k;
@@ -318,10 +318,11 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int seg_i = GEN ? rdlane(g_l, k) : 0;                                         // chain.c:191
 			const int lo = rdlane(cur_st, k);                                                   // chain.c:192-193
 			Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
-			stamp_v += 1;
 			int rem = i - lo;                  // predecessors still to visit
 			if (rem > 0) {
-				const int stamp = i + 1;
+				const int stamp = i + 1;              // stamp in the global scratch t[] (look-back beyond the ring)
+				const int s16 = 1 + i % 65535;        // stamp in the LDS ring
+				const int s16_v = s16;                 // (one v_mov: the ds_write data operand)
 				int jtop = i - 1;
 				bool broke = false;
 				// ---------------- chunk 0 from registers
@@ -332,11 +333,11 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 					const mask_t valid = pair_filter<GEN>(P, first_lanes(rem), dr, dq, dd, same);
 					if (valid != 0) {
 						int tj = 0;                    // stamp round trip through LDS overlaps the scoring below
-						if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, stamp_v, t_bytes, t, lane,
-						                                        (((jtop << 3) + nl8) & ((R - 1) << 3)) >> 1);
+						if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, s16_v, t_bytes, t, lane,
+						                                        (((jtop << 1) + nl2) & ((2 * R - 1) << 1)));
 						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
 						const int scv = sel(valid, SENT, sc);
-						const mask_t marked = SKIP ? BALLOT(tj == stamp) : 0;
+						const mask_t marked = SKIP ? BALLOT(tj == s16) : 0;
 						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
 					}
 					jtop -= 64; rem -= 64;
@@ -348,7 +349,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 					const int2 fp = *(const int2 *)(fp_bytes + off8);
 					int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
 					if (GEN) gj = s_g[off8 >> 3];
-					const int own_off4 = off8 >> 1;
+					const int own_off2 = ((jtop << 1) + nl2) & ((2 * R - 1) << 1);
 					const mask_t in_w = first_lanes(rem);
 					mask_t far_l = 0;                                     // lanes whose predecessor left the ring
 					if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
@@ -379,7 +380,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 							if (SKIP) {
 								const bool mkv = (valid >> lane & 1) && pj >= lo;
 								if (mkv) {
-									if (pj >= lds_lo) s_t[pj & (R - 1)] = stamp;
+									if (pj >= lds_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
 									else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								}
 								asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
@@ -387,16 +388,16 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 								__builtin_amdgcn_wave_barrier();
 								int tj = 0;
 								if (fl) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								else tj = s_t[j & (R - 1)];
+								else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
 								marked = BALLOT(tj == stamp);
 							}
 						}
 						int tj = 0;
 						const bool near_stamps = SKIP && !(FAR && far_l != 0);
-						if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, stamp_v, t_bytes, t, lane, own_off4);
+						if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
 						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
 						const int scv = sel(valid, SENT, sc);
-						if (near_stamps) marked = BALLOT(tj == stamp);
+						if (near_stamps) marked = BALLOT(tj == s16);
 						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
 					}
 					jtop -= 64; rem -= 64;
@@ -413,7 +414,9 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// reach into the current tile, so once per tile is enough) and leave in coalesced 256 B stores
 		if (lane < cnt) {
 			const int o = i0 + cnt - 1 - lane;
+			s_xq[o & (R - 1)] = make_uint2((uint32_t)wx, (uint32_t)wq);
 			s_fp[o & (R - 1)] = make_int2(wf, wp);
+			if (GEN) s_g[o & (R - 1)] = (uint8_t)wg;
 			f[o] = wf; p[o] = wp;
 		}
 		cur = nxt; cur_st = nxt_st;
@@ -455,7 +458,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const bool gs1 = P.gap_scale == 1.0f;
 	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
-	const bool far_ = (int64_t)P.max_iter + 64 > (int64_t)R;
+	const bool far_ = (int64_t)P.max_iter > (int64_t)R;   // the ring always holds the R anchors before the current tile
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(64), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st);
 	hipError_t e = hipGetLastError();

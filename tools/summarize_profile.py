@@ -27,7 +27,7 @@ for fn in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))
         k = r["Kernel_Name"]
         if "mm2c::" not in k:
             continue
-        kk = "chain_dp_wave (general redo pass)" if ("chain_dp_wave" in k and float(r["Counter_Value"]) >= 0 and ", true, true" in k.split("(")[0] + "x" and False) else k.split("(")[0].replace("void ", "")
+        kk = k.split("(")[0].replace("void ", "")
         agg[kk][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines += ["", "## PMC counters, mean per launch", ""]
 traffic = None
@@ -42,6 +42,9 @@ for k, d in sorted(agg.items()):
         fs = sorted(d["FETCH_SIZE"])[len(d["FETCH_SIZE"]) // 2:]
         ws = sorted(d["WRITE_SIZE"])[len(d["WRITE_SIZE"]) // 2:]
         fetch_kb, write_kb = sum(fs) / len(fs), sum(ws) / len(ws)
+        if traffic is not None and traffic["fetch_size_kb"] >= fetch_kb:
+            lines.append("")
+            continue
         traffic = {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
                    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024, "anchors_per_launch": anchors,
                    "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
