@@ -6,13 +6,17 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or load it.  The shipped library
  * (minimap2-fpga_amd/csrc) never calls into this file.
  *
- * PARITY PINNING STATUS: see DESIGN.md "Oracle pinning".  The reference's own chain.c cannot be built in
- * this image (chain.c -> chain_hardware.h:6 -> xcl2.hpp:34 includes <CL/cl_ext_xilinx.h>, a Xilinx XRT
- * vendor header that is absent), the reference tree holds no f[]/p[] known-answer vectors, so the DP
- * restatement is pinned (a) by hand-derived known-answer cases from the recurrence, (b) by an independent
- * literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree with the CPU restatement
- * under V2 parameters, and (c) end-to-end through the reference's own non-path host sources + test FASTA
- * (oracle/ref_host, PAF lines recorded in SURVEY.md section 4) when that harness is built.
+ * PARITY PINNING STATUS (details: DESIGN.md section 4).  The reference's own chain.c cannot be built in this image
+ * (chain.c -> chain_hardware.h:6 -> xcl2.hpp:34 includes <CL/cl_ext_xilinx.h>, a Xilinx XRT vendor header that is absent;
+ * no stand-in header is written) and the reference tree holds no f[]/p[] known-answer vectors.  The restatement is pinned
+ *  (a) END TO END AGAINST THE REFERENCE'S RECORDED OUTPUT: oracle/ref_host links the reference's own non-path host objects
+ *      (index, sketch, seeding, hit, format; built in place from /root/reference) with mm2o_mm_chain_dp and reproduces,
+ *      byte for byte, the PAF the real reference prints for its test data (MT-human vs MT-orang,
+ *      md5 f49a6331..., cm:i:342 s1:i:3189; t-inv vs q-inv; t2 vs q2) -- tests/test_cpu_ref_host.py;
+ *  (b) by hand-derived known-answer cases from the recurrence and an independent Python restatement;
+ *  (c) by a literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree under V2 parameters.
+ * (a) constrains f[]/p[] through the chains they produce on three real anchor lists (n = 346, 223, 732), not element by
+ * element on arbitrary inputs: element-wise coverage rests on (b) and (c).
  */
 #ifndef MM2_CHAIN_ORACLE_H
 #define MM2_CHAIN_ORACLE_H

@@ -1,0 +1,43 @@
+/* chain_shim.c -- test infrastructure: gives the reference host objects an mm_chain_dp (mmpriv.h:65) that is computed
+ * by the repo's CPU oracle, and optionally dumps every anchor list that reaches it (MM2O_DUMP=<file>): per call a
+ * header {int64 n; int32 max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, is_cdna, n_segs; float gap_scale}
+ * followed by n 16-byte anchors. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "minimap.h"
+#include "mmpriv.h"
+#include "kalloc.h"
+#include "chain_oracle.h"
+
+mm128_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc, float gap_scale,
+                     int is_cdna, int n_segs, int64_t n, mm128_t *a, int *n_u_, uint64_t **_u, void *km, int tid)
+{
+	mm2o_params_t par = { max_dist_x, max_dist_y, bw, max_skip, max_iter, gap_scale, is_cdna, n_segs };
+	uint64_t *u = 0;
+	mm2o_anchor_t *b = 0;
+	int64_t n_b = 0;
+	int32_t n_u;
+	mm128_t *ret = 0;
+	const char *dump = getenv("MM2O_DUMP");
+	(void)tid;
+	if (_u) *_u = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) { kfree(km, a); return 0; }
+	if (dump) {
+		FILE *fp = fopen(dump, "ab");
+		int32_t h[9] = { max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, is_cdna, n_segs };
+		fwrite(&n, 8, 1, fp); fwrite(h, 4, 9, fp); fwrite(&gap_scale, 4, 1, fp); fwrite(a, 16, (size_t)n, fp);
+		fclose(fp);
+	}
+	n_u = mm2o_mm_chain_dp(&par, min_cnt, min_sc, n, (const mm2o_anchor_t *)a, &u, &b, &n_b);
+	kfree(km, a);                                         /* chain.c:421: the callee owns a */
+	if (n_u > 0) {
+		uint64_t *uk = (uint64_t *)kmalloc(km, (size_t)n_u * 8);
+		ret = (mm128_t *)kmalloc(km, (size_t)n_b * sizeof(mm128_t));
+		memcpy(uk, u, (size_t)n_u * 8);
+		memcpy(ret, b, (size_t)n_b * sizeof(mm128_t));
+		*n_u_ = n_u, *_u = uk;
+	}
+	free(u); free(b);
+	return ret;
+}

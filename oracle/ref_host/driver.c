@@ -1,0 +1,62 @@
+/* driver.c -- test infrastructure: `minimap2 -x map-ont -t 1 <ref.fa> <query.fa>` without main.c / options.c (which need
+ * the Xilinx header).  Option values restated from options.c:8-57 (defaults) and :93-94 (map-ont: k=15, flag 0); flow as
+ * main.c:286-287,371-410.  Links the reference's own index / sketch / map / hit / format objects. */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "minimap.h"
+#include "mmpriv.h"
+
+/* symbols of options.c that the library objects import */
+void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi)          /* options.c:59-69 */
+{
+	if ((opt->flag & MM_F_SPLICE_FOR) || (opt->flag & MM_F_SPLICE_REV)) opt->flag |= MM_F_SPLICE;
+	if (opt->mid_occ <= 0) opt->mid_occ = mm_idx_cal_max_occ(mi, opt->mid_occ_frac);
+	if (opt->mid_occ < opt->min_mid_occ) opt->mid_occ = opt->min_mid_occ;
+}
+
+void mm_idxopt_init(mm_idxopt_t *io)                                    /* options.c:8-15, imported by index.c:569 */
+{
+	memset(io, 0, sizeof(*io));
+	io->k = 15; io->w = 10; io->flag = 0; io->bucket_bits = 14;
+	io->mini_batch_size = 50000000; io->batch_size = 4000000000ULL;
+}
+
+static void defaults(mm_idxopt_t *io, mm_mapopt_t *mo)
+{
+	mm_idxopt_init(io); memset(mo, 0, sizeof(*mo));
+	mo->seed = 11; mo->mid_occ_frac = 2e-4f; mo->sdust_thres = 0;          /* options.c:20-22 */
+	mo->min_cnt = 3; mo->min_chain_score = 40; mo->bw = 500; mo->max_gap = 5000; mo->max_gap_ref = -1;   /* :24-28 */
+	mo->max_chain_skip = 25; mo->max_chain_iter = 5000; mo->chain_gap_scale = 1.0f;                       /* :29-31 */
+	mo->mask_level = 0.5f; mo->mask_len = INT_MAX; mo->pri_ratio = 0.8f; mo->best_n = 5;                  /* :33-36 */
+	mo->max_join_long = 20000; mo->max_join_short = 2000; mo->min_join_flank_sc = 1000; mo->min_join_flank_ratio = 0.5f;
+	mo->alt_drop = 0.15f;
+	mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1;                 /* :45-46 */
+	mo->zdrop = 400; mo->zdrop_inv = 200; mo->end_bonus = -1; mo->min_dp_max = mo->min_chain_score * mo->a;
+	mo->min_ksw_len = 200; mo->anchor_ext_len = 20; mo->anchor_ext_shift = 6; mo->max_clip_ratio = 1.0f;
+	mo->mini_batch_size = 500000000; mo->pe_ori = 0; mo->pe_bonus = 33;                                    /* :53-56 */
+}
+
+int main(int argc, char *argv[])
+{
+	mm_idxopt_t io;
+	mm_mapopt_t mo;
+	mm_idx_reader_t *r;
+	mm_idx_t *mi;
+	if (argc < 3) { fprintf(stderr, "usage: %s <ref.fa> <query.fa>\n", argv[0]); return 1; }
+	mm_verbose = 1;
+	mm_realtime0 = realtime();
+	defaults(&io, &mo);
+	io.flag = 0; io.k = 15;                              /* -x map-ont, options.c:93-94 */
+	io.flag |= MM_I_NO_SEQ;                              /* main.c:286-287: no -d, no CIGAR */
+	r = mm_idx_reader_open(argv[1], &io, 0);
+	if (!r) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+	while ((mi = mm_idx_reader_read(r, 1)) != 0) {
+		mm_mapopt_update(&mo, mi);                       /* main.c:399 */
+		if (mm_map_file(mi, argv[2], &mo, 1) < 0) { fprintf(stderr, "mapping failed\n"); return 1; }   /* main.c:406 */
+		mm_idx_destroy(mi);
+	}
+	mm_idx_reader_close(r);
+	return fflush(stdout) == EOF;
+}

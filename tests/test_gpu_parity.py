@@ -201,6 +201,25 @@ def test_host_paths_and_mm_chain_dp():
     assert u.size == 0 and b.size == 0
 
 
+def test_real_anchor_lists_from_the_reference_test_data():
+    """anchors that reach mm_chain_dp for test/MT-human.fa vs MT-orang.fa and t-inv.fa vs q-inv.fa (dumped through the
+    reference's own host objects, tests/golden/make_ref_anchor_fixtures.py): f/p through the kernel, chains through mm_chain_dp"""
+    import os
+    import mm2chain
+    from mm2chain import params
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_testdata_anchors.npz"))
+    for k in range(int(z["n_calls"])):
+        h = z[f"c{k}_par"]
+        a = z[f"c{k}_anchors"]
+        P = params.make_params(int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4]), float(h[9]), int(h[7]), int(h[8]))
+        f, p = gpu_batch(P, np.array([0, a.shape[0]], dtype=np.int64), a)
+        assert_same(f, p, z[f"c{k}_f"], z[f"c{k}_p"], None, f"real anchors call {k}")
+        u, b = mm2chain.mm_chain_dp(int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4]), int(h[5]), int(h[6]), float(h[9]),
+                                    int(h[7]), int(h[8]), a)
+        assert np.array_equal(u, z[f"c{k}_u"]) and np.array_equal(b, z[f"c{k}_b"])
+    assert int(z["c0_u"][0] >> np.uint64(32)) == 3189        # PAF s1:i:3189 of the reference (SURVEY section 4)
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (5000 anchors per read, many reads): properties that need no oracle at full size, plus a
     sampled oracle check.  f[i] >= span, -1 <= p[i] < i, f[i] - f[p[i]] <= span, replicated tasks give replicated output."""
