@@ -94,6 +94,14 @@ int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
 int mm2c_plan_last_prepass_ms(mm2c_plan_t *plan, float *ms);
 
+/*
+ * The reference's HW/SW prediction pass (chain.c:53-78) for every task of the plan, on the GPU: num_subparts[total]
+ * (uint8, what chain.c:76 stores and run_chaining_on_hw receives), and per task total_subparts (chain.c:77) and
+ * total_trip_count (chain.c:69), the inputs of the two linear time models of chain.c:80-81.  Any output may be NULL.
+ */
+int mm2c_plan_predict_device(mm2c_plan_t *plan, const void *d_anchors, uint8_t *d_num_subparts,
+                             int64_t *d_total_subparts, int64_t *d_total_trip_count, void *stream);
+
 /* ---- host-buffer paths (PCIe included) ---------------------------------------------------------------------- */
 /* whole batch from pageable host memory: staging, H2D, DP, D2H, sync */
 int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets,

@@ -34,6 +34,9 @@ struct LaunchArgs {
 };
 
 int chain_ring_anchors(int ring_class);
+// chain.c:53-78 for a CSR batch: per-anchor sub-part counts, per-task totals (any output may be nullptr)
+hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_offsets, const int32_t *d_order, const void *d_anchors,
+                          uint8_t *d_num_subparts, int64_t *d_total_subparts, int64_t *d_total_trip, hipStream_t st);
 // ev_dp_begin (optional) is recorded between the window-start prepass and the DP kernel
 hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin);
 

@@ -248,6 +248,40 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	}
 }
 
+// ---------------------------------------------------------------- the reference's HW/SW prediction pass, chain.c:53-78
+// Per anchor: inner-loop trip count min(i - st, 1024) with the UNclamped st of chain.c:64 (no max_iter here), the
+// number of 128-wide sub-parts the FPGA pipeline would spend on it (chain.c:74-76, chain_hardware.h:58-60); per task
+// their sums (total_trip_count chain.c:69, total_subparts chain.c:77), which feed the two linear time models
+// (chain.c:80-81).  One wave per task.
+__global__ void __launch_bounds__(64)
+chain_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+              const ulonglong2 *__restrict__ a_all, uint8_t *__restrict__ nsub_all, int64_t *__restrict__ total_sub,
+              int64_t *__restrict__ total_trip)
+{
+	const int lane = threadIdx.x;
+	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
+	if (task >= n_tasks) return;
+	const int64_t base = offsets[task];
+	const int n = (int)(offsets[task + 1] - base);
+	const ulonglong2 *a = a_all + base;
+	const uint64_t D = (uint64_t)(int64_t)max_dist_x;
+	int64_t s_sub = 0, s_trip = 0;
+	for (int i = lane; i < n; i += 64) {
+		const uint64_t xi = a[i].x;
+		int lo = 0, hi = i;
+		while (lo < hi) {
+			const int mid = (lo + hi) >> 1;
+			if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;
+		}
+		const int trip = min(i - lo, 1024);
+		const int sub = trip / 128 + ((trip == 0 || trip % 128 > 0) ? 1 : 0);
+		if (nsub_all) nsub_all[base + i] = (uint8_t)sub;
+		s_sub += sub; s_trip += trip;
+	}
+	for (int o = 32; o > 0; o >>= 1) { s_sub += __shfl_xor(s_sub, o); s_trip += __shfl_xor(s_trip, o); }
+	if (lane == 0) { if (total_sub) total_sub[task] = s_sub; if (total_trip) total_trip[task] = s_trip; }
+}
+
 // ---------------------------------------------------------------- the kernel: one wave per task
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __global__ void __launch_bounds__(64)
@@ -445,6 +479,15 @@ static hipError_t launch_r(const LaunchArgs &L, hipStream_t st, bool skip, bool 
 {
 	if (gen) return far_ ? launch_sg<R, true, true>(L, st, skip, gs1, only_flagged) : launch_sg<R, true, false>(L, st, skip, gs1, only_flagged);
 	return far_ ? launch_sg<R, false, true>(L, st, skip, gs1, only_flagged) : launch_sg<R, false, false>(L, st, skip, gs1, only_flagged);
+}
+
+hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_offsets, const int32_t *d_order, const void *d_anchors,
+                          uint8_t *d_num_subparts, int64_t *d_total_subparts, int64_t *d_total_trip, hipStream_t st)
+{
+	if (n_tasks <= 0) return hipSuccess;
+	hipLaunchKernelGGL(chain_predict, dim3((unsigned)n_tasks), dim3(64), 0, st, max_dist_x, n_tasks, d_offsets, d_order,
+	                   (const ulonglong2 *)d_anchors, d_num_subparts, d_total_subparts, d_total_trip);
+	return hipGetLastError();
 }
 
 int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : 1024; }

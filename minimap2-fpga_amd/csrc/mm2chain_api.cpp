@@ -311,6 +311,20 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	return 0;
 }
 
+int mm2c_plan_predict_device(mm2c_plan_t *pl, const void *d_anchors, uint8_t *d_num_subparts, int64_t *d_total_subparts,
+                             int64_t *d_total_trip_count, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (pl->n_tasks == 0) return 0;
+	if (!d_anchors && pl->total > 0) return fail(MM2C_E_ARG, "device pointer is NULL");
+	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	HIP_TRY(mm2c::launch_predict(pl->par.max_dist_x, pl->n_tasks, pl->d_off, pl->d_order, d_anchors, d_num_subparts,
+	                             d_total_subparts, d_total_trip_count, st));
+	G.launches += 1;
+	return 0;
+}
+
 int mm2c_plan_last_prepass_ms(mm2c_plan_t *pl, float *ms)
 {
 	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");

@@ -75,6 +75,18 @@ class ChainPlan:
         N.check(self.lib.mm2c_plan_run_device(self.handle, anchors.data_ptr(), avg.data_ptr() if avg is not None else None,
                                               f.data_ptr(), p.data_ptr(), st), "mm2c_plan_run_device")
 
+    def predict(self, anchors: torch.Tensor, stream=None):
+        """chain.c:53-78 on the GPU: returns (num_subparts uint8 [total], total_subparts int64 [n_tasks],
+        total_trip_count int64 [n_tasks]) as device tensors"""
+        assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.numel() == 2 * self.total
+        ns = torch.empty(self.total, dtype=torch.uint8, device=anchors.device)
+        ts = torch.empty(self.n_tasks, dtype=torch.int64, device=anchors.device)
+        tt = torch.empty(self.n_tasks, dtype=torch.int64, device=anchors.device)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.mm2c_plan_predict_device(self.handle, anchors.data_ptr(), ns.data_ptr(), ts.data_ptr(), tt.data_ptr(), st),
+                "mm2c_plan_predict_device")
+        return ns, ts, tt
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")

@@ -182,6 +182,20 @@ def test_fpga_v2_through_the_reference_symbol():
         assert_same(f, p, f_v1, p_v1, None, "v2 as v1")
 
 
+def test_prediction_pass_matches_chain_c_53_78():
+    import mm2chain
+    from mm2chain import params
+    off, a = _stream("dense", 7, (100, 4000), seed=41, locus=7000)
+    plan = mm2chain.ChainPlan(params.map_ont(), off)
+    ns, ts, tt = plan.predict(torch.from_numpy(a.view(np.int64)).cuda())
+    torch.cuda.synchronize()
+    ns, ts, tt = ns.cpu().numpy(), ts.cpu().numpy(), tt.cpu().numpy()
+    for k in range(7):
+        ns_ref, tot_ref, trip_ref = ob.predict(a[off[k]:off[k + 1]], 5000)
+        assert np.array_equal(ns[off[k]:off[k + 1]], ns_ref) and ts[k] == tot_ref and tt[k] == trip_ref
+    plan.close()
+
+
 def test_host_paths_and_mm_chain_dp():
     import mm2chain
     from mm2chain import params
