@@ -115,6 +115,8 @@ def chain_batch_host(params: Params, offsets, anchors, avg=None):
     off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
     a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
     total = int(off[-1] - off[0]) if off.size else 0
+    if off.size and (off[0] < 0 or off[-1] > a.shape[0]):
+        raise ValueError("offsets do not fit the anchor array")
     f = np.empty(int(off[-1]) if off.size else 0, dtype=np.int32)
     p = np.empty_like(f)
     avg_p = None

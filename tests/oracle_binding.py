@@ -85,6 +85,7 @@ def chain_batch(par, offsets, anchors, n_threads=1):
     """f, p over a CSR batch; returns (f, p, seconds)"""
     a = as_anchor_array(anchors)
     off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    assert off.size >= 1 and off[0] >= 0 and off[-1] <= a.shape[0] and np.all(np.diff(off) >= 0), "offsets do not fit the anchor array"
     f = np.zeros(a.shape[0], np.int32); p = np.zeros(a.shape[0], np.int32)
     op = par if isinstance(par, OParams) else oparams(par)
     secs = load().mm2o_bench_batch(C.byref(op), off.size - 1, _ptr(off), _ptr(a), _ptr(f), _ptr(p), n_threads)

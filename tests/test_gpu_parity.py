@@ -234,6 +234,28 @@ def test_real_anchor_lists_from_the_reference_test_data():
     assert int(z["c0_u"][0] >> np.uint64(32)) == 3189        # PAF s1:i:3189 of the reference
 
 
+def test_one_long_task_and_many_tiny_tasks():
+    """ava-ont-like: one task of 300k anchors (long colinear chains + noise) beside 20k tasks of 1..40 anchors"""
+    from mm2chain import params, synth
+    P = params.ava_ont()
+    _, a_long = synth.make_stream("mixed", 1, 300000, seed=77, locus=3000000)
+    sizes = [300000]
+    parts = [a_long.numpy().view(np.uint64)]
+    rng = np.random.default_rng(5)
+    _, a_small = synth.make_stream("dense", 1, 820000, seed=78, locus=40000000)
+    a_small = a_small.numpy().view(np.uint64)
+    pos = 0
+    for _ in range(20000):
+        n = int(rng.integers(1, 41))
+        assert pos + n <= a_small.shape[0]
+        parts.append(a_small[pos:pos + n]); sizes.append(n); pos += n
+    a = np.concatenate(parts)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "long + tiny")
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (5000 anchors per read, many reads): properties that need no oracle at full size, plus a
     sampled oracle check.  f[i] >= span, -1 <= p[i] < i, f[i] - f[p[i]] <= span, replicated tasks give replicated output."""
