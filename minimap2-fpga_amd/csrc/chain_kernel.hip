@@ -195,7 +195,7 @@ __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t va
 
 // ---------------------------------------------------------------- chain.c:233 + :229 for a chunk whose lanes are all ring-resident
 // Every visited, unfiltered j stamps its predecessor p[j] (stamps for targets outside the window are never read for
-// this i and are dropped); then each lane fetches its own stamp.  LDS stamps are 16 bit, s16 = 1 + i % 65535 (0 = never
+// this i and are dropped); then each lane fetches its own stamp.  LDS stamps are 16 bit, s16 = 1 + i % 16384 (0 = never
 // stamped, chain.c:46), in a ring of 2R slots that is cleared as anchors enter it, so a value identifies its anchor.
 // Lanes that do not stamp write to the sink slot [2R].  A ring-resident j may still point beyond the ring: that
 // stamp (the full i+1) goes to the global scratch t[].
@@ -218,6 +218,106 @@ __device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	return *(const uint16_t *)(t_bytes + own_off2);                   // the caller tests it against s16 (chain.c:229 `t[j] == i`)
+}
+
+// ---------------------------------------------------------------- the look-back scan of one anchor, chain.c:197-235
+struct Win { int x, q, f, p, g; };      // chunk-0 window registers: lane L = anchor i-1-L
+
+template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
+__device__ __forceinline__ void scan_window(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int xi, int qi, int span_i,
+                                            int seg_i, const Win &w, const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g,
+                                            char *t_bytes, uint16_t *s_t, const uint4 *a, const int32_t *f, const int32_t *p,
+                                            int32_t *t, Carry &c)
+{
+	const int nl8 = -8 * lane, nl2 = -2 * lane;               // ring byte offsets go down with the lane
+	const int wx = w.x, wq = w.q, wf = w.f, wp = w.p, wg = w.g;
+	int rem = i - lo;                  // predecessors still to visit (> 0)
+	{
+		const int stamp = i + 1;              // stamp in the global scratch t[] (look-back beyond the ring)
+		const int s16 = 1 + (i & 0x3fff);     // stamp in the LDS ring: unique over the < R+64 anchors that can stamp a slot between two clears
+		const int s16_v = s16;                 // (one v_mov: the ds_write data operand)
+		int jtop = i - 1;
+		bool broke = false;
+		// ---------------- chunk 0 from registers
+		{
+			const int dr = xi - wx, dq = qi - wq;
+			const int dd = absdiff(dr, dq);
+			const mask_t same = GEN ? BALLOT(wg == seg_i) : ~0ull;
+			const mask_t valid = pair_filter<GEN>(P, first_lanes(rem), dr, dq, dd, same);
+			if (valid != 0) {
+				int tj = 0;                    // stamp round trip through LDS overlaps the scoring below
+				if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, s16_v, t_bytes, t, lane,
+				                                        (((jtop << 1) + nl2) & ((2 * R - 1) << 1)));
+				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
+				const int scv = sel(valid, SENT, sc);
+				const mask_t marked = SKIP ? BALLOT(tj == s16) : 0;
+				broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
+			}
+			jtop -= 64; rem -= 64;
+		}
+		// ---------------- older chunks from the LDS ring (and from L2/HBM beyond it)
+		while (rem > 0 && !broke) {
+			const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
+			const uint2 xq = *(const uint2 *)(xq_bytes + off8);
+			const int2 fp = *(const int2 *)(fp_bytes + off8);
+			int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
+			if (GEN) gj = s_g[off8 >> 3];
+			const int own_off2 = ((jtop << 1) + nl2) & ((2 * R - 1) << 1);
+			const mask_t in_w = first_lanes(rem);
+			mask_t far_l = 0;                                     // lanes whose predecessor left the ring
+			if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
+				int j = jtop - lane;
+				asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
+				far_l = BALLOT(j < lds_lo) & in_w;
+				if (far_l >> lane & 1) {
+					const uint4 aj = a[j];
+					xj = (int)aj.x; qj = (int)aj.z;
+					if (GEN) gj = (aj.w >> 16) & 0xff;
+				}
+			}
+			const int dr = xi - xj, dq = qi - qj;
+			const int dd = absdiff(dr, dq);
+			const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
+			const mask_t valid = pair_filter<GEN>(P, in_w, dr, dq, dd, same);
+			if (valid != 0) {
+				mask_t marked = 0;
+				if (FAR && far_l != 0) {
+					// look-back beyond the ring: f, p and stamps from L2/HBM, only for lanes that passed the filters
+					int j = jtop - lane;
+					asm volatile("" : "+v"(j));
+					const bool fl = (far_l & valid) >> lane & 1;
+					if (fl) {
+						fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+					if (SKIP) {
+						const bool mkv = (valid >> lane & 1) && pj >= lo;
+						if (mkv) {
+							if (pj >= lds_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
+							else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+						__builtin_amdgcn_wave_barrier();
+						int tj = 0;
+						if (fl) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
+						marked = BALLOT(tj == stamp);
+					}
+				}
+				int tj = 0;
+				const bool near_stamps = SKIP && !(FAR && far_l != 0);
+				if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
+				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
+				const int scv = sel(valid, SENT, sc);
+				if (near_stamps) marked = BALLOT(tj == s16);
+				broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
+			}
+			jtop -= 64; rem -= 64;
+		}
+	
+
+	}
 }
 
 // ---------------------------------------------------------------- prepass: window start of every anchor
@@ -319,7 +419,6 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
 	}
 
-	const int nl8 = -8 * lane, nl2 = -2 * lane;               // ring byte offsets go down with the lane
 	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
 	int seg0 = 0;
 	char *const t_bytes = (char *)s_t;
@@ -352,90 +451,15 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int seg_i = GEN ? rdlane(g_l, k) : 0;                                         // chain.c:191
 			const int lo = rdlane(cur_st, k);                                                   // chain.c:192-193
 			Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
-			int rem = i - lo;                  // predecessors still to visit
-			if (rem > 0) {
-				const int stamp = i + 1;              // stamp in the global scratch t[] (look-back beyond the ring)
-				const int s16 = 1 + i % 65535;        // stamp in the LDS ring
-				const int s16_v = s16;                 // (one v_mov: the ds_write data operand)
-				int jtop = i - 1;
-				bool broke = false;
-				// ---------------- chunk 0 from registers
-				{
-					const int dr = xi - wx, dq = qi - wq;
-					const int dd = absdiff(dr, dq);
-					const mask_t same = GEN ? BALLOT(wg == seg_i) : ~0ull;
-					const mask_t valid = pair_filter<GEN>(P, first_lanes(rem), dr, dq, dd, same);
-					if (valid != 0) {
-						int tj = 0;                    // stamp round trip through LDS overlaps the scoring below
-						if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, s16_v, t_bytes, t, lane,
-						                                        (((jtop << 1) + nl2) & ((2 * R - 1) << 1)));
-						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
-						const int scv = sel(valid, SENT, sc);
-						const mask_t marked = SKIP ? BALLOT(tj == s16) : 0;
-						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
-					}
-					jtop -= 64; rem -= 64;
-				}
-				// ---------------- older chunks from the LDS ring (and from L2/HBM beyond it)
-				while (rem > 0 && !broke) {
-					const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
-					const uint2 xq = *(const uint2 *)(xq_bytes + off8);
-					const int2 fp = *(const int2 *)(fp_bytes + off8);
-					int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
-					if (GEN) gj = s_g[off8 >> 3];
-					const int own_off2 = ((jtop << 1) + nl2) & ((2 * R - 1) << 1);
-					const mask_t in_w = first_lanes(rem);
-					mask_t far_l = 0;                                     // lanes whose predecessor left the ring
-					if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
-						int j = jtop - lane;
-						asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
-						far_l = BALLOT(j < lds_lo) & in_w;
-						if (far_l >> lane & 1) {
-							const uint4 aj = a[j];
-							xj = (int)aj.x; qj = (int)aj.z;
-							if (GEN) gj = (aj.w >> 16) & 0xff;
-						}
-					}
-					const int dr = xi - xj, dq = qi - qj;
-					const int dd = absdiff(dr, dq);
-					const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
-					const mask_t valid = pair_filter<GEN>(P, in_w, dr, dq, dd, same);
-					if (valid != 0) {
-						mask_t marked = 0;
-						if (FAR && far_l != 0) {
-							// look-back beyond the ring: f, p and stamps from L2/HBM, only for lanes that passed the filters
-							int j = jtop - lane;
-							asm volatile("" : "+v"(j));
-							const bool fl = (far_l & valid) >> lane & 1;
-							if (fl) {
-								fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							}
-							if (SKIP) {
-								const bool mkv = (valid >> lane & 1) && pj >= lo;
-								if (mkv) {
-									if (pj >= lds_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
-									else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								}
-								asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
-								__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-								__builtin_amdgcn_wave_barrier();
-								int tj = 0;
-								if (fl) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
-								marked = BALLOT(tj == stamp);
-							}
-						}
-						int tj = 0;
-						const bool near_stamps = SKIP && !(FAR && far_l != 0);
-						if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
-						const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
-						const int scv = sel(valid, SENT, sc);
-						if (near_stamps) marked = BALLOT(tj == s16);
-						broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
-					}
-					jtop -= 64; rem -= 64;
-				}
+			if (i - lo > 0) {
+				Win w = { wx, wq, wf, wp, wg };
+				// the common case (window entirely inside the LDS ring) runs a loop with no look-back-beyond-the-ring tests
+				if (!FAR || lo >= lds_lo)
+					scan_window<R, SKIP, GEN, GS1, false>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
+					                                      t_bytes, s_t, a, f, p, t, c);
+				else
+					scan_window<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
+					                                    t_bytes, s_t, a, f, p, t, c);
 			}
 			// ---- commit anchor i (chain.c:236) into the chunk-0 window
 			wx = window_push(wx, xi);
