@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
     ap.add_argument("--ring-class", type=int, default=None)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,6 +175,8 @@ def main():
 
     # ---- secondary figures (outside the timed region, rank 0)
     try:
+        if args.no_secondary:
+            raise StopIteration
         _, _, tt = plan_predict_totals(mm2chain, P, off1, a1)
         out["secondary"] = {"nominal_cells_per_s": float(tt) * times / (k_avg_ms * 1e-3),
                             "nominal_cells_definition": "sum over anchors of min(i - st, 1024), the reference's total_trip_count (chain.c:69)",
@@ -188,6 +191,8 @@ def main():
         out["host_streamed"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s",
                                 "sample": f"{n_h} reads ({int(off_host[-1])} anchors) from pageable host memory: H2D + prepass + DP + D2H + sync, 1 call",
                                 "matches_resident": bool(np.array_equal(fh, d_f[: int(off_host[-1])].cpu().numpy()))}
+    except StopIteration:
+        pass
     except Exception as e:                                                   # never let a secondary figure break the line
         out["secondary_error"] = repr(e)
 

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-seconds 0 $*"
+BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-secondary $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace exit $?" >> $OUT/trace.log
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
