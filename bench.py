@@ -91,10 +91,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (never set by the driver): MM2C_BENCH_BACKEND=gloo and MM2C_BENCH_ONE_DEVICE=1 let several ranks share
+    # one GPU on a 1-GPU box to exercise the multi-process flow; the real runs use nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get("MM2C_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MM2C_BENCH_ONE_DEVICE") == "1" else local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
