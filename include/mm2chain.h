@@ -128,6 +128,21 @@ mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip,
                            int min_sc, float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a,
                            int *n_u_, uint64_t **_u, void *km, int tid);
 
+/* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
+typedef struct {
+	mm2c_params_t par;            /* scalars of the mm_chain_dp calls the tasks came from */
+	int32_t min_cnt, min_sc;      /* mm_chain_dp arguments 6-7, used by the backtrack only */
+	int64_t n_tasks, total;
+	int64_t *offsets;             /* n_tasks + 1, offsets[0] = 0; malloc'ed by the readers */
+	mm2c_anchor_t *anchors;       /* total */
+} mm2c_stream_t;
+int  mm2c_stream_write(const char *path, const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_tasks,
+                       const int64_t *offsets, const mm2c_anchor_t *anchors);
+int  mm2c_stream_read(const char *path, mm2c_stream_t *out);
+/* import what `minimap2 --print-seeds` prints before chaining (RS / SD lines, map.c:298-303) */
+int  mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par, int min_cnt, int min_sc, mm2c_stream_t *out);
+void mm2c_stream_free(mm2c_stream_t *s);
+
 /* statistics since mm2c_init: tasks, anchors, and kernel launches issued through any entry point */
 typedef struct { uint64_t tasks, anchors, launches; } mm2c_stats_t;
 void mm2c_get_stats(mm2c_stats_t *out);

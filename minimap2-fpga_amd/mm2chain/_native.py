@@ -17,6 +17,12 @@ class Params(C.Structure):
                 ("flags", C.c_int32)]
 
 
+class Stream(C.Structure):
+    """mm2c_stream_t"""
+    _fields_ = [("par", Params), ("min_cnt", C.c_int32), ("min_sc", C.c_int32), ("n_tasks", C.c_int64), ("total", C.c_int64),
+                ("offsets", C.POINTER(C.c_int64)), ("anchors", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64)]
 
@@ -42,6 +48,10 @@ C_SYMBOLS = {
     "mm_chain_dp": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                  C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
     "mm2c_get_stats": (None, [C.POINTER(Stats)]),
+    "mm2c_stream_write": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mm2c_stream_read": (C.c_int, [C.c_char_p, C.POINTER(Stream)]),
+    "mm2c_stream_from_seed_dump": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Stream)]),
+    "mm2c_stream_free": (None, [C.POINTER(Stream)]),
 }
 # C++-linkage drop-in symbols the reference objects import (chain_hardware.h:68-71)
 CXX_SYMBOLS = {

@@ -46,6 +46,7 @@ int main(int argc, char *argv[])
 	mm_idx_t *mi;
 	if (argc < 3) { fprintf(stderr, "usage: %s <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
+	if (getenv("MM2_PRINT_SEEDS")) mm_dbg_flag |= MM_DBG_PRINT_SEED;   /* main.c:193 --print-seeds */
 	mm_realtime0 = realtime();
 	defaults(&io, &mo);
 	io.flag = 0; io.k = 15;                              /* -x map-ont, options.c:93-94 */

@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP kernel, called through the C ABI, must equal the CPU oracle bit for bit (f[] and p[]).
 Reference path: chain.c:184-238 (V1) and device/minimap2_opencl.cl (V2)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -254,6 +256,29 @@ def test_one_long_task_and_many_tiny_tasks():
     f_ref, p_ref = oracle_batch(P, off, a)
     f, p = gpu_batch(P, off, a)
     assert_same(f, p, f_ref, p_ref, off, "long + tiny")
+
+
+def test_batched_runner_on_a_stream_file(tmp_path):
+    """tools/mm2chain_run: stream file -> mini-batches through the C ABI -> f/p file and chains"""
+    import subprocess
+    import mm2chain
+    from mm2chain import params, stream
+    P = params.map_ont()
+    off, a = _stream("mixed", 40, (200, 3000), seed=13)
+    src, out = tmp_path / "in.mm2a", tmp_path / "out.bin"
+    stream.write(src, P, off, a)
+    exe = os.path.join(os.path.dirname(mm2chain.LIB_PATH), "tools", "mm2chain_run")
+    r = subprocess.run([exe, "-b", "20000", "-c", "-o", str(out), str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    fp = np.fromfile(out, dtype=np.int32)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    assert_same(fp[: f_ref.size], fp[f_ref.size:], f_ref, p_ref, off, "runner")
+    got = [tuple(map(int, ln.split("\t")[1:])) for ln in r.stdout.splitlines() if ln.startswith("CH")]
+    want = []
+    for k in range(40):
+        u, _ = ob.mm_chain_dp(P, 3, 40, a[off[k]:off[k + 1]])
+        want += [(k, int(x >> np.uint64(32)), int(x & np.uint64(0xFFFFFFFF))) for x in u]
+    assert got == want
 
 
 def test_full_size_properties():
