@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--anchors-per-read", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--preset", default="map-ont", choices=["map-ont", "asm20", "ava-ont"],
+                    help="chaining scalars + stream shape: map-ont (BASELINE config 2, default), asm20 (config 4 stand-in: span 19, "
+                         "7500 anchors/read), ava-ont (config 5 stand-in: bw 2000, max_gap 10000, 20000 anchors/read)")
     ap.add_argument("--ring-class", type=int, default=None)
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     args = ap.parse_args()
@@ -112,11 +115,24 @@ def main():
     if args.ring_class is not None:
         mm2chain.tune("ring_class", args.ring_class)
     P = params.map_ont()                                       # max_iter = 5000, max_skip = 25 (options.c:29-30)
+    q_span, locus = 15, None
+    if args.preset == "asm20":                                 # options.c:113-122: k = 19; cleaner, longer chains
+        P, q_span = params.asm20(), 19
+        if args.anchors_per_read == 5000:
+            args.anchors_per_read = 7500
+    elif args.preset == "ava-ont":                             # options.c:83-86
+        P = params.ava_ont()
+        if args.anchors_per_read == 5000:
+            args.anchors_per_read = 20000
+        locus = 400000
+        if args.reads == 65536:
+            args.reads, args.distinct = 16384, min(args.distinct, 2048)
 
     # ---- synthetic batch of this rank, generated on the device (deterministic: splitmix64 of seed + rank)
     distinct = min(args.distinct, args.reads)
     times = max(1, args.reads // distinct)
-    off1, a1 = synth.make_stream(args.profile, distinct, args.anchors_per_read, seed=args.seed + rank, device="cuda")
+    off1, a1 = synth.make_stream(args.profile, distinct, args.anchors_per_read, seed=args.seed + rank, q_span=q_span, device="cuda",
+                                 locus=locus)
     off, anchors = synth.replicate(off1, a1, times)
     n_tasks = off.numel() - 1
     total = int(off[-1])
@@ -170,9 +186,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"synthetic ONT anchor stream ({args.profile}), {args.anchors_per_read} anchors/read, "
-                               f"map-ont chaining params (max_iter=5000, max_skip=25), HBM-resident",
+                               f"{args.preset} chaining params (max_dist={P.max_dist_x}, bw={P.bw}, max_iter={P.max_iter}, max_skip={P.max_skip}), "
+                               f"HBM-resident",
                    "reads_per_gpu_per_step": n_tasks, "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
-                   "profile": args.profile, "parallelism": f"read-sharded x{world}"},
+                   "profile": args.profile, "preset": args.preset, "parallelism": f"read-sharded x{world}"},
         "verified_vs_oracle": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_wave", "kernel_ms_avg": k_avg_ms,
