@@ -258,6 +258,38 @@ def test_one_long_task_and_many_tiny_tasks():
     assert_same(f, p, f_ref, p_ref, off, "long + tiny")
 
 
+def _random_task(rng, n, n_refs, n_segs, dense):
+    """adversarial anchors: duplicated x, dq <= 0, huge jumps, several references/strands, random spans and segment ids"""
+    rows = []
+    for _ in range(n_refs):
+        strand, rid = int(rng.integers(0, 2)), int(rng.integers(0, 5))
+        pos = int(rng.integers(0, 1 << 20)); q = int(rng.integers(0, 5000))
+        for _ in range(n // n_refs):
+            r = rng.random()
+            pos += 0 if r < .08 else int(rng.integers(1, 12 if dense else 400)) if r < .95 else int(rng.integers(3000, 30000))
+            q += int(rng.integers(-40, 60 if dense else 300))
+            rows.append(mk_anchor(strand, rid, pos, max(q, 0), span=int(rng.integers(1, 40)), seg=int(rng.integers(0, n_segs))))
+    return pack(rows)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_parameters_and_adversarial_anchors(seed):
+    """every scalar of mm_chain_dp drawn at random (incl. degenerate values) on adversarial anchor lists"""
+    from mm2chain import params
+    rng = np.random.default_rng(1000 + seed)
+    n_segs = int(rng.choice([1, 1, 2, 3]))
+    P = params.make_params(max_dist_x=int(rng.choice([0, 50, 700, 5000, 100000])), max_dist_y=int(rng.choice([-5, 60, 700, 5000])),
+                           bw=int(rng.choice([-1, 0, 10, 500, 5000])), max_skip=int(rng.choice([-1, 0, 1, 5, 25, 300, INT32_MAX])),
+                           max_iter=int(rng.choice([-3, 0, 1, 63, 64, 65, 200, 5000, INT32_MAX])),
+                           gap_scale=float(rng.choice([1.0, 1.0, 0.5, 2.25, 0.0])), is_cdna=int(rng.integers(0, 2)), n_segs=n_segs)
+    tasks = [_random_task(rng, int(rng.integers(1, 1500)), int(rng.integers(1, 4)), n_segs, bool(rng.integers(0, 2))) for _ in range(10)]
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, f"random seed {seed}: {params.as_dict(P)}")
+
+
 def test_batched_runner_on_a_stream_file(tmp_path):
     """tools/mm2chain_run: stream file -> mini-batches through the C ABI -> f/p file and chains"""
     import subprocess
