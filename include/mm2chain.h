@@ -124,9 +124,11 @@ int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_
  * through mm2c_chain_task_host; v[] and the backtrack run on the calling thread.  Needs the host program's
  * kmalloc/kfree (kalloc.h:14,17) at link/load time.  Declared here with mm2c_anchor_t == mm128_t.
  */
+#ifndef MM2C_NO_MM_CHAIN_DP_DECL   /* define it in a host that already includes mmpriv.h (same function, mm128_t spelling) */
 mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt,
                            int min_sc, float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a,
                            int *n_u_, uint64_t **_u, void *km, int tid);
+#endif
 
 /* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
 typedef struct {

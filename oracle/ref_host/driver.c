@@ -7,6 +7,10 @@
 #include <string.h>
 #include "minimap.h"
 #include "mmpriv.h"
+#ifdef MM2_GPU_CHAINING
+#define MM2C_NO_MM_CHAIN_DP_DECL
+#include "mm2chain.h"
+#endif
 
 /* symbols of options.c that the library objects import */
 void mm_mapopt_update(mm_mapopt_t *opt, const mm_idx_t *mi)          /* options.c:59-69 */
@@ -46,6 +50,9 @@ int main(int argc, char *argv[])
 	mm_idx_t *mi;
 	if (argc < 3) { fprintf(stderr, "usage: %s <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
+#ifdef MM2_GPU_CHAINING
+	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
+#endif
 	if (getenv("MM2_PRINT_SEEDS")) mm_dbg_flag |= MM_DBG_PRINT_SEED;   /* main.c:193 --print-seeds */
 	mm_realtime0 = realtime();
 	defaults(&io, &mo);
@@ -59,5 +66,10 @@ int main(int argc, char *argv[])
 		mm_idx_destroy(mi);
 	}
 	mm_idx_reader_close(r);
+#ifdef MM2_GPU_CHAINING
+	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu launches\n",
+	                                                 (unsigned long long)st.tasks, (unsigned long long)st.anchors, (unsigned long long)st.launches); }
+	mm2c_shutdown();                                     /* cleanup, main.c:430 */
+#endif
 	return fflush(stdout) == EOF;
 }
