@@ -60,7 +60,8 @@ void mm2c_shutdown(void);
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
 /* tuning knobs (key, value): "ring_class" 0/1/2 = 256/512/1024 anchors of LDS ring per task (default 0, or env
- * MM2C_RING_CLASS).  Results never depend on a knob. */
+ * MM2C_RING_CLASS); "seg_min" = shortest piece (anchors) the host-buffer paths cut a task into at empty-window positions
+ * (default 256, 0 = never cut).  Results never depend on a knob. */
 int  mm2c_tune(const char *key, int value);
 
 /* defaults of `minimap2 -x map-ont` (options.c:24-31,93-99; map.c:305-316) */
@@ -146,7 +147,8 @@ int  mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par,
 void mm2c_stream_free(mm2c_stream_t *s);
 
 /* statistics since mm2c_init: tasks, anchors, and kernel launches issued through any entry point */
-typedef struct { uint64_t tasks, anchors, launches; } mm2c_stats_t;
+typedef struct { uint64_t tasks, anchors, launches, segments, host_call_ns; } mm2c_stats_t;   /* segments: pieces the host paths cut
+   tasks into; host_call_ns: wall time spent inside the host-buffer entry points, summed over calling threads */
 void mm2c_get_stats(mm2c_stats_t *out);
 
 #ifdef __cplusplus

@@ -26,6 +26,7 @@ struct LaunchArgs {
 	const int32_t *d_order;     // launch order (longest task first) or nullptr
 	const void *d_anchors;      // 16 B per anchor
 	const float *d_avg;         // per task or nullptr (computed in kernel, chain.c:48-49)
+	const int32_t *d_pbase;     // per task or nullptr: added to every p >= 0 on output (tasks that are pieces of a caller's task)
 	int32_t *d_f, *d_p;
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel

@@ -227,7 +227,7 @@ template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int xi, int qi, int span_i,
                                             int seg_i, const Win &w, const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g,
                                             char *t_bytes, uint16_t *s_t, const uint4 *a, const int32_t *f, const int32_t *p,
-                                            int32_t *t, Carry &c)
+                                            int32_t *t, int pbase, Carry &c)
 {
 	const int nl8 = -8 * lane, nl2 = -2 * lane;               // ring byte offsets go down with the lane
 	const int wx = w.x, wq = w.q, wf = w.f, wp = w.p, wg = w.g;
@@ -289,6 +289,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 					if (fl) {
 						fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (pj >= 0) pj -= pbase;             // p[] in memory is relative to the caller's task, the scan works piece-relative
 					}
 					if (SKIP) {
 						const bool mkv = (valid >> lane & 1) && pj >= lo;
@@ -386,8 +387,8 @@ chain_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *__restrict__ o
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __global__ void __launch_bounds__(64)
 chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-              const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ st_all,
-              int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
+              const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
+              const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
               int32_t *__restrict__ status, int only_flagged)
 {
 	static_assert(R >= 128 && (R & (R - 1)) == 0, "ring must be a power of two >= 128");
@@ -408,6 +409,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	int32_t *f = f_all + base, *p = p_all + base, *t = FAR ? t_all + base : nullptr;
 
 	for (int s = lane; s < 2 * R + 2; s += 64) s_t[s] = 0;
+	const int pbase = pbase_in ? pbase_in[task] : 0;
 
 	// avg_qspan_scaled, chain.c:48-49
 	float avg;
@@ -456,10 +458,10 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				// the common case (window entirely inside the LDS ring) runs a loop with no look-back-beyond-the-ring tests
 				if (!FAR || lo >= lds_lo)
 					scan_window<R, SKIP, GEN, GS1, false>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
-					                                      t_bytes, s_t, a, f, p, t, c);
+					                                      t_bytes, s_t, a, f, p, t, pbase, c);
 				else
 					scan_window<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
-					                                    t_bytes, s_t, a, f, p, t, c);
+					                                    t_bytes, s_t, a, f, p, t, pbase, c);
 			}
 			// ---- commit anchor i (chain.c:236) into the chunk-0 window
 			wx = window_push(wx, xi);
@@ -475,7 +477,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			s_xq[o & (R - 1)] = make_uint2((uint32_t)wx, (uint32_t)wq);
 			s_fp[o & (R - 1)] = make_int2(wf, wp);
 			if (GEN) s_g[o & (R - 1)] = (uint8_t)wg;
-			f[o] = wf; p[o] = wp;
+			f[o] = wf; p[o] = wp < 0 ? wp : wp + pbase;
 		}
 		cur = nxt; cur_st = nxt_st;
 	}
@@ -486,7 +488,7 @@ template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagged)
 {
 	hipLaunchKernelGGL((chain_dp_wave<R, SKIP, GEN, GS1, FAR>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
-	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, L.d_avg, L.d_st, L.d_f, L.d_p, L.d_t,
+	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, L.d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t,
 	                   L.d_status, only_flagged);
 	return hipGetLastError();
 }

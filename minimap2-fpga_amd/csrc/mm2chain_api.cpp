@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -43,23 +44,27 @@ struct Global {
 	bool ready = false;
 	int device = -1;
 	int ring_class = 0;
+	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
+	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
 	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
-	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0};
+	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0};
 	uint64_t epoch = 0;                     // bumped by shutdown so stale thread-local pointers are dropped
 } G;
 
-// per host thread: stream + grow-only device buffers (the reference keeps one buffer set per FPGA kernel,
-// chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex)
+// per host thread: stream + grow-only buffers (the reference keeps one buffer set per FPGA kernel,
+// chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex).  One device arena for everything that is uploaded
+// ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
+// mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
 struct ThreadCtx {
 	hipStream_t st = nullptr;
-	void *d_a = nullptr; int32_t *d_f = nullptr, *d_p = nullptr, *d_t = nullptr, *d_st = nullptr;
-	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr; float *d_avg = nullptr;
-	size_t cap_anchors = 0, cap_tasks = 0;
+	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
+	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
+	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
 	void release()
 	{
-		if (d_a) (void)hipFree(d_a); if (d_f) (void)hipFree(d_f); if (d_p) (void)hipFree(d_p); if (d_t) (void)hipFree(d_t); if (d_st) (void)hipFree(d_st);
-		if (d_off) (void)hipFree(d_off); if (d_order) (void)hipFree(d_order); if (d_status) (void)hipFree(d_status); if (d_avg) (void)hipFree(d_avg);
+		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
+		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
 		if (st) (void)hipStreamDestroy(st);
 		*this = ThreadCtx();
 	}
@@ -83,31 +88,29 @@ int get_thread_ctx(ThreadCtx **out)
 	return 0;
 }
 
-int ensure_capacity(ThreadCtx *c, size_t n_anchors, size_t n_tasks)
+int grow_device(char **p, size_t *cap, size_t need)
 {
-	if (n_anchors > c->cap_anchors) {
-		size_t cap = std::max(n_anchors, c->cap_anchors * 2);
-		if (c->d_a) (void)hipFree(c->d_a); if (c->d_f) (void)hipFree(c->d_f); if (c->d_p) (void)hipFree(c->d_p); if (c->d_t) (void)hipFree(c->d_t); if (c->d_st) (void)hipFree(c->d_st);
-		c->d_a = nullptr; c->d_f = c->d_p = c->d_t = c->d_st = nullptr; c->cap_anchors = 0;
-		HIP_TRY(hipMalloc(&c->d_a, cap * 16));
-		HIP_TRY(hipMalloc((void **)&c->d_f, cap * 4));
-		HIP_TRY(hipMalloc((void **)&c->d_p, cap * 4));
-		HIP_TRY(hipMalloc((void **)&c->d_t, cap * 4));
-		HIP_TRY(hipMalloc((void **)&c->d_st, cap * 4));
-		c->cap_anchors = cap;
-	}
-	if (n_tasks > c->cap_tasks) {
-		size_t cap = std::max(n_tasks, c->cap_tasks * 2);
-		if (c->d_off) (void)hipFree(c->d_off); if (c->d_order) (void)hipFree(c->d_order); if (c->d_status) (void)hipFree(c->d_status); if (c->d_avg) (void)hipFree(c->d_avg);
-		c->d_off = nullptr; c->d_order = c->d_status = nullptr; c->d_avg = nullptr; c->cap_tasks = 0;
-		HIP_TRY(hipMalloc((void **)&c->d_off, (cap + 1) * 8));
-		HIP_TRY(hipMalloc((void **)&c->d_order, cap * 4));
-		HIP_TRY(hipMalloc((void **)&c->d_status, cap * 4));
-		HIP_TRY(hipMalloc((void **)&c->d_avg, cap * 4));
-		c->cap_tasks = cap;
-	}
+	if (need <= *cap) return 0;
+	const size_t want = std::max(need, *cap * 2);
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; *cap = 0;
+	HIP_TRY(hipMalloc((void **)p, want));
+	*cap = want;
 	return 0;
 }
+
+int grow_pinned(char **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return 0;
+	const size_t want = std::max(need, *cap * 2);
+	if (*p) (void)hipHostFree(*p);
+	*p = nullptr; *cap = 0;
+	HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
+	*cap = want;
+	return 0;
+}
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 int check_params(const mm2c_params_t *p)
 {
@@ -216,6 +219,11 @@ int mm2c_tune(const char *key, int value)
 		G.ring_class = value;
 		return 0;
 	}
+	if (strcmp(key, "seg_min") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "seg_min must be >= 0");
+		G.seg_min = value;
+		return 0;
+	}
 	return fail(MM2C_E_ARG, "unknown tuning key '%s'", key);
 }
 
@@ -239,7 +247,7 @@ void mm2c_params_fpga_v2(mm2c_params_t *p, int32_t max_dist_x, int32_t max_dist_
 void mm2c_get_stats(mm2c_stats_t *out)
 {
 	if (!out) return;
-	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load();
+	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load(); out->segments = G.segments.load(); out->host_call_ns = G.host_call_ns.load();
 }
 
 // ------------------------------------------------------------------------------------------------ plans
@@ -299,7 +307,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
-	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
+	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.ring_class = G.ring_class;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	HIP_TRY(hipEventRecord(pl->ev_pre, st));
@@ -348,6 +356,7 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
                           const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
 {
 	int rc;
+	const auto t_begin = std::chrono::steady_clock::now();
 	if ((rc = check_params(par))) return rc;
 	std::vector<int32_t> order;
 	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;
@@ -355,28 +364,88 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	const int64_t base = h_offsets[0], total = h_offsets[n_tasks] - base;
 	if (total == 0) return 0;
 	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
+
+	// ---- split every task at empty-window cut points: where x_i > x_{i-1} + max_dist_x no anchor at or
+	// after i can chain to, stamp or be stamped by an anchor before i (chain.c:192 pushes st to i), so the pieces are
+	// independent tasks for f[]/p[] and run as parallel waves.  Real reads hit many loci, so this is what gives a single
+	// mm_chain_dp call more than one wave of work.  Pieces shorter than seg_min anchors are merged with their successor.
+	// avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
+	const mm2c_anchor_t *a = h_anchors + base;
+	const uint64_t D = (uint64_t)(int64_t)par->max_dist_x;
+	const int64_t seg_min = G.seg_min;
+	std::vector<int64_t> seg_off; std::vector<int32_t> pbase; std::vector<float> seg_avg;
+	seg_off.reserve((size_t)n_tasks + 16); pbase.reserve((size_t)n_tasks + 16); seg_avg.reserve((size_t)n_tasks + 16);
+	for (int64_t k = 0; k < n_tasks; ++k) {
+		const int64_t t0 = h_offsets[k] - base, t1 = h_offsets[k + 1] - base;
+		if (t1 == t0) continue;
+		float avg;
+		if (h_avg_qspan) avg = h_avg_qspan[k];
+		else {
+			uint64_t sum = 0;
+			for (int64_t i = t0; i < t1; ++i) sum += a[i].y >> 32 & 0xff;
+			avg = (float)(.01 * (float)sum / (t1 - t0));
+		}
+		int64_t s0 = t0;
+		for (int64_t i = t0 + 1; i < t1; ++i)
+			if (seg_min > 0 && i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
+				seg_off.push_back(s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+				s0 = i;
+			}
+		seg_off.push_back(s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+	}
+	const int64_t n_seg = (int64_t)seg_off.size();
+	seg_off.push_back(total);
+	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
+
 	ThreadCtx *c;
 	if ((rc = get_thread_ctx(&c))) return rc;
 	HIP_TRY(hipSetDevice(G.device));
-	if ((rc = ensure_capacity(c, (size_t)total, (size_t)n_tasks))) return rc;
-	std::vector<int64_t> off((size_t)n_tasks + 1);
-	for (int64_t k = 0; k <= n_tasks; ++k) off[(size_t)k] = h_offsets[k] - base;
-	HIP_TRY(hipMemcpyAsync(c->d_off, off.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice, c->st));
-	HIP_TRY(hipMemcpyAsync(c->d_order, order.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->st));
-	HIP_TRY(hipMemcpyAsync(c->d_a, h_anchors + base, (size_t)total * 16, hipMemcpyHostToDevice, c->st)); // cf. chain_hardware.cpp:110
-	if (h_avg_qspan) HIP_TRY(hipMemcpyAsync(c->d_avg, h_avg_qspan, (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->st));
-	HIP_TRY(hipMemsetAsync(c->d_status, 0, (size_t)n_tasks * 4, c->st));
+	// upload arena: [anchors | piece offsets | launch order | p base | avg | status(0)]
+	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
+	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
+	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
+	const size_t meta_bytes = in_bytes - o_off;
+	const bool staged = (size_t)total <= G.stage_max_anchors;      // small calls go through pinned staging, big ones copy in place
+	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
+	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
+	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
+	if ((rc = grow_pinned(&c->h_in, &c->cap_hin, staged ? in_bytes : meta_bytes))) return rc;
+	char *hm = staged ? c->h_in + o_off : c->h_in;                 // where the metadata block starts in the staging buffer
+	memcpy(hm, seg_off.data(), ((size_t)n_seg + 1) * 8);
+	memcpy(hm + (o_ord - o_off), order.data(), (size_t)n_seg * 4);
+	memcpy(hm + (o_pb - o_off), pbase.data(), (size_t)n_seg * 4);
+	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
+	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);
+	if (staged) {
+		memcpy(c->h_in + o_a, a, (size_t)total * 16);
+		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
+	} else {
+		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
+		HIP_TRY(hipMemcpyAsync(c->d_in + o_a, a, (size_t)total * 16, hipMemcpyHostToDevice, c->st));
+	}
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(par);
-	L.n_tasks = n_tasks; L.d_offsets = c->d_off; L.d_order = c->d_order; L.d_anchors = c->d_a;
-	L.d_avg = h_avg_qspan ? c->d_avg : nullptr; L.d_f = c->d_f; L.d_p = c->d_p; L.d_t = c->d_t; L.d_st = c->d_st; L.d_status = c->d_status;
+	L.n_tasks = n_seg; L.d_offsets = (const int64_t *)(c->d_in + o_off); L.d_order = (const int32_t *)(c->d_in + o_ord);
+	L.d_anchors = c->d_in + o_a; L.d_avg = (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
+	L.d_status = (int32_t *)(c->d_in + o_stat);
+	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
+	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
 	L.ring_class = G.ring_class;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
-	HIP_TRY(hipMemcpyAsync(h_f + base, c->d_f, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:167
-	HIP_TRY(hipMemcpyAsync(h_p + base, c->d_p, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));          // cf. chain_hardware.cpp:170
-	HIP_TRY(hipStreamSynchronize(c->st));                                                                   // cf. chain_hardware.cpp:175
-	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl;
+	if (staged) {
+		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
+		HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
+		memcpy(h_f + base, c->h_out, (size_t)total * 4);
+		memcpy(h_p + base, c->h_out + (size_t)total * 4, (size_t)total * 4);
+	} else {
+		HIP_TRY(hipMemcpyAsync(h_f + base, L.d_f, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));
+		HIP_TRY(hipMemcpyAsync(h_p + base, L.d_p, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));
+		HIP_TRY(hipStreamSynchronize(c->st));
+	}
+	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
+	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
 	return 0;
 }
 

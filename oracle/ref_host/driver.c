@@ -48,7 +48,9 @@ int main(int argc, char *argv[])
 	mm_mapopt_t mo;
 	mm_idx_reader_t *r;
 	mm_idx_t *mi;
-	if (argc < 3) { fprintf(stderr, "usage: %s <ref.fa> <query.fa>\n", argv[0]); return 1; }
+	int n_threads = 1;
+	if (argc >= 5 && strcmp(argv[1], "-t") == 0) { n_threads = atoi(argv[2]); argv += 2; argc -= 2; }   /* main.c:153 -t */
+	if (argc < 3) { fprintf(stderr, "usage: %s [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
 #ifdef MM2_GPU_CHAINING
 	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
@@ -60,15 +62,16 @@ int main(int argc, char *argv[])
 	io.flag |= MM_I_NO_SEQ;                              /* main.c:286-287: no -d, no CIGAR */
 	r = mm_idx_reader_open(argv[1], &io, 0);
 	if (!r) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
-	while ((mi = mm_idx_reader_read(r, 1)) != 0) {
+	while ((mi = mm_idx_reader_read(r, n_threads)) != 0) {
 		mm_mapopt_update(&mo, mi);                       /* main.c:399 */
-		if (mm_map_file(mi, argv[2], &mo, 1) < 0) { fprintf(stderr, "mapping failed\n"); return 1; }   /* main.c:406 */
+		if (mm_map_file(mi, argv[2], &mo, n_threads) < 0) { fprintf(stderr, "mapping failed\n"); return 1; }   /* main.c:406 */
 		mm_idx_destroy(mi);
 	}
 	mm_idx_reader_close(r);
 #ifdef MM2_GPU_CHAINING
-	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu launches\n",
-	                                                 (unsigned long long)st.tasks, (unsigned long long)st.anchors, (unsigned long long)st.launches); }
+	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu pieces, %llu launches, %.3f s inside the chaining calls (summed over threads), %.1f us per call\n",
+	                                                 (unsigned long long)st.tasks, (unsigned long long)st.anchors, (unsigned long long)st.segments, (unsigned long long)st.launches,
+	                                                 st.host_call_ns * 1e-9, st.tasks ? st.host_call_ns * 1e-3 / st.tasks : 0.0); }
 	mm2c_shutdown();                                     /* cleanup, main.c:430 */
 #endif
 	return fflush(stdout) == EOF;

@@ -184,6 +184,37 @@ def test_fpga_v2_through_the_reference_symbol():
         assert_same(f, p, f_v1, p_v1, None, "v2 as v1")
 
 
+def test_host_paths_cut_tasks_at_empty_windows():
+    """multi-locus reads (many references / far-apart loci): the host-buffer paths split a task into independent pieces;
+    results must not depend on the piece size, incl. look-back beyond the LDS ring inside a piece"""
+    import mm2chain
+    from mm2chain import params
+    rng = np.random.default_rng(99)
+    tasks = []
+    for _ in range(6):
+        rows = []
+        for _ in range(int(rng.integers(3, 30))):
+            strand, rid = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+            pos = int(rng.integers(0, 1 << 26)); q = int(rng.integers(0, 3000))
+            for _ in range(int(rng.integers(1, 700))):
+                pos += int(rng.integers(1, 9)); q += int(rng.integers(-3, 12))
+                rows.append(mk_anchor(strand, rid, pos, max(q, 0)))
+        tasks.append(pack(rows))
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    P = params.make_params(max_skip=300)           # long scans: windows of up to ~1200 anchors, beyond the ring
+    f_ref, p_ref = oracle_batch(P, off, a)
+    try:
+        for seg_min in (0, 1, 64, 1000):
+            mm2chain.tune("seg_min", seg_min)
+            f, p = mm2chain.chain_batch_host(P, off, a)
+            assert_same(f, p, f_ref, p_ref, off, f"seg_min {seg_min}")
+            f1, p1 = mm2chain.chain_task(P, tasks[0], ob.avg_qspan(tasks[0]))
+            assert_same(f1, p1, f_ref[: off[1]], p_ref[: off[1]], None, f"task seg_min {seg_min}")
+    finally:
+        mm2chain.tune("seg_min", 256)
+
+
 def test_prediction_pass_matches_chain_c_53_78():
     import mm2chain
     from mm2chain import params
