@@ -199,7 +199,7 @@ def main():
 
     # ---- secondary figures (outside the timed region, rank 0)
     try:
-        if args.no_secondary:
+        if args.no_secondary or world > 1:                                # N = 1 only: keep multi-GPU runs lean
             raise StopIteration
         _, _, tt = plan_predict_totals(mm2chain, P, off1, a1)
         out["secondary"] = {"nominal_cells_per_s": float(tt) * times / (k_avg_ms * 1e-3),
@@ -221,7 +221,7 @@ def main():
         out["secondary_error"] = repr(e)
 
     # ---- CPU baseline: the oracle (port of chain.c:184-238) on the host cores, bounded sample of the same batch
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:                                  # rank 0 at N = 1 only
         cores = host_cores()
         off_np = off1.numpy()
         a_np = a1.cpu().numpy().view(np.uint64)
