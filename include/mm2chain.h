@@ -147,8 +147,9 @@ int  mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par,
 void mm2c_stream_free(mm2c_stream_t *s);
 
 /* statistics since mm2c_init: tasks, anchors, and kernel launches issued through any entry point */
-typedef struct { uint64_t tasks, anchors, launches, segments, host_call_ns; } mm2c_stats_t;   /* segments: pieces the host paths cut
-   tasks into; host_call_ns: wall time spent inside the host-buffer entry points, summed over calling threads */
+typedef struct { uint64_t tasks, anchors, launches, segments, host_call_ns, passes; } mm2c_stats_t;   /* segments: pieces the host
+   paths cut tasks into; host_call_ns: wall time inside the host-buffer entry points, summed over calling threads; passes: GPU
+   passes they issued (concurrent small calls are combined into one pass) */
 void mm2c_get_stats(mm2c_stats_t *out);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,17 +39,19 @@ int fail(int code, const char *fmt, ...)
 	return fail(MM2C_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 struct ThreadCtx;
+void release_combiner();
 
 struct Global {
 	std::mutex mu;
 	bool ready = false;
 	int device = -1;
 	int ring_class = 0;
+	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
 	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
 	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
 	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
-	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0};
+	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0}, passes{0};
 	uint64_t epoch = 0;                     // bumped by shutdown so stale thread-local pointers are dropped
 } G;
 
@@ -193,6 +196,7 @@ void mm2c_shutdown(void)
 	(void)hipSetDevice(G.device);
 	(void)hipDeviceSynchronize();
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
+	release_combiner();
 	G.thread_ctxs.clear();
 	if (G.stream) (void)hipStreamDestroy(G.stream);
 	G.stream = nullptr;
@@ -247,7 +251,7 @@ void mm2c_params_fpga_v2(mm2c_params_t *p, int32_t max_dist_x, int32_t max_dist_
 void mm2c_get_stats(mm2c_stats_t *out)
 {
 	if (!out) return;
-	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load(); out->segments = G.segments.load(); out->host_call_ns = G.host_call_ns.load();
+	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load(); out->segments = G.segments.load(); out->host_call_ns = G.host_call_ns.load(); out->passes = G.passes.load();
 }
 
 // ------------------------------------------------------------------------------------------------ plans
@@ -352,60 +356,71 @@ int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 }
 
 // ------------------------------------------------------------------------------------------------ host-buffer paths
-int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
-                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+} // extern "C"
+
+namespace {
+
+// one caller's batch: CSR tasks in pageable host memory
+struct HostReq {
+	const mm2c_params_t *par; int64_t n_tasks; const int64_t *off; const mm2c_anchor_t *a; const float *avg;
+	int32_t *f, *p;
+	int rc = 0; bool done = false; char err[256];
+};
+
+// Runs one GPU pass over the union of the requests (all with the same scalars).
+//  * every task is split at empty-window cut points: where x_i > x_{i-1} + max_dist_x no anchor at or
+//    after i can chain to, stamp or be stamped by an anchor before i (chain.c:192 pushes st to i), so the pieces are
+//    independent tasks for f[]/p[] and run as parallel waves.  Real reads hit many loci: this is what gives one mm_chain_dp
+//    call more than one wave of work.  Pieces shorter than seg_min anchors are merged with their successor.
+//  * avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
+//  * one upload arena [anchors | piece offsets | launch order | p base | avg | status(0)] and one download arena [f | p],
+//    mirrored in pinned memory for small passes: one H2D copy, the kernels, one D2H copy, one sync.
+int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 {
 	int rc;
-	const auto t_begin = std::chrono::steady_clock::now();
-	if ((rc = check_params(par))) return rc;
-	std::vector<int32_t> order;
-	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;
-	if (n_tasks == 0) return 0;
-	const int64_t base = h_offsets[0], total = h_offsets[n_tasks] - base;
-	if (total == 0) return 0;
-	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
-
-	// ---- split every task at empty-window cut points: where x_i > x_{i-1} + max_dist_x no anchor at or
-	// after i can chain to, stamp or be stamped by an anchor before i (chain.c:192 pushes st to i), so the pieces are
-	// independent tasks for f[]/p[] and run as parallel waves.  Real reads hit many loci, so this is what gives a single
-	// mm_chain_dp call more than one wave of work.  Pieces shorter than seg_min anchors are merged with their successor.
-	// avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
-	const mm2c_anchor_t *a = h_anchors + base;
+	const mm2c_params_t *par = reqs[0]->par;
 	const uint64_t D = (uint64_t)(int64_t)par->max_dist_x;
 	const int64_t seg_min = G.seg_min;
-	std::vector<int64_t> seg_off; std::vector<int32_t> pbase; std::vector<float> seg_avg;
-	seg_off.reserve((size_t)n_tasks + 16); pbase.reserve((size_t)n_tasks + 16); seg_avg.reserve((size_t)n_tasks + 16);
-	for (int64_t k = 0; k < n_tasks; ++k) {
-		const int64_t t0 = h_offsets[k] - base, t1 = h_offsets[k + 1] - base;
-		if (t1 == t0) continue;
-		float avg;
-		if (h_avg_qspan) avg = h_avg_qspan[k];
-		else {
-			uint64_t sum = 0;
-			for (int64_t i = t0; i < t1; ++i) sum += a[i].y >> 32 & 0xff;
-			avg = (float)(.01 * (float)sum / (t1 - t0));
-		}
-		int64_t s0 = t0;
-		for (int64_t i = t0 + 1; i < t1; ++i)
-			if (seg_min > 0 && i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
-				seg_off.push_back(s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
-				s0 = i;
+	int64_t total = 0, n_tasks_all = 0;
+	for (int r = 0; r < n_req; ++r) { total += reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]; n_tasks_all += reqs[r]->n_tasks; }
+	if (total == 0) return 0;
+	std::vector<int64_t> seg_off; std::vector<int32_t> pbase, order; std::vector<float> seg_avg;
+	seg_off.reserve((size_t)n_tasks_all + 16); pbase.reserve((size_t)n_tasks_all + 16); seg_avg.reserve((size_t)n_tasks_all + 16);
+	int64_t g0 = 0;                                                // where this request's anchors start in the arena
+	for (int r = 0; r < n_req; ++r) {
+		const HostReq &q = *reqs[r];
+		const int64_t base = q.off[0];
+		const mm2c_anchor_t *a = q.a + base;
+		for (int64_t k = 0; k < q.n_tasks; ++k) {
+			const int64_t t0 = q.off[k] - base, t1 = q.off[k + 1] - base;
+			if (t1 == t0) continue;
+			float avg;
+			if (q.avg) avg = q.avg[k];
+			else {
+				uint64_t sum = 0;
+				for (int64_t i = t0; i < t1; ++i) sum += a[i].y >> 32 & 0xff;
+				avg = (float)(.01 * (float)sum / (t1 - t0));
 			}
-		seg_off.push_back(s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+			int64_t s0 = t0;
+			for (int64_t i = t0 + 1; i < t1; ++i)
+				if (seg_min > 0 && i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
+					seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+					s0 = i;
+				}
+			seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+		}
+		g0 += q.off[q.n_tasks] - base;
 	}
 	const int64_t n_seg = (int64_t)seg_off.size();
 	seg_off.push_back(total);
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
-	ThreadCtx *c;
-	if ((rc = get_thread_ctx(&c))) return rc;
 	HIP_TRY(hipSetDevice(G.device));
-	// upload arena: [anchors | piece offsets | launch order | p base | avg | status(0)]
 	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
 	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
 	const size_t meta_bytes = in_bytes - o_off;
-	const bool staged = (size_t)total <= G.stage_max_anchors;      // small calls go through pinned staging, big ones copy in place
+	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
 	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
 	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
@@ -417,11 +432,21 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
 	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);
 	if (staged) {
-		memcpy(c->h_in + o_a, a, (size_t)total * 16);
+		size_t at = o_a;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t nb = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]) * 16;
+			memcpy(c->h_in + at, reqs[r]->a + reqs[r]->off[0], nb);
+			at += nb;
+		}
 		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
 	} else {
 		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
-		HIP_TRY(hipMemcpyAsync(c->d_in + o_a, a, (size_t)total * 16, hipMemcpyHostToDevice, c->st));
+		size_t at = o_a;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t nb = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]) * 16;
+			HIP_TRY(hipMemcpyAsync(c->d_in + at, reqs[r]->a + reqs[r]->off[0], nb, hipMemcpyHostToDevice, c->st));
+			at += nb;
+		}
 	}
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(par);
@@ -437,16 +462,122 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
 		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
 		HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
-		memcpy(h_f + base, c->h_out, (size_t)total * 4);
-		memcpy(h_p + base, c->h_out + (size_t)total * 4, (size_t)total * 4);
+		size_t at = 0;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t n = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]);
+			memcpy(reqs[r]->f + reqs[r]->off[0], c->h_out + at * 4, n * 4);
+			memcpy(reqs[r]->p + reqs[r]->off[0], c->h_out + (size_t)total * 4 + at * 4, n * 4);
+			at += n;
+		}
 	} else {
-		HIP_TRY(hipMemcpyAsync(h_f + base, L.d_f, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));
-		HIP_TRY(hipMemcpyAsync(h_p + base, L.d_p, (size_t)total * 4, hipMemcpyDeviceToHost, c->st));
+		size_t at = 0;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t n = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]);
+			HIP_TRY(hipMemcpyAsync(reqs[r]->f + reqs[r]->off[0], L.d_f + at, n * 4, hipMemcpyDeviceToHost, c->st));
+			HIP_TRY(hipMemcpyAsync(reqs[r]->p + reqs[r]->off[0], L.d_p + at, n * 4, hipMemcpyDeviceToHost, c->st));
+			at += n;
+		}
 		HIP_TRY(hipStreamSynchronize(c->st));
 	}
-	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
-	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
+	G.passes += 1;
 	return 0;
+}
+
+// Combiner for small synchronous calls (the reference's call pattern: up to n_threads host threads, each blocking in
+// run_chaining_on_hw / mm_chain_dp, map.c:561).  A caller that finds no pass in flight becomes the leader: it takes every
+// pending request with the same scalars, runs ONE GPU pass for all of them and wakes their owners; callers that arrive
+// meanwhile queue up and are served by the next leader.  (The reference instead serialises callers on a mutex and a FIFO,
+// chain_hardware.cpp:54-93.)  Big requests skip the combiner and run on the caller's own stream.
+struct Combiner {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<HostReq *> pending;
+	bool leader_active = false;
+	ThreadCtx ctx;                      // stream + arenas of the pass in flight (leader-exclusive)
+	uint64_t epoch = ~0ull;
+} CB;
+
+void release_combiner()
+{
+	std::lock_guard<std::mutex> lk(CB.mu);
+	CB.ctx.release();
+	CB.epoch = ~0ull;
+}
+
+int submit_combined(HostReq *me)
+{
+	std::unique_lock<std::mutex> lk(CB.mu);
+	CB.pending.push_back(me);
+	for (;;) {
+		if (me->done) return me->rc;
+		if (!CB.leader_active) break;
+		CB.cv.wait(lk);
+	}
+	// leader: collect the pending requests that share my scalars, up to the staging size
+	CB.leader_active = true;
+	std::vector<HostReq *> batch, rest;
+	size_t tot = 0;
+	for (HostReq *q : CB.pending) {
+		const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
+		if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; }
+		else rest.push_back(q);
+	}
+	CB.pending.swap(rest);
+	lk.unlock();
+	int rc = 0;
+	{
+		std::lock_guard<std::mutex> gl(G.mu);
+		if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+		else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
+			CB.ctx = ThreadCtx();
+			hipError_t e = hipSetDevice(G.device);
+			if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
+			if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
+			else CB.epoch = G.epoch;
+		}
+	}
+	if (rc == 0) rc = run_requests(&CB.ctx, batch.data(), (int)batch.size());
+	lk.lock();
+	for (HostReq *q : batch) {
+		q->rc = rc; q->done = true;
+		if (rc != 0) { strncpy(q->err, g_err, sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
+	}
+	CB.leader_active = false;
+	CB.cv.notify_all();
+	return me->rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+{
+	int rc;
+	const auto t_begin = std::chrono::steady_clock::now();
+	if ((rc = check_params(par))) return rc;
+	std::vector<int32_t> order;
+	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;      // validates the offsets
+	if (n_tasks == 0) return 0;
+	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
+	if (total == 0) return 0;
+	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
+	HostReq req;
+	req.par = par; req.n_tasks = n_tasks; req.off = h_offsets; req.a = h_anchors; req.avg = h_avg_qspan; req.f = h_f; req.p = h_p;
+	req.err[0] = 0;
+	if ((size_t)total <= G.combine_max_anchors) {
+		rc = submit_combined(&req);
+		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
+	} else {
+		ThreadCtx *c;
+		if ((rc = get_thread_ctx(&c))) return rc;
+		HostReq *one = &req;
+		rc = run_requests(c, &one, 1);
+	}
+	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	return rc;
 }
 
 int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,

@@ -24,7 +24,7 @@ class Stream(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64), ("segments", C.c_uint64), ("host_call_ns", C.c_uint64)]
+    _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64), ("segments", C.c_uint64), ("host_call_ns", C.c_uint64), ("passes", C.c_uint64)]
 
 
 # every symbol include/mm2chain.h declares with C linkage: name -> (restype, argtypes)

@@ -215,6 +215,31 @@ def test_host_paths_cut_tasks_at_empty_windows():
         mm2chain.tune("seg_min", 256)
 
 
+def test_concurrent_callers_are_combined_into_shared_passes():
+    """the reference's call pattern (map.c:561): many host threads, each blocking in a per-read chaining call"""
+    import threading
+    import mm2chain
+    from mm2chain import params, _native as N
+    P = params.map_ont()
+    off, a = _stream("mixed", 96, (50, 1500), seed=61)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    results = {}
+
+    def worker(tid):
+        for k in range(tid, 96, 12):
+            t = a[off[k]:off[k + 1]]
+            results[k] = mm2chain.chain_task(P, t, ob.avg_qspan(t), tid=tid)
+
+    st0 = N.Stats(); N.load().mm2c_get_stats(st0)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(12)]
+    for x in th: x.start()
+    for x in th: x.join()
+    st1 = N.Stats(); N.load().mm2c_get_stats(st1)
+    for k in range(96):
+        assert_same(results[k][0], results[k][1], f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"thread task {k}")
+    assert st1.tasks - st0.tasks == 96 and 1 <= st1.passes - st0.passes <= 96
+
+
 def test_prediction_pass_matches_chain_c_53_78():
     import mm2chain
     from mm2chain import params
