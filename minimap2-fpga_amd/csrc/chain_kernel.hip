@@ -324,9 +324,9 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 // ---------------------------------------------------------------- prepass: window start of every anchor
 // st[i] = max(first j of the task with x_i <= x_j + max_dist_x, i - max_iter), chain.c:192-193 (the `st` pointer of the
 // reference is monotone, so its value at i is exactly this).  Full 64-bit compares, so inside
-// [st[i], i) every x difference fits 31 bits and the DP kernel works on low words.  One wave per task, 64 anchors
-// per step, each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
-__global__ void __launch_bounds__(64)
+// [st[i], i) every x difference fits 31 bits and the DP kernel works on low words.  One 256-thread block per task,
+// each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
+__global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all)
 {
@@ -338,7 +338,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	const ulonglong2 *a = a_all + base;
 	int32_t *st = st_all + base;
 	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
-	for (int i = lane; i < n; i += 64) {
+	for (int i = lane; i < n; i += 256) {                          // 4 waves per task: the searches are latency bound
 		const uint64_t xi = a[i].x;
 		int lo = max(i - P.max_iter, 0), hi = i;                    // answer in [lo, i]; x_i <= x_i + D always holds
 		while (lo < hi) {
@@ -528,7 +528,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
 	const bool far_ = (int64_t)P.max_iter > (int64_t)R;   // the ring always holds the R anchors before the current tile
-	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(64), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
+	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
