@@ -197,16 +197,16 @@ __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t va
 // Every visited, unfiltered j stamps its predecessor p[j] (stamps for targets outside the window are never read for
 // this i and are dropped); then each lane fetches its own stamp.  LDS stamps are 16 bit, s16 = 1 + i % 16384 (0 = never
 // stamped, chain.c:46), in a ring of 2R slots that is cleared as anchors enter it, so a value identifies its anchor.
-// Lanes that do not stamp write to the sink slot [2R].  A ring-resident j may still point beyond the ring: that
-// stamp (the full i+1) goes to the global scratch t[].
+// Lanes that do not stamp write to the sink slot [2R].  The stamp ring holds the 2R anchors before the end of the current
+// tile (stamp_lo = i0 + 64 - 2R), twice the data ring; a stamp for an older target (the full i+1) goes to the global scratch t[].
 template <int R, bool FAR>
-__device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int lds_lo, int stamp, int s16_v, char *t_bytes,
+__device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int stamp_lo, int stamp, int s16_v, char *t_bytes,
                                                int32_t *t_glob, int lane, int own_off2)
 {
 	const mask_t mk = valid & BALLOT(pj >= lo);
 	int tgt = sel(mk, 2 * R * 2, (pj & (2 * R - 1)) << 1);
 	if (FAR) {
-		const mask_t fm = mk & BALLOT(pj < lds_lo);
+		const mask_t fm = mk & BALLOT(pj < stamp_lo);
 		if (fm != 0) {
 			int pj2 = pj;
 			asm volatile("" : "+v"(pj2));                             // keep the far addressing out of the hot loop
@@ -222,10 +222,12 @@ __device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int
 
 // ---------------------------------------------------------------- the look-back scan of one anchor, chain.c:197-235
 struct Win { int x, q, f, p, g; };      // chunk-0 window registers: lane L = anchor i-1-L
+// the tile that most recently left the LDS ring, kept in registers: lane L = anchor base + 63 - L ("victim" tile)
+struct Victim { int x, q, f, p, g, base; };
 
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int xi, int qi, int span_i,
-                                            int seg_i, const Win &w, const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g,
+                                            int seg_i, const Win &w, const Victim &vt, const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g,
                                             char *t_bytes, uint16_t *s_t, const uint4 *a, const int32_t *f, const int32_t *p,
                                             int32_t *t, int pbase, Carry &c)
 {
@@ -234,7 +236,8 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 	int rem = i - lo;                  // predecessors still to visit (> 0)
 	{
 		const int stamp = i + 1;              // stamp in the global scratch t[] (look-back beyond the ring)
-		const int s16 = 1 + (i & 0x3fff);     // stamp in the LDS ring: unique over the < R+64 anchors that can stamp a slot between two clears
+		const int s16 = 1 + (i & 0x3fff);     // stamp in the LDS ring: unique over the < 2R+64 anchors that can stamp a slot between two clears
+		const int stamp_lo = lds_lo + 64 - R;  // = i0 + 64 - 2R: oldest anchor whose stamp slot is in the LDS ring
 		const int s16_v = s16;                 // (one v_mov: the ds_write data operand)
 		int jtop = i - 1;
 		bool broke = false;
@@ -246,7 +249,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 			const mask_t valid = pair_filter<GEN>(P, first_lanes(rem), dr, dq, dd, same);
 			if (valid != 0) {
 				int tj = 0;                    // stamp round trip through LDS overlaps the scoring below
-				if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, lds_lo, stamp, s16_v, t_bytes, t, lane,
+				if (SKIP) tj = stamp_and_fetch<R, FAR>(valid, wp, lo, stamp_lo, stamp, s16_v, t_bytes, t, lane,
 				                                        (((jtop << 1) + nl2) & ((2 * R - 1) << 1)));
 				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
 				const int scv = sel(valid, SENT, sc);
@@ -268,7 +271,15 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 			if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
 				int j = jtop - lane;
 				asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
-				far_l = BALLOT(j < lds_lo) & in_w;
+				const mask_t out_l = BALLOT(j < lds_lo) & in_w;       // lanes beyond the ring
+				// the 64 anchors just beyond the ring are still in registers: fetch them across lanes (no memory access)
+				const int src4 = (63 - (j - vt.base)) << 2;
+				const int vx = __builtin_amdgcn_ds_bpermute(src4, vt.x), vq = __builtin_amdgcn_ds_bpermute(src4, vt.q);
+				const int vf = __builtin_amdgcn_ds_bpermute(src4, vt.f), vp = __builtin_amdgcn_ds_bpermute(src4, vt.p);
+				const mask_t vic_l = out_l & BALLOT(j >= vt.base);
+				xj = sel(vic_l, xj, vx); qj = sel(vic_l, qj, vq); fj = sel(vic_l, fj, vf); pj = sel(vic_l, pj, vp);
+				if (GEN) gj = sel(vic_l, gj, __builtin_amdgcn_ds_bpermute(src4, vt.g));
+				far_l = out_l & ~vic_l;                               // what is left goes to L2/HBM
 				if (far_l >> lane & 1) {
 					const uint4 aj = a[j];
 					xj = (int)aj.x; qj = (int)aj.z;
@@ -294,21 +305,21 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 					if (SKIP) {
 						const bool mkv = (valid >> lane & 1) && pj >= lo;
 						if (mkv) {
-							if (pj >= lds_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
+							if (pj >= stamp_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
 							else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						}
 						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 						__builtin_amdgcn_wave_barrier();
 						int tj = 0;
-						if (fl) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (fl && j < stamp_lo) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
 						marked = BALLOT(tj == stamp);
 					}
 				}
 				int tj = 0;
 				const bool near_stamps = SKIP && !(FAR && far_l != 0);
-				if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, lds_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
+				if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, stamp_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
 				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
 				const int scv = sel(valid, SENT, sc);
 				if (near_stamps) marked = BALLOT(tj == s16);
@@ -422,6 +433,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	}
 
 	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
+	Victim vt = { 0, 0, 0, -1, 0, INT_MIN / 2 };              // tile that left the ring last (FAR variants only)
 	int seg0 = 0;
 	char *const t_bytes = (char *)s_t;
 	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
@@ -457,10 +469,10 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				Win w = { wx, wq, wf, wp, wg };
 				// the common case (window entirely inside the LDS ring) runs a loop with no look-back-beyond-the-ring tests
 				if (!FAR || lo >= lds_lo)
-					scan_window<R, SKIP, GEN, GS1, false>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
+					scan_window<R, SKIP, GEN, GS1, false>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, vt, xq_bytes, fp_bytes, s_g,
 					                                      t_bytes, s_t, a, f, p, t, pbase, c);
 				else
-					scan_window<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, xq_bytes, fp_bytes, s_g,
+					scan_window<R, SKIP, GEN, GS1, FAR>(P, avg, lane, i, lo, lds_lo, xi, qi, span_i, seg_i, w, vt, xq_bytes, fp_bytes, s_g,
 					                                    t_bytes, s_t, a, f, p, t, pbase, c);
 			}
 			// ---- commit anchor i (chain.c:236) into the chunk-0 window
@@ -472,6 +484,13 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		// after the tile, window lane L holds anchor i0+cnt-1-L: f/p of the tile enter the ring (older chunks never
 		// reach into the current tile, so once per tile is enough) and leave in coalesced 256 B stores
+		if (FAR) {
+			// the tile that the finished one pushes out of the ring stays reachable in registers for one more tile
+			const int o = i0 + 63 - lane;                         // its slots are the ones written just below
+			const uint2 oxq = s_xq[o & (R - 1)]; const int2 ofp = s_fp[o & (R - 1)];
+			vt.x = (int)oxq.x; vt.q = (int)oxq.y; vt.f = ofp.x; vt.p = ofp.y; vt.base = i0 - R;
+			if (GEN) vt.g = s_g[o & (R - 1)];
+		}
 		if (lane < cnt) {
 			const int o = i0 + cnt - 1 - lane;
 			s_xq[o & (R - 1)] = make_uint2((uint32_t)wx, (uint32_t)wq);
