@@ -222,8 +222,10 @@ __device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int
 
 // ---------------------------------------------------------------- the look-back scan of one anchor, chain.c:197-235
 struct Win { int x, q, f, p, g; };      // chunk-0 window registers: lane L = anchor i-1-L
-// the tile that most recently left the LDS ring, kept in registers: lane L = anchor base + 63 - L ("victim" tile)
-struct Victim { int x, q, f, p, g, base; };
+// the NV tiles that most recently left the LDS ring, kept in registers ("victim" tiles): tile k covers anchors
+// [base - 64k, base - 64k + 64), lane L = anchor base - 64k + 63 - L
+#define NV 3
+struct Victim { int x[NV], q[NV], f[NV], p[NV], g[NV], base; };
 
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int xi, int qi, int span_i,
@@ -272,14 +274,22 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 				int j = jtop - lane;
 				asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
 				const mask_t out_l = BALLOT(j < lds_lo) & in_w;       // lanes beyond the ring
-				// the 64 anchors just beyond the ring are still in registers: fetch them across lanes (no memory access)
-				const int src4 = (63 - (j - vt.base)) << 2;
-				const int vx = __builtin_amdgcn_ds_bpermute(src4, vt.x), vq = __builtin_amdgcn_ds_bpermute(src4, vt.q);
-				const int vf = __builtin_amdgcn_ds_bpermute(src4, vt.f), vp = __builtin_amdgcn_ds_bpermute(src4, vt.p);
-				const mask_t vic_l = out_l & BALLOT(j >= vt.base);
-				xj = sel(vic_l, xj, vx); qj = sel(vic_l, qj, vq); fj = sel(vic_l, fj, vf); pj = sel(vic_l, pj, vp);
-				if (GEN) gj = sel(vic_l, gj, __builtin_amdgcn_ds_bpermute(src4, vt.g));
-				far_l = out_l & ~vic_l;                               // what is left goes to L2/HBM
+				// the 64*NV anchors just beyond the ring are still in registers: fetch them across lanes (no memory access)
+				far_l = out_l;
+#pragma unroll
+				for (int k = 0; k < NV; ++k) {
+					const int rel = j - (vt.base - 64 * k);            // position inside victim tile k
+					const mask_t vic = out_l & BALLOT((unsigned)rel < 64u);
+					if (vic != 0) {
+						const int src4 = (63 - rel) << 2;
+						xj = sel(vic, xj, __builtin_amdgcn_ds_bpermute(src4, vt.x[k]));
+						qj = sel(vic, qj, __builtin_amdgcn_ds_bpermute(src4, vt.q[k]));
+						fj = sel(vic, fj, __builtin_amdgcn_ds_bpermute(src4, vt.f[k]));
+						pj = sel(vic, pj, __builtin_amdgcn_ds_bpermute(src4, vt.p[k]));
+						if (GEN) gj = sel(vic, gj, __builtin_amdgcn_ds_bpermute(src4, vt.g[k]));
+						far_l &= ~vic;                                  // what is left goes to L2/HBM
+					}
+				}
 				if (far_l >> lane & 1) {
 					const uint4 aj = a[j];
 					xj = (int)aj.x; qj = (int)aj.z;
@@ -433,7 +443,10 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	}
 
 	int wx = 0, wq = 0, wf = 0, wp = -1, wg = 0;              // chunk-0 window: lane L = anchor i-1-L
-	Victim vt = { 0, 0, 0, -1, 0, INT_MIN / 2 };              // tile that left the ring last (FAR variants only)
+	Victim vt;                                                // tiles that left the ring last (FAR variants only)
+#pragma unroll
+	for (int k = 0; k < NV; ++k) { vt.x[k] = vt.q[k] = vt.f[k] = vt.g[k] = 0; vt.p[k] = -1; }
+	vt.base = INT_MIN / 2;
 	int seg0 = 0;
 	char *const t_bytes = (char *)s_t;
 	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
@@ -485,11 +498,13 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// after the tile, window lane L holds anchor i0+cnt-1-L: f/p of the tile enter the ring (older chunks never
 		// reach into the current tile, so once per tile is enough) and leave in coalesced 256 B stores
 		if (FAR) {
-			// the tile that the finished one pushes out of the ring stays reachable in registers for one more tile
+			// the tile that the finished one pushes out of the ring stays reachable in registers for NV more tiles
 			const int o = i0 + 63 - lane;                         // its slots are the ones written just below
 			const uint2 oxq = s_xq[o & (R - 1)]; const int2 ofp = s_fp[o & (R - 1)];
-			vt.x = (int)oxq.x; vt.q = (int)oxq.y; vt.f = ofp.x; vt.p = ofp.y; vt.base = i0 - R;
-			if (GEN) vt.g = s_g[o & (R - 1)];
+#pragma unroll
+			for (int k = NV - 1; k > 0; --k) { vt.x[k] = vt.x[k - 1]; vt.q[k] = vt.q[k - 1]; vt.f[k] = vt.f[k - 1]; vt.p[k] = vt.p[k - 1]; if (GEN) vt.g[k] = vt.g[k - 1]; }
+			vt.x[0] = (int)oxq.x; vt.q[0] = (int)oxq.y; vt.f[0] = ofp.x; vt.p[0] = ofp.y; vt.base = i0 - R;
+			if (GEN) vt.g[0] = s_g[o & (R - 1)];
 		}
 		if (lane < cnt) {
 			const int o = i0 + cnt - 1 - lane;
