@@ -242,6 +242,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 		const int stamp_lo = lds_lo + 64 - R;  // = i0 + 64 - 2R: oldest anchor whose stamp slot is in the LDS ring
 		const int s16_v = s16;                 // (one v_mov: the ds_write data operand)
 		int jtop = i - 1;
+		asm volatile("" : "+s"(jtop));      // opaque: keeps per-lane ring offsets out of the per-anchor loop (computed where used)
 		bool broke = false;
 		// ---------------- chunk 0 from registers
 		{
@@ -419,11 +420,11 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	__shared__ uint8_t s_g[GEN ? R : 64];
 
 	const int lane = threadIdx.x;
-	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
+	const int64_t task = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int64_t)blockIdx.x;
 	if (task >= n_tasks) return;
 	if (only_flagged && status[task] == 0) return;
 	const int64_t base = offsets[task];
-	const int n = (int)(offsets[task + 1] - base);
+	const int n = __builtin_amdgcn_readfirstlane((int)(offsets[task + 1] - base));   // wave-uniform: loop bounds stay on the scalar unit
 	if (n <= 0) return;
 	const uint4 *a = a_all + base;         // {x lo, x hi, y lo (= query pos), y hi (span | flags | seg)}
 	const int32_t *st = st_all + base;
@@ -455,7 +456,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	int cur_st = (lane < n) ? st[lane] : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int idx = i0 + lane;
-		const int cnt = min(64, n - i0);
+		const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - i0));   // keep the anchor loop bound on the scalar unit
 		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
 		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64]; }   // prefetch the next tile
 		const int g_l = (cur.w >> 16) & 0xff;                                 // MM_SEED_SEG_MASK mmpriv.h:22-23
