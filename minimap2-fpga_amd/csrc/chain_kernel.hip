@@ -227,13 +227,99 @@ struct Win { int x, q, f, p, g; };      // chunk-0 window registers: lane L = an
 #define NV 3
 struct Victim { int x[NV], q[NV], f[NV], p[NV], g[NV], base; };
 
+// ---------------------------------------------------------------- one older chunk (j <= i-65): LDS ring, victim tiles, L2/HBM
+// Returns true when the reference loop executes `break` inside the chunk.  FULL: all 64 lanes are inside the window.
+template <int R, bool SKIP, bool GEN, bool GS1, bool FAR, bool FULL>
+__device__ __forceinline__ bool older_chunk(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int stamp_lo, int stamp, int s16,
+                                            int s16_v, int xi, int qi, int span_i, int seg_i, int jtop, int rem, const Victim &vt,
+                                            const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g, char *t_bytes, uint16_t *s_t,
+                                            const uint4 *a, const int32_t *f, const int32_t *p, int32_t *t, int pbase, Carry &c)
+{
+	const int nl8 = -8 * lane, nl2 = -2 * lane;
+	const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
+	const uint2 xq = *(const uint2 *)(xq_bytes + off8);
+	const int2 fp = *(const int2 *)(fp_bytes + off8);
+	int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
+	if (GEN) gj = s_g[off8 >> 3];
+	const int own_off2 = ((jtop << 1) + nl2) & ((2 * R - 1) << 1);
+	const mask_t in_w = FULL ? ~0ull : first_lanes(rem);   // only the last chunk of a window is partial
+	mask_t far_l = 0;                                     // lanes whose predecessor left the ring
+	if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
+		int j = jtop - lane;
+		asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
+		const mask_t out_l = BALLOT(j < lds_lo) & in_w;       // lanes beyond the ring
+		// the 64*NV anchors just beyond the ring are still in registers: fetch them across lanes (no memory access)
+		far_l = out_l;
+#pragma unroll
+		for (int k = 0; k < NV; ++k) {
+			const int rel = j - (vt.base - 64 * k);            // position inside victim tile k
+			const mask_t vic = out_l & BALLOT((unsigned)rel < 64u);
+			if (vic != 0) {
+				const int src4 = (63 - rel) << 2;
+				xj = sel(vic, xj, __builtin_amdgcn_ds_bpermute(src4, vt.x[k]));
+				qj = sel(vic, qj, __builtin_amdgcn_ds_bpermute(src4, vt.q[k]));
+				fj = sel(vic, fj, __builtin_amdgcn_ds_bpermute(src4, vt.f[k]));
+				pj = sel(vic, pj, __builtin_amdgcn_ds_bpermute(src4, vt.p[k]));
+				if (GEN) gj = sel(vic, gj, __builtin_amdgcn_ds_bpermute(src4, vt.g[k]));
+				far_l &= ~vic;                                  // what is left goes to L2/HBM
+			}
+		}
+		if (far_l >> lane & 1) {
+			const uint4 aj = a[j];
+			xj = (int)aj.x; qj = (int)aj.z;
+			if (GEN) gj = (aj.w >> 16) & 0xff;
+		}
+	}
+	const int dr = xi - xj, dq = qi - qj;
+	const int dd = absdiff(dr, dq);
+	const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
+	const mask_t valid = pair_filter<GEN>(P, in_w, dr, dq, dd, same);
+	if (valid == 0) return false;
+	{
+		mask_t marked = 0;
+		if (FAR && far_l != 0) {
+			// look-back beyond the ring: f, p and stamps from L2/HBM, only for lanes that passed the filters
+			int j = jtop - lane;
+			asm volatile("" : "+v"(j));
+			const bool fl = (far_l & valid) >> lane & 1;
+			if (fl) {
+				fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (pj >= 0) pj -= pbase;             // p[] in memory is relative to the caller's task, the scan works piece-relative
+			}
+			if (SKIP) {
+				const bool mkv = (valid >> lane & 1) && pj >= lo;
+				if (mkv) {
+					if (pj >= stamp_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
+					else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				int tj = 0;
+				if (fl && j < stamp_lo) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
+				marked = BALLOT(tj == stamp);
+			}
+		}
+		int tj = 0;
+		const bool near_stamps = SKIP && !(FAR && far_l != 0);
+		if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, stamp_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
+		const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
+		const int scv = sel(valid, SENT, sc);
+		if (near_stamps) marked = BALLOT(tj == s16);
+		return fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
+	}
+	return false;
+}
+
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lane, int i, int lo, int lds_lo, int xi, int qi, int span_i,
                                             int seg_i, const Win &w, const Victim &vt, const char *xq_bytes, const char *fp_bytes, const uint8_t *s_g,
                                             char *t_bytes, uint16_t *s_t, const uint4 *a, const int32_t *f, const int32_t *p,
                                             int32_t *t, int pbase, Carry &c)
 {
-	const int nl8 = -8 * lane, nl2 = -2 * lane;               // ring byte offsets go down with the lane
+	const int nl2 = -2 * lane;                                // ring byte offsets go down with the lane
 	const int wx = w.x, wq = w.q, wf = w.f, wp = w.p, wg = w.g;
 	int rem = i - lo;                  // predecessors still to visit (> 0)
 	{
@@ -261,85 +347,14 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 			}
 			jtop -= 64; rem -= 64;
 		}
-		// ---------------- older chunks from the LDS ring (and from L2/HBM beyond it)
-		while (rem > 0 && !broke) {
-			const int off8 = ((jtop << 3) + nl8) & ((R - 1) << 3);
-			const uint2 xq = *(const uint2 *)(xq_bytes + off8);
-			const int2 fp = *(const int2 *)(fp_bytes + off8);
-			int xj = (int)xq.x, qj = (int)xq.y, fj = fp.x, pj = fp.y, gj = 0;
-			if (GEN) gj = s_g[off8 >> 3];
-			const int own_off2 = ((jtop << 1) + nl2) & ((2 * R - 1) << 1);
-			const mask_t in_w = first_lanes(rem);
-			mask_t far_l = 0;                                     // lanes whose predecessor left the ring
-			if (FAR && jtop - 63 < lds_lo && lo < lds_lo) {
-				int j = jtop - lane;
-				asm volatile("" : "+v"(j));                       // keep the far addressing out of the hot loop
-				const mask_t out_l = BALLOT(j < lds_lo) & in_w;       // lanes beyond the ring
-				// the 64*NV anchors just beyond the ring are still in registers: fetch them across lanes (no memory access)
-				far_l = out_l;
-#pragma unroll
-				for (int k = 0; k < NV; ++k) {
-					const int rel = j - (vt.base - 64 * k);            // position inside victim tile k
-					const mask_t vic = out_l & BALLOT((unsigned)rel < 64u);
-					if (vic != 0) {
-						const int src4 = (63 - rel) << 2;
-						xj = sel(vic, xj, __builtin_amdgcn_ds_bpermute(src4, vt.x[k]));
-						qj = sel(vic, qj, __builtin_amdgcn_ds_bpermute(src4, vt.q[k]));
-						fj = sel(vic, fj, __builtin_amdgcn_ds_bpermute(src4, vt.f[k]));
-						pj = sel(vic, pj, __builtin_amdgcn_ds_bpermute(src4, vt.p[k]));
-						if (GEN) gj = sel(vic, gj, __builtin_amdgcn_ds_bpermute(src4, vt.g[k]));
-						far_l &= ~vic;                                  // what is left goes to L2/HBM
-					}
-				}
-				if (far_l >> lane & 1) {
-					const uint4 aj = a[j];
-					xj = (int)aj.x; qj = (int)aj.z;
-					if (GEN) gj = (aj.w >> 16) & 0xff;
-				}
-			}
-			const int dr = xi - xj, dq = qi - qj;
-			const int dd = absdiff(dr, dq);
-			const mask_t same = GEN ? BALLOT(gj == seg_i) : ~0ull;
-			const mask_t valid = pair_filter<GEN>(P, in_w, dr, dq, dd, same);
-			if (valid != 0) {
-				mask_t marked = 0;
-				if (FAR && far_l != 0) {
-					// look-back beyond the ring: f, p and stamps from L2/HBM, only for lanes that passed the filters
-					int j = jtop - lane;
-					asm volatile("" : "+v"(j));
-					const bool fl = (far_l & valid) >> lane & 1;
-					if (fl) {
-						fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if (pj >= 0) pj -= pbase;             // p[] in memory is relative to the caller's task, the scan works piece-relative
-					}
-					if (SKIP) {
-						const bool mkv = (valid >> lane & 1) && pj >= lo;
-						if (mkv) {
-							if (pj >= stamp_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
-							else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						}
-						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
-						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-						__builtin_amdgcn_wave_barrier();
-						int tj = 0;
-						if (fl && j < stamp_lo) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
-						marked = BALLOT(tj == stamp);
-					}
-				}
-				int tj = 0;
-				const bool near_stamps = SKIP && !(FAR && far_l != 0);
-				if (near_stamps) tj = stamp_and_fetch<R, FAR>(valid, pj, lo, stamp_lo, stamp, s16_v, t_bytes, t, lane, own_off2);
-				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
-				const int scv = sel(valid, SENT, sc);
-				if (near_stamps) marked = BALLOT(tj == s16);
-				broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
-			}
-			jtop -= 64; rem -= 64;
-		}
-	
-
+		// ---------------- older chunks from the LDS ring (and from registers / L2 / HBM beyond it): full chunks, then the partial one
+		if (broke) return;
+		for (; rem >= 64; jtop -= 64, rem -= 64)
+			if (older_chunk<R, SKIP, GEN, GS1, FAR, true>(P, avg, lane, i, lo, lds_lo, stamp_lo, stamp, s16, s16_v, xi, qi, span_i, seg_i, jtop, rem,
+			                                              vt, xq_bytes, fp_bytes, s_g, t_bytes, s_t, a, f, p, t, pbase, c)) return;
+		if (rem > 0)
+			older_chunk<R, SKIP, GEN, GS1, FAR, false>(P, avg, lane, i, lo, lds_lo, stamp_lo, stamp, s16, s16_v, xi, qi, span_i, seg_i, jtop, rem,
+			                                           vt, xq_bytes, fp_bytes, s_g, t_bytes, s_t, a, f, p, t, pbase, c);
 	}
 }
 
