@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--reads", type=int, default=65536, help="reads (tasks) per GPU per step")
     ap.add_argument("--distinct", type=int, default=8192, help="distinct synthetic reads generated; tiled up to --reads")
     ap.add_argument("--anchors-per-read", type=int, default=5000)
+    ap.add_argument("--ragged", action="store_true", help="anchors per read ~ U[0.2, 1.8] x --anchors-per-read (SURVEY 8d ragged variant)")
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
     ap.add_argument("--preset", default="map-ont", choices=["map-ont", "asm20", "ava-ont"],
@@ -131,8 +132,8 @@ def main():
     # ---- synthetic batch of this rank, generated on the device (deterministic: splitmix64 of seed + rank)
     distinct = min(args.distinct, args.reads)
     times = max(1, args.reads // distinct)
-    off1, a1 = synth.make_stream(args.profile, distinct, args.anchors_per_read, seed=args.seed + rank, q_span=q_span, device="cuda",
-                                 locus=locus)
+    n_per = (int(0.2 * args.anchors_per_read), int(1.8 * args.anchors_per_read)) if args.ragged else args.anchors_per_read
+    off1, a1 = synth.make_stream(args.profile, distinct, n_per, seed=args.seed + rank, q_span=q_span, device="cuda", locus=locus)
     off, anchors = synth.replicate(off1, a1, times)
     n_tasks = off.numel() - 1
     total = int(off[-1])
@@ -189,7 +190,7 @@ def main():
                                f"{args.preset} chaining params (max_dist={P.max_dist_x}, bw={P.bw}, max_iter={P.max_iter}, max_skip={P.max_skip}), "
                                f"HBM-resident",
                    "reads_per_gpu_per_step": n_tasks, "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
-                   "profile": args.profile, "preset": args.preset, "parallelism": f"read-sharded x{world}"},
+                   "profile": args.profile, "preset": args.preset, "ragged": bool(args.ragged), "parallelism": f"read-sharded x{world}"},
         "verified_vs_oracle": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_wave", "kernel_ms_avg": k_avg_ms,

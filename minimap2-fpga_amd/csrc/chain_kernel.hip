@@ -464,6 +464,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	for (int k = 0; k < NV; ++k) { vt.x[k] = vt.q[k] = vt.f[k] = vt.g[k] = 0; vt.p[k] = -1; }
 	vt.base = INT_MIN / 2;
 	int seg0 = 0;
+	bool t_ready = false;                                     // t[0 .. i0) has been zeroed (wave-uniform)
 	char *const t_bytes = (char *)s_t;
 	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
 
@@ -483,7 +484,15 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// while this tile is processed the ring holds anchors [i0-R, i0): the tile itself lives in `cur` and in the
 		// chunk-0 window and enters the ring when it is finished (older chunks never reach into the current tile)
 		s_t[idx & (2 * R - 1)] = 0;          // stamp slots of the entering anchors (recycled from idx-2R)
-		if (FAR && idx < n) t[idx] = 0;
+		// global stamp scratch t[]: zeroed lazily, only once this task's windows can reach beyond the LDS stamp ring
+		if (FAR) {
+			const int reach = rdlane(cur_st, 0);                  // window start of the first anchor of the tile (st[] is monotone)
+			if (!t_ready && reach < i0 + 64 - 2 * R) {
+				for (int z = lane; z < i0; z += 64) t[z] = 0;
+				t_ready = true;
+			}
+			if (t_ready && idx < n) t[idx] = 0;
+		}
 		const int span_l = P.span_override >= 0 ? P.span_override : (int)(cur.w & 0xff);   // chain.c:189
 		const int lds_lo = i0 - R;            // oldest anchor index still in the ring while this tile is processed
 
