@@ -83,6 +83,28 @@ def test_ring_classes_and_far_lookback(ring_class):
         mm2chain.tune("ring_class", 0)
 
 
+@pytest.mark.parametrize("max_skip", [25, 1000, INT32_MAX])
+def test_window_lengths_around_ring_and_victim_boundaries(max_skip):
+    """one dense cluster per task (every anchor within max_dist_x of every other): look-back lengths of exactly
+    ring (256), ring + 1..3 register tiles (320/384/448) and beyond (L2/HBM), +-1 anchor each"""
+    from mm2chain import params
+    rng = np.random.default_rng(int(max_skip) % 1000)
+    sizes = [63, 64, 65, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 511, 512, 513, 640, 900]
+    tasks = []
+    for n in sizes:
+        pos = 50000 + np.cumsum(rng.integers(0, 3, n))           # spans < 2n bp, far below max_dist_x
+        q = 100 + np.cumsum(rng.integers(0, 4, n))
+        x = (np.uint64(3) << np.uint64(32)) | pos.astype(np.uint64)
+        y = (np.uint64(15) << np.uint64(32)) | q.astype(np.uint64)
+        tasks.append(np.stack((x, y), 1))
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    P = params.make_params(max_skip=max_skip, bw=5000)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, f"boundaries max_skip={max_skip}")
+
+
 def test_ava_ont_and_asm20_shapes():
     from mm2chain import params
     for P, span in ((params.ava_ont(), 15), (params.asm20(), 19)):
