@@ -14,12 +14,18 @@
 //     chunk c holding j = i-1-64c-L, i.e. ascending lane = the reference's scan order.
 //   * chunk 0 (the 64 nearest predecessors) lives in VGPRs and is shifted one lane per anchor with a
 //     DPP wave_shr:1, so the i -> i+1 dependency never goes through memory.
-//   * chunks 1.. read an LDS ring (x, q | f, p as two ds_read_b64 per lane, conflict-free); anchors enter
-//     the ring in coalesced 1 KiB tiles (one global_load_dwordx4 per lane per 64 anchors, next tile
-//     prefetched while the current one is processed), f/p enter it once per tile.  Only look-back beyond
-//     the ring goes to L2/HBM, and there f/p/stamps are fetched only when some lane passes the filters.
-//   * the kernel is VALU-issue bound (measured: SQ_ACTIVE_INST_VALU ~ all SIMD cycles, integer VALU = 4
-//     cycles per wave64 instruction), so the instruction stream is kept lean: lane predicates live as
+//   * the window start of every anchor (chain.c:192-193) comes from a prepass kernel (chain_window_start, 64-bit
+//     binary searches), so the DP works on low words of x and knows each window exactly.
+//   * chunks 1.. read an LDS ring of R anchors (x, q | f, p as two ds_read_b64 per lane, conflict-free); anchors
+//     arrive in coalesced 1 KiB tiles (one global_load_dwordx4 per lane per 64 anchors, next tile prefetched while
+//     the current one is processed) and a finished tile enters the ring in one shot, so the ring always holds the R
+//     anchors before the current tile.  The NV tiles that left the ring last stay in VGPRs ("victim" tiles) and are
+//     read across lanes with ds_bpermute.  Only look-back beyond that goes to L2/HBM, and there f/p/stamps are
+//     fetched only for lanes that passed the filters.
+//   * chain.c's t[] (stamps "predecessor already on a visited chain") is a 16-bit stamp ring in LDS covering 2R
+//     anchors (scatter by p[j], gather by j, cleared as anchors enter), 32-bit stamps in a global scratch beyond it.
+//   * the kernel is integer-issue bound (measured: SQ_ACTIVE_INST_VALU ~84 %, SQ_ACTIVE_INST_SCA ~77 % of all SIMD cycles,
+//     both 4 cycles per wave64 instruction), so the instruction stream is kept lean: lane predicates live as
 //     64-bit masks in SGPRs (one v_cmp each, combined on the scalar unit), the window bound j >= lo is a
 //     scalar-built lane mask, a chunk with no lane passing the filters (chain.c:202-206) skips scoring.
 //   * the max_skip rule is order dependent.  Per chunk it is evaluated with a DPP prefix max (which lanes
