@@ -48,6 +48,7 @@ struct Global {
 	int ring_class = 0;
 	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
 	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
+	int64_t cut_below_tasks = 4096;         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
 	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
@@ -380,10 +381,11 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	int rc;
 	const mm2c_params_t *par = reqs[0]->par;
 	const uint64_t D = (uint64_t)(int64_t)par->max_dist_x;
-	const int64_t seg_min = G.seg_min;
 	int64_t total = 0, n_tasks_all = 0;
 	for (int r = 0; r < n_req; ++r) { total += reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]; n_tasks_all += reqs[r]->n_tasks; }
 	if (total == 0) return 0;
+	// cutting costs a host pass over the anchors: only worth it when the pass has too few tasks to fill the GPU on its own
+	const int64_t seg_min = n_tasks_all < G.cut_below_tasks ? G.seg_min : 0;
 	std::vector<int64_t> seg_off; std::vector<int32_t> pbase, order; std::vector<float> seg_avg;
 	seg_off.reserve((size_t)n_tasks_all + 16); pbase.reserve((size_t)n_tasks_all + 16); seg_avg.reserve((size_t)n_tasks_all + 16);
 	int64_t g0 = 0;                                                // where this request's anchors start in the arena
