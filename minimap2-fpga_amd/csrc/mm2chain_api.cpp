@@ -386,6 +386,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	if (total == 0) return 0;
 	// cutting costs a host pass over the anchors: only worth it when the pass has too few tasks to fill the GPU on its own
 	const int64_t seg_min = n_tasks_all < G.cut_below_tasks ? G.seg_min : 0;
+	// uncut tasks without a caller-supplied avg_qspan_scaled: the kernel sums the spans itself (chain.c:48-49), no host pass
+	bool kernel_avg = seg_min == 0;
+	for (int r = 0; r < n_req; ++r) if (reqs[r]->avg) kernel_avg = false;
 	std::vector<int64_t> seg_off; std::vector<int32_t> pbase, order; std::vector<float> seg_avg;
 	seg_off.reserve((size_t)n_tasks_all + 16); pbase.reserve((size_t)n_tasks_all + 16); seg_avg.reserve((size_t)n_tasks_all + 16);
 	int64_t g0 = 0;                                                // where this request's anchors start in the arena
@@ -396,9 +399,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		for (int64_t k = 0; k < q.n_tasks; ++k) {
 			const int64_t t0 = q.off[k] - base, t1 = q.off[k + 1] - base;
 			if (t1 == t0) continue;
-			float avg;
+			float avg = 0.f;
 			if (q.avg) avg = q.avg[k];
-			else {
+			else if (!kernel_avg) {
 				uint64_t sum = 0;
 				for (int64_t i = t0; i < t1; ++i) sum += a[i].y >> 32 & 0xff;
 				avg = (float)(.01 * (float)sum / (t1 - t0));
@@ -453,7 +456,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(par);
 	L.n_tasks = n_seg; L.d_offsets = (const int64_t *)(c->d_in + o_off); L.d_order = (const int32_t *)(c->d_in + o_ord);
-	L.d_anchors = c->d_in + o_a; L.d_avg = (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
+	L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
 	L.d_status = (int32_t *)(c->d_in + o_stat);
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
