@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Parity soak (GPU box): many random parameter sets x adversarial / synthetic anchor lists, HIP path vs CPU oracle, bit for bit.
+usage: tools/soak.py [n_rounds] [seed0]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, mm2chain
+from mm2chain import params, synth
+from helpers import mk_anchor, pack, oracle_batch, gpu_batch
+from test_gpu_parity import _random_task
+INT32_MAX = 2**31 - 1
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+mm2chain.init()
+t0 = time.time(); n_anchor = 0; bad = 0
+for r in range(rounds):
+    rng = np.random.default_rng(seed0 + r)
+    n_segs = int(rng.choice([1, 1, 1, 2, 3]))
+    P = params.make_params(max_dist_x=int(rng.choice([0, 50, 700, 5000, 10000, 100000])), max_dist_y=int(rng.choice([-5, 60, 700, 5000, 10000])),
+                           bw=int(rng.choice([-1, 0, 10, 500, 2000, 5000])), max_skip=int(rng.choice([-1, 0, 1, 5, 25, 25, 300, INT32_MAX])),
+                           max_iter=int(rng.choice([-3, 0, 1, 63, 64, 65, 200, 1024, 5000, 5000, INT32_MAX])),
+                           gap_scale=float(rng.choice([1.0, 1.0, 0.5, 0.8, 2.25, 0.0])), is_cdna=int(rng.integers(0, 2)) if n_segs > 1 or rng.random() < .2 else 0,
+                           n_segs=n_segs)
+    mm2chain.tune("ring_class", int(rng.choice([0, 0, 0, 1, 2])))
+    tasks = []
+    for _ in range(int(rng.integers(1, 12))):
+        kind = rng.random()
+        if kind < 0.5:
+            tasks.append(_random_task(rng, int(rng.integers(1, 2500)), int(rng.integers(1, 4)), n_segs, bool(rng.integers(0, 2))))
+        else:
+            prof = str(rng.choice(["mixed", "dense", "colinear", "sparse"]))
+            _, a = synth.make_stream(prof, 1, int(rng.integers(1, 3000)), seed=int(rng.integers(0, 1 << 30)), q_span=int(rng.choice([15, 19])),
+                                     locus=int(rng.choice([3000, 20000, 100000])) if prof != "sparse" else None)
+            tasks.append(a.numpy().view(np.uint64))
+    a = np.concatenate(tasks); off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    n_anchor += a.shape[0]
+    if not (np.array_equal(f, f_ref) and np.array_equal(p, p_ref)):
+        bad += 1
+        i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
+        print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
+mm2chain.tune("ring_class", 0)
+print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
