@@ -216,6 +216,15 @@ def main():
         out["host_streamed"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s",
                                 "sample": f"{n_h} reads ({int(off_host[-1])} anchors) from pageable host memory: H2D + prepass + DP + D2H + sync, 1 call",
                                 "matches_resident": bool(np.array_equal(fh, d_f[: int(off_host[-1])].cpu().numpy()))}
+        pa = mm2chain.PinnedArray(a_host.shape, np.uint64); pf = mm2chain.PinnedArray(fh.shape, np.int32); pp = mm2chain.PinnedArray(ph.shape, np.int32)
+        pa.array[:] = a_host
+        mm2chain.chain_batch_host_into(P, off_host, pa.array, pf.array, pp.array)
+        th = time.perf_counter()
+        mm2chain.chain_batch_host_into(P, off_host, pa.array, pf.array, pp.array)
+        th = time.perf_counter() - th
+        out["host_streamed_pinned"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s",
+                                       "sample": "same call with anchors and outputs in page-locked host memory (mm2c_pinned_alloc)",
+                                       "matches_resident": bool(np.array_equal(pf.array, fh) and np.array_equal(pp.array, ph))}
     except StopIteration:
         pass
     except Exception as e:                                                   # never let a secondary figure break the line

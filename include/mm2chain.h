@@ -61,7 +61,8 @@ const char *mm2c_last_error(void);            /* thread-local message of the las
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
 /* tuning knobs (key, value): "ring_class" 0/1/2 = 256/512/1024 anchors of LDS ring per task (default 0, or env
  * MM2C_RING_CLASS); "seg_min" = shortest piece (anchors) the host-buffer paths cut a task into at empty-window positions
- * (default 256, 0 = never cut).  Results never depend on a knob. */
+ * (default 256, 0 = never cut); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for host batches of at least
+ * twice that size (default 20 Mi anchors).  Results never depend on a knob. */
 int  mm2c_tune(const char *key, int value);
 
 /* defaults of `minimap2 -x map-ont` (options.c:24-31,93-99; map.c:305-316) */
@@ -108,6 +109,11 @@ int mm2c_plan_predict_device(mm2c_plan_t *plan, const void *d_anchors, uint8_t *
 int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets,
                           const mm2c_anchor_t *h_anchors, const float *h_avg_qspan /* or NULL */,
                           int32_t *h_f, int32_t *h_p);
+
+/* page-locked host memory for callers that want full PCIe rate on the host-buffer paths (any pointer works there; pageable
+ * memory is staged by the runtime at roughly a quarter of the rate).  NULL on failure. */
+void *mm2c_pinned_alloc(size_t bytes);
+void  mm2c_pinned_free(void *ptr);
 
 /*
  * One task, synchronous, V1 (stock CPU) semantics: the EXTENDED form of run_chaining_on_hw

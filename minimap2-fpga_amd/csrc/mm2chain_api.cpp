@@ -48,6 +48,7 @@ struct Global {
 	int ring_class = 0;
 	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
 	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
+	int64_t pipeline_chunk_anchors = 20 << 20;  // host paths: batches of at least twice this size are pipelined in chunks of this size
 	int64_t cut_below_tasks = 4096;         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
@@ -61,7 +62,8 @@ struct Global {
 // ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
 // mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
 struct ThreadCtx {
-	hipStream_t st = nullptr;
+	hipStream_t st = nullptr, st2 = nullptr;   // st2: second stream of the pipelined big-batch path
+	hipEvent_t ev = nullptr;
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
 	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
 	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
@@ -69,7 +71,7 @@ struct ThreadCtx {
 	{
 		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
 		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
-		if (st) (void)hipStreamDestroy(st);
+		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
 		*this = ThreadCtx();
 	}
 };
@@ -222,6 +224,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "ring_class") == 0) {
 		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "ring_class must be 0, 1 or 2");
 		G.ring_class = value;
+		return 0;
+	}
+	if (strcmp(key, "pipeline_chunk_anchors") == 0) {
+		if (value < 1024) return fail(MM2C_E_ARG, "pipeline_chunk_anchors must be >= 1024");
+		G.pipeline_chunk_anchors = value;
 		return 0;
 	}
 	if (strcmp(key, "seg_min") == 0) {
@@ -444,6 +451,43 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			at += nb;
 		}
 		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
+	} else if (n_req == 1 && total >= 2 * G.pipeline_chunk_anchors) {
+		// big batch: pipeline it in chunks of whole pieces on two streams, so that the upload of chunk k+1, the kernels of chunk k
+		// and the download of chunk k-1 overlap (PCIe is full duplex); with page-locked caller buffers this runs at PCIe rate
+		if (!c->st2) HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+		if (!c->ev) HIP_TRY(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
+		HIP_TRY(hipEventRecord(c->ev, c->st));
+		HIP_TRY(hipStreamWaitEvent(c->st2, c->ev, 0));
+		const HostReq &q = *reqs[0];
+		const mm2c_anchor_t *src = q.a + q.off[0];
+		int32_t *dst_f = q.f + q.off[0], *dst_p = q.p + q.off[0];
+		const int64_t chunk_anchors = G.pipeline_chunk_anchors;      // big enough for one chunk to fill the GPU on its own
+		int nl = 0, k = 0;
+		for (int64_t s0 = 0; s0 < n_seg; ++k) {
+			int64_t s1 = s0 + 1;
+			while (s1 < n_seg && seg_off[(size_t)s1 + 1] - seg_off[(size_t)s0] <= chunk_anchors) ++s1;
+			const int64_t a0 = seg_off[(size_t)s0], a1 = seg_off[(size_t)s1];
+			hipStream_t st = (k & 1) ? c->st2 : c->st;
+			HIP_TRY(hipMemcpyAsync(c->d_in + o_a + (size_t)a0 * 16, src + a0, (size_t)(a1 - a0) * 16, hipMemcpyHostToDevice, st));
+			mm2c::LaunchArgs L;
+			L.P = to_kparams(par);
+			L.n_tasks = s1 - s0; L.d_offsets = (const int64_t *)(c->d_in + o_off) + s0; L.d_order = nullptr;
+			L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg) + s0;
+			L.d_pbase = (const int32_t *)(c->d_in + o_pb) + s0; L.d_status = (int32_t *)(c->d_in + o_stat) + s0;
+			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
+			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
+			L.ring_class = G.ring_class;
+			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
+			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
+			s0 = s1;
+		}
+		HIP_TRY(hipStreamSynchronize(c->st));
+		HIP_TRY(hipStreamSynchronize(c->st2));
+		G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
+		G.passes += 1;
+		return 0;
 	} else {
 		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
 		size_t at = o_a;
@@ -584,6 +628,19 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
 	return rc;
 }
+
+void *mm2c_pinned_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (hipSetDevice(G.device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+		fail(MM2C_E_HIP, "hipHostMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+void mm2c_pinned_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
 int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
                          int32_t *f, int32_t *p, int tid)

@@ -109,6 +109,44 @@ class ChainPlan:
             pass
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory from mm2c_pinned_alloc (freed when the object dies)"""
+
+    def __init__(self, shape, dtype):
+        self.lib = N.load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.lib.mm2c_pinned_alloc(self.nbytes)
+        if not self.ptr:
+            N.check(-1, "mm2c_pinned_alloc")
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.array = None
+                self.lib.mm2c_pinned_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def chain_batch_host_into(params: Params, offsets, anchors, f, p, avg=None):
+    """as chain_batch_host, but into caller-provided int32 arrays (e.g. PinnedArray.array); anchors may be pinned too"""
+    lib = N.load()
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    a = anchors.view(np.uint64).reshape(-1, 2)
+    assert a.flags.c_contiguous and f.flags.c_contiguous and p.flags.c_contiguous and f.dtype == np.int32 and p.dtype == np.int32
+    if off.size and (off[0] < 0 or off[-1] > a.shape[0] or off[-1] > f.size or off[-1] > p.size):
+        raise ValueError("offsets do not fit the arrays")
+    avg_p = None
+    if avg is not None:
+        avg = np.ascontiguousarray(avg, dtype=np.float32)
+        avg_p = _np_ptr(avg)
+    N.check(lib.mm2c_chain_batch_host(C.byref(params), off.size - 1, _np_ptr(off), _np_ptr(a), avg_p, _np_ptr(f), _np_ptr(p)),
+            "mm2c_chain_batch_host")
+
+
 def chain_batch_host(params: Params, offsets, anchors, avg=None):
     """Whole batch from host numpy arrays (uint64 [total,2]); returns (f, p) int32 arrays.  PCIe included."""
     lib = N.load()

@@ -391,6 +391,28 @@ def test_batched_runner_on_a_stream_file(tmp_path):
     assert got == want
 
 
+def test_big_host_batch_is_pipelined_in_chunks():
+    """> 2 M anchors from host memory (pageable and page-locked): the two-stream chunked path"""
+    import mm2chain
+    from mm2chain import params, _native as N
+    P = params.map_ont()
+    off, a = _stream("mixed", 700, (2000, 5000), seed=71)
+    assert a.shape[0] > (1 << 21)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    mm2chain.tune("pipeline_chunk_anchors", 300000)          # force the chunked two-stream path at this size
+    try:
+        f, p = mm2chain.chain_batch_host(P, off, a)
+    finally:
+        mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
+    assert_same(f, p, f_ref, p_ref, off, "big pageable batch, pipelined")
+    f, p = mm2chain.chain_batch_host(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "big pageable batch")
+    pa = mm2chain.PinnedArray(a.shape, np.uint64); pf = mm2chain.PinnedArray(f.shape, np.int32); pp = mm2chain.PinnedArray(p.shape, np.int32)
+    pa.array[:] = a
+    mm2chain.chain_batch_host_into(P, off, pa.array, pf.array, pp.array)
+    assert_same(pf.array, pp.array, f_ref, p_ref, off, "big pinned batch")
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (5000 anchors per read, many reads): properties that need no oracle at full size, plus a
     sampled oracle check.  f[i] >= span, -1 <= p[i] < i, f[i] - f[p[i]] <= span, replicated tasks give replicated output."""
