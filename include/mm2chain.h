@@ -56,7 +56,7 @@ typedef struct {
 
 /* ---- lifecycle: replaces hardware_init(BUFFER_N, XCLBIN_FILE) / cleanup() (chain_hardware.h:70-71, main.c:367,430) ---- */
 int  mm2c_init(int device_ordinal);           /* -1: current device.  Idempotent. */
-void mm2c_shutdown(void);
+void mm2c_shutdown(void);                     /* not while another thread is inside a compute entry */
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
 /* tuning knobs (key, value): "ring_class" 0/1/2 = 256/512/1024 anchors of LDS ring per task (default 0, or env
@@ -86,6 +86,7 @@ int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
  * own stream).  All pointers are DEVICE pointers: d_anchors[total] (16 B each), d_f[total], d_p[total].
  * d_avg_qspan is either NULL (the kernel computes avg_qspan_scaled per task exactly as chain.c:48-49) or
  * n_tasks floats.  p[] is task-relative, -1 = no predecessor, exactly as chain.c:236.  Asynchronous.
+ * A plan owns one workspace: do not run the same plan concurrently with itself (different plans and different streams are fine).
  */
 int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *d_avg_qspan,
                          int32_t *d_f, int32_t *d_p, void *stream);
