@@ -138,6 +138,28 @@ mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip,
                            int *n_u_, uint64_t **_u, void *km, int tid);
 #endif
 
+/* ---- whole mm_chain_dp for a batch: DP + epilogue (chain.c:106-111,348-422) ----
+ * Outputs are compact: the chains of task k are u[u_off[k] .. u_off[k+1]) (score<<32 | count, in the order mm_chain_dp returns
+ * them, chain.c:385-388,406-420) and their anchors b[b_off[k] .. b_off[k+1]); u_off / b_off have n_tasks+1 entries, u and b need
+ * room for every anchor of the batch.  Results equal mm_chain_dp called task by task. */
+
+/* the epilogue on the GPU, after mm2c_plan_run_device on the same stream; all pointers are device memory; needs
+ * mm2c_plan_total_anchors < 2^31 */
+int mm2c_plan_chains_device(mm2c_plan_t *plan, const void *d_anchors, const int32_t *d_f, const int32_t *d_p, int min_cnt, int min_sc,
+                            int64_t *d_u_off, uint64_t *d_u, int64_t *d_b_off, void *d_b, void *stream);
+int mm2c_plan_last_epilogue_ms(mm2c_plan_t *plan, float *ms);
+
+/* the epilogue on n_threads host threads from f[] / p[] in host memory (what the reference does on the calling thread) */
+int mm2c_chain_epilogue_host(int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                             const int32_t *h_f, const int32_t *h_p, int n_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
+                             mm2c_anchor_t *b);
+
+/* host buffers in, chains out.  epilogue_threads == 0: DP and epilogue on the GPU, only chains come back over PCIe;
+ * epilogue_threads > 0: DP on the GPU, f[] / p[] come back and the epilogue runs on that many host threads. */
+int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets,
+                                const mm2c_anchor_t *h_anchors, int epilogue_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
+                                mm2c_anchor_t *b);
+
 /* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
 typedef struct {
 	mm2c_params_t par;            /* scalars of the mm_chain_dp calls the tasks came from */

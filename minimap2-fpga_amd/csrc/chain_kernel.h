@@ -41,5 +41,30 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 // ev_dp_begin (optional) is recorded between the window-start prepass and the DP kernel
 hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin);
 
+// ---- device epilogue of mm_chain_dp (chain.c:106-111,348-422), chain_epilogue.hip ----
+struct EpiArgs {
+	int64_t n_tasks, total;
+	const int64_t *d_off;       // n_tasks+1, CSR (task 0 at 0)
+	const int32_t *d_order;     // longest task first, or nullptr
+	const ulonglong2 *d_a;      // anchors
+	const int32_t *d_f, *d_p;   // DP result
+	int32_t min_cnt, min_sc;
+	// scratch, `total` entries each unless noted
+	int32_t *v;                 // v[] (chain.c:106-111), later the depth of an anchor inside its chain
+	int32_t *own;               // child marks, later the rank of the chain that takes the anchor
+	int32_t *ctop, *rk2kk, *dest, *val0, *val1;
+	uint64_t *key0, *key1;      // chain-end keys (f[peak]<<32 | peak) unsorted / sorted; key0 is reused for the first-x keys
+	uint64_t *u2, *rkey1;       // score<<32|count per kept chain; first-x keys sorted
+	uint32_t *seg_begin, *seg_end1, *seg_end2;   // per task: segment bounds for the two sorts
+	int32_t *cnt_u, *cnt_b;     // per task: kept chains, their anchors
+	void *sort_tmp; size_t sort_tmp_bytes;
+	// outputs (compact): chains of task k are u_out[u_off[k] .. u_off[k+1]), their anchors b_out[b_off[k] .. b_off[k+1])
+	int64_t *u_off, *b_off;     // n_tasks+1 each
+	uint64_t *u_out;
+	ulonglong2 *b_out;
+};
+size_t epilogue_sort_temp_bytes(int64_t total, int64_t n_tasks);
+hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launches);
+
 } // namespace mm2c
 #endif

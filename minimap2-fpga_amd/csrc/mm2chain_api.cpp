@@ -164,8 +164,10 @@ struct mm2c_plan {
 	mm2c_params_t par;
 	int64_t n_tasks = 0, total = 0;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr;
-	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr;
-	bool ran = false;
+	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
+	bool ran = false, epi_ran = false;
+	char *d_epi = nullptr;                  // scratch of the device epilogue, allocated by the first mm2c_plan_chains_device
+	mm2c::EpiArgs E;
 };
 
 extern "C" {
@@ -304,6 +306,8 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 	if (pl->d_status) (void)hipFree(pl->d_status); if (pl->d_t) (void)hipFree(pl->d_t); if (pl->d_st) (void)hipFree(pl->d_st);
 	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
+	if (pl->d_epi) (void)hipFree(pl->d_epi);
 	delete pl;
 }
 
@@ -360,6 +364,65 @@ int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
 	HIP_TRY(hipEventSynchronize(pl->ev1));
 	HIP_TRY(hipEventElapsedTime(ms, pl->ev0, pl->ev1));
+	return 0;
+}
+
+// the epilogue of mm_chain_dp (chain.c:106-111,348-422) for every task of the plan, on the GPU (chain_epilogue.hip)
+int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_t *d_f, const int32_t *d_p, int min_cnt, int min_sc,
+                            int64_t *d_u_off, uint64_t *d_u, int64_t *d_b_off, void *d_b, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!d_u_off || !d_b_off) return fail(MM2C_E_ARG, "device pointer is NULL");
+	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	if (pl->n_tasks == 0 || pl->total == 0) {
+		HIP_TRY(hipMemsetAsync(d_u_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));
+		HIP_TRY(hipMemsetAsync(d_b_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));
+		return 0;
+	}
+	if (!d_anchors || !d_f || !d_p || !d_u || !d_b) return fail(MM2C_E_ARG, "device pointer is NULL");
+	if (pl->total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "the device epilogue takes batches of fewer than 2^31 anchors (got %lld)", (long long)pl->total);
+	mm2c::EpiArgs &E = pl->E;
+	if (!pl->d_epi) {
+		HIP_TRY(hipSetDevice(G.device));
+		const size_t tot = (size_t)pl->total, nt = (size_t)pl->n_tasks;
+		const size_t tmp = mm2c::epilogue_sort_temp_bytes(pl->total, pl->n_tasks);
+		size_t at = 0;
+		auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+		const size_t o_key0 = take(tot * 8), o_key1 = take(tot * 8), o_u2 = take(tot * 8), o_rkey1 = take(tot * 8);
+		const size_t o_v = take(tot * 4), o_own = take(tot * 4), o_ctop = take(tot * 4), o_rk = take(tot * 4), o_dest = take(tot * 4),
+		             o_val0 = take(tot * 4), o_val1 = take(tot * 4);
+		const size_t o_sb = take(nt * 4), o_se1 = take(nt * 4), o_se2 = take(nt * 4), o_cu = take(nt * 4), o_cb = take(nt * 4);
+		const size_t o_tmp = take(tmp ? tmp : 1);
+		HIP_TRY(hipMalloc((void **)&pl->d_epi, at));
+		char *b = pl->d_epi;
+		E.key0 = (uint64_t *)(b + o_key0); E.key1 = (uint64_t *)(b + o_key1); E.u2 = (uint64_t *)(b + o_u2); E.rkey1 = (uint64_t *)(b + o_rkey1);
+		E.v = (int32_t *)(b + o_v); E.own = (int32_t *)(b + o_own); E.ctop = (int32_t *)(b + o_ctop); E.rk2kk = (int32_t *)(b + o_rk);
+		E.dest = (int32_t *)(b + o_dest); E.val0 = (int32_t *)(b + o_val0); E.val1 = (int32_t *)(b + o_val1);
+		E.seg_begin = (uint32_t *)(b + o_sb); E.seg_end1 = (uint32_t *)(b + o_se1); E.seg_end2 = (uint32_t *)(b + o_se2);
+		E.cnt_u = (int32_t *)(b + o_cu); E.cnt_b = (int32_t *)(b + o_cb);
+		E.sort_tmp = b + o_tmp; E.sort_tmp_bytes = tmp;
+		HIP_TRY(hipEventCreate(&pl->ev_e0));
+		HIP_TRY(hipEventCreate(&pl->ev_e1));
+	}
+	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off; E.d_order = pl->d_order;
+	E.d_a = (const ulonglong2 *)d_anchors; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
+	E.u_off = d_u_off; E.b_off = d_b_off; E.u_out = d_u; E.b_out = (ulonglong2 *)d_b;
+	int nl = 0;
+	HIP_TRY(hipEventRecord(pl->ev_e0, st));
+	HIP_TRY(mm2c::launch_chain_epilogue(E, st, &nl));
+	HIP_TRY(hipEventRecord(pl->ev_e1, st));
+	pl->epi_ran = true;
+	G.launches += (uint64_t)nl;
+	return 0;
+}
+
+int mm2c_plan_last_epilogue_ms(mm2c_plan_t *pl, float *ms)
+{
+	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
+	if (!pl->epi_ran) return fail(MM2C_E_ARG, "mm2c_plan_chains_device has not been run");
+	HIP_TRY(hipEventSynchronize(pl->ev_e1));
+	HIP_TRY(hipEventElapsedTime(ms, pl->ev_e0, pl->ev_e1));
 	return 0;
 }
 
@@ -626,6 +689,58 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 		rc = run_requests(c, &one, 1);
 	}
 	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	return rc;
+}
+
+int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets,
+                                const mm2c_anchor_t *h_anchors, int epilogue_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
+                                mm2c_anchor_t *b)
+{
+	int rc;
+	if ((rc = check_params(par))) return rc;
+	if (n_tasks < 0 || !u_off || !b_off) return fail(MM2C_E_ARG, "bad argument");
+	u_off[0] = b_off[0] = 0;
+	if (n_tasks == 0) return 0;
+	if (!h_offsets) return fail(MM2C_E_ARG, "offsets is NULL");
+	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
+	if (total > 0 && (!h_anchors || !u || !b)) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (epilogue_threads > 0) {
+		std::vector<int32_t> f((size_t)std::max<int64_t>(total, 1)), p((size_t)std::max<int64_t>(total, 1));
+		if ((rc = mm2c_chain_batch_host(par, n_tasks, h_offsets, h_anchors, nullptr, f.data() - h_offsets[0], p.data() - h_offsets[0]))) return rc;
+		rc = mm2c_chain_epilogue_host(min_cnt, min_sc, n_tasks, h_offsets, h_anchors, f.data() - h_offsets[0], p.data() - h_offsets[0],
+		                              epilogue_threads, u_off, u, b_off, b);
+		return rc ? fail(rc, "mm2c_chain_epilogue_host failed") : 0;
+	}
+	if (total == 0) { for (int64_t k = 1; k <= n_tasks; ++k) u_off[k] = b_off[k] = 0; return 0; }
+	// everything on the GPU: anchors up, DP, epilogue, chains down
+	ThreadCtx *c;
+	if ((rc = get_thread_ctx(&c))) return rc;
+	mm2c_plan_t *pl = mm2c_plan_create(par, n_tasks, h_offsets);
+	if (!pl) return MM2C_E_HIP;
+	const size_t tot = (size_t)total, nt = (size_t)n_tasks;
+	const size_t o_uoff = 0, o_boff = align16((nt + 1) * 8), o_u = align16(o_boff + (nt + 1) * 8), o_b = align16(o_u + tot * 8), out_bytes = o_b + tot * 16;
+	auto body = [&]() -> int {
+		int r;
+		if ((r = grow_device(&c->d_in, &c->cap_in, tot * 16))) return r;
+		if ((r = grow_device(&c->d_out, &c->cap_out, tot * 8))) return r;
+		if ((r = grow_device(&c->d_scratch, &c->cap_scratch, out_bytes))) return r;
+		int32_t *d_f = (int32_t *)c->d_out, *d_p = d_f + tot;
+		char *o = c->d_scratch;
+		HIP_TRY(hipMemcpyAsync(c->d_in, h_anchors + h_offsets[0], tot * 16, hipMemcpyHostToDevice, c->st));
+		if ((r = mm2c_plan_run_device(pl, c->d_in, nullptr, d_f, d_p, c->st))) return r;
+		if ((r = mm2c_plan_chains_device(pl, c->d_in, d_f, d_p, min_cnt, min_sc, (int64_t *)(o + o_uoff), (uint64_t *)(o + o_u),
+		                                 (int64_t *)(o + o_boff), o + o_b, c->st))) return r;
+		HIP_TRY(hipMemcpyAsync(u_off, o + o_uoff, (nt + 1) * 8, hipMemcpyDeviceToHost, c->st));
+		HIP_TRY(hipMemcpyAsync(b_off, o + o_boff, (nt + 1) * 8, hipMemcpyDeviceToHost, c->st));
+		HIP_TRY(hipStreamSynchronize(c->st));
+		if (u_off[nt] > 0) HIP_TRY(hipMemcpyAsync(u, o + o_u, (size_t)u_off[nt] * 8, hipMemcpyDeviceToHost, c->st));
+		if (b_off[nt] > 0) HIP_TRY(hipMemcpyAsync(b, o + o_b, (size_t)b_off[nt] * 16, hipMemcpyDeviceToHost, c->st));
+		HIP_TRY(hipStreamSynchronize(c->st));
+		return 0;
+	};
+	rc = body();
+	mm2c_plan_destroy(pl);
+	G.passes += 1;
 	return rc;
 }
 

@@ -88,54 +88,34 @@ static int cmp_u64(const void *x, const void *y)
 	return a < b ? -1 : a > b;
 }
 
-mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
-                           float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a, int *n_u_, uint64_t **_u,
-                           void *km, int tid)
+/*
+ * The O(n) epilogue of mm_chain_dp (chain.c:106-111, 348-422) on caller-provided storage: v[] from f[]/p[], chain ends, peak
+ * search, sort by score, backtrack without re-using anchors, emission, chains ordered by the x of their first anchor.
+ * f, p: the DP result (read only).  vt: scratch of 2n ints, 8-byte aligned (v[] then t[]).  u_out / b_out: room for n entries
+ * each (a chain has >= 1 anchor).  tmp: scratch for 2n anchors.  Returns the number of chains; *n_b_out = anchors in b_out.
+ */
+static int32_t chain_epilogue(int min_cnt, int min_sc, int64_t n, const mm2c_anchor_t *a, const int32_t *f, const int32_t *p,
+                              int32_t *vt, uint64_t *u_out, mm2c_anchor_t *b_out, mm2c_anchor_t *tmp, int64_t *n_b_out)
 {
-	int32_t *f, *p, *t, *v, n_u, n_v, k;
+	int32_t *v = vt, *t = vt + n, n_u, n_v, k;
 	int64_t i, j;
-	uint64_t *u, *u2, sum_qspan = 0;
-	float avg_qspan_scaled;
-	mm2c_anchor_t *b, *w;
-	mm2c_params_t par;
-
-	if (_u) *_u = 0, *n_u_ = 0;
-	if (n == 0 || a == 0) { xfree(km, a); return 0; }                       /* chain.c:37-41 */
-	f = (int32_t *)xalloc(km, (size_t)n * 4); p = (int32_t *)xalloc(km, (size_t)n * 4);
-	t = (int32_t *)xalloc(km, (size_t)n * 4); v = (int32_t *)xalloc(km, (size_t)n * 4);
-
-	for (i = 0; i < n; ++i) sum_qspan += a[i].y >> 32 & 0xff;                /* chain.c:48-49 */
-	avg_qspan_scaled = (float)(.01 * (float)sum_qspan / n);
-
-	par.max_dist_x = max_dist_x; par.max_dist_y = max_dist_y; par.bw = bw;
-	par.max_skip = max_skip; par.max_iter = max_iter; par.gap_scale = gap_scale;
-	par.is_cdna = is_cdna; par.n_segs = n_segs; par.q_span_override = -1; par.flags = 0;
-	if (mm2c_chain_task_host(&par, n, a, avg_qspan_scaled, f, p, tid) != 0) { /* chain.c:103; errors as chain_hardware.cpp:208-235 */
-		fprintf(stderr, "Error: GPU chaining failed (n = %ld): %s\n", (long)n, mm2c_last_error());
-		exit(EXIT_FAILURE);
-	}
+	uint64_t *u = u_out;
+	*n_b_out = 0;
 	for (i = 0; i < n; ++i)                                                  /* chain.c:106-111 */
 		v[i] = (p[i] >= 0 && v[p[i]] > f[i]) ? v[p[i]] : f[i];
-
 	/* chain ends (chain.c:349-367) */
 	memset(t, 0, (size_t)n * 4);
 	for (i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
-	for (i = 0, n_u = 0; i < n; ++i) if (t[i] == 0 && v[i] >= min_sc) ++n_u;
-	if (n_u == 0) {
-		xfree(km, a); xfree(km, f); xfree(km, p); xfree(km, t); xfree(km, v);
-		return 0;
-	}
-	u = (uint64_t *)xalloc(km, (size_t)n_u * 8);
 	for (i = 0, n_u = 0; i < n; ++i) {
 		if (t[i] != 0 || v[i] < min_sc) continue;
 		for (j = i; j >= 0 && f[j] < v[j]; ) j = p[j];
 		if (j < 0) j = i;
 		u[n_u++] = (uint64_t)f[j] << 32 | (uint64_t)j;
 	}
+	if (n_u == 0) return 0;
 	qsort(u, (size_t)n_u, 8, cmp_u64);                                       /* chain.c:368 */
 	for (i = 0; i < n_u >> 1; ++i) { uint64_t s = u[i]; u[i] = u[n_u - i - 1]; u[n_u - i - 1] = s; }
-
-	/* backtrack (chain.c:375-390) */
+	/* backtrack (chain.c:375-390); v[] is reused as the list of chained anchors */
 	memset(t, 0, (size_t)n * 4);
 	for (i = 0, n_v = 0, k = 0; i < n_u; ++i) {
 		const int32_t n_v0 = n_v, k0 = k, peak = (int32_t)(u[i] >> 32);
@@ -147,28 +127,121 @@ mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip,
 		else if (peak - f[j] >= min_sc) { if (len >= min_cnt) u[k++] = (uint64_t)(peak - f[j]) << 32 | (uint32_t)len; }
 		if (k0 == k) n_v = n_v0;
 	}
-	*n_u_ = n_u = k, *_u = u;
-	xfree(km, f); xfree(km, p); xfree(km, t);
-
-	/* emit (chain.c:397-402) and order chains by first x (chain.c:406-420) */
-	b = (mm2c_anchor_t *)xalloc(km, (size_t)n_v * sizeof(mm2c_anchor_t));
+	n_u = k;
+	if (n_u == 0) return 0;
+	/* emit (chain.c:397-402) into tmp, then order chains by first x (chain.c:406-420) into b_out */
 	for (i = 0, k = 0; i < n_u; ++i) {
 		const int32_t k0 = k, ni = (int32_t)u[i];
-		for (j = 0; j < ni; ++j) b[k++] = a[v[k0 + (ni - j - 1)]];
+		for (j = 0; j < ni; ++j) tmp[k++] = a[v[k0 + (ni - j - 1)]];
 	}
-	xfree(km, v);
-	w = (mm2c_anchor_t *)xalloc(km, (size_t)n_u * sizeof(mm2c_anchor_t));
-	for (i = 0, k = 0; i < n_u; ++i) { w[i].x = b[k].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
-	sort128x(w, (size_t)n_u);
-	u2 = (uint64_t *)xalloc(km, (size_t)n_u * 8);
-	for (i = 0, k = 0; i < n_u; ++i) {
-		const int32_t src = (int32_t)w[i].y, cnt = (int32_t)u[src];
-		u2[i] = u[src];
-		memcpy(&a[k], &b[w[i].y >> 32], (size_t)cnt * sizeof(mm2c_anchor_t));
-		k += cnt;
+	{
+		mm2c_anchor_t *w = tmp + n;                                          /* second half of tmp: one sort record per chain */
+		uint64_t *u2 = (uint64_t *)vt;                                       /* v[] and t[] are dead from here on */
+		int64_t n_b = 0;
+		for (i = 0, k = 0; i < n_u; ++i) { w[i].x = tmp[k].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
+		sort128x(w, (size_t)n_u);
+		for (i = 0; i < n_u; ++i) {
+			const int32_t src = (int32_t)w[i].y, cnt = (int32_t)u[src];
+			u2[i] = u[src];
+			memcpy(&b_out[n_b], &tmp[w[i].y >> 32], (size_t)cnt * sizeof(mm2c_anchor_t));
+			n_b += cnt;
+		}
+		memcpy(u, u2, (size_t)n_u * 8);
+		*n_b_out = n_b;
 	}
-	if (n_u) memcpy(u, u2, (size_t)n_u * 8);
-	if (k) memcpy(b, a, (size_t)k * sizeof(mm2c_anchor_t));
-	xfree(km, a); xfree(km, w); xfree(km, u2);
+	return n_u;
+}
+
+mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
+                           float gap_scale, int is_cdna, int n_segs, int64_t n, mm2c_anchor_t *a, int *n_u_, uint64_t **_u,
+                           void *km, int tid)
+{
+	int32_t *f, *p, *vt, n_u;
+	int64_t i, n_b = 0;
+	uint64_t *u, sum_qspan = 0;
+	float avg_qspan_scaled;
+	mm2c_anchor_t *b, *tmp;
+	mm2c_params_t par;
+
+	if (_u) *_u = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) { xfree(km, a); return 0; }                       /* chain.c:37-41 */
+	f = (int32_t *)xalloc(km, (size_t)n * 4); p = (int32_t *)xalloc(km, (size_t)n * 4);
+	vt = (int32_t *)xalloc(km, (size_t)n * 8);
+
+	for (i = 0; i < n; ++i) sum_qspan += a[i].y >> 32 & 0xff;                /* chain.c:48-49 */
+	avg_qspan_scaled = (float)(.01 * (float)sum_qspan / n);
+
+	par.max_dist_x = max_dist_x; par.max_dist_y = max_dist_y; par.bw = bw;
+	par.max_skip = max_skip; par.max_iter = max_iter; par.gap_scale = gap_scale;
+	par.is_cdna = is_cdna; par.n_segs = n_segs; par.q_span_override = -1; par.flags = 0;
+	if (mm2c_chain_task_host(&par, n, a, avg_qspan_scaled, f, p, tid) != 0) { /* chain.c:103; errors as chain_hardware.cpp:208-235 */
+		fprintf(stderr, "Error: GPU chaining failed (n = %ld): %s\n", (long)n, mm2c_last_error());
+		exit(EXIT_FAILURE);
+	}
+	u = (uint64_t *)xalloc(km, (size_t)n * 8);
+	b = (mm2c_anchor_t *)xalloc(km, (size_t)n * sizeof(mm2c_anchor_t));
+	tmp = (mm2c_anchor_t *)xalloc(km, (size_t)n * 2 * sizeof(mm2c_anchor_t));
+	n_u = chain_epilogue(min_cnt, min_sc, n, a, f, p, vt, u, b, tmp, &n_b);
+	xfree(km, f); xfree(km, p); xfree(km, vt); xfree(km, tmp); xfree(km, a);   /* chain.c:394,421: the callee owns a */
+	if (n_u == 0) { xfree(km, u); xfree(km, b); return 0; }
+	*n_u_ = n_u, *_u = u;
 	return b;
+}
+
+/* ---- the epilogue for a CSR batch on host threads (tasks handed out through an atomic counter, in the style of kt_for,
+ * kthread.c:30-52); compact outputs as mm2c_plan_chains_device ---- */
+#include <pthread.h>
+typedef struct {
+	int min_cnt, min_sc; int64_t n_tasks; const int64_t *off; const mm2c_anchor_t *a; const int32_t *f, *p;
+	int64_t *n_u, *n_b; uint64_t *u; mm2c_anchor_t *b; int64_t next; int64_t max_n;
+} epi_shared_t;
+
+static void *epi_worker(void *vp)
+{
+	epi_shared_t *s = (epi_shared_t *)vp;
+	int32_t *vt = (int32_t *)malloc((size_t)(s->max_n ? s->max_n : 1) * 8);
+	mm2c_anchor_t *tmp = (mm2c_anchor_t *)malloc((size_t)(s->max_n ? s->max_n : 1) * 2 * sizeof(mm2c_anchor_t));
+	for (;;) {
+		const int64_t k = __sync_fetch_and_add(&s->next, 1);
+		int64_t o, n;
+		if (k >= s->n_tasks) break;
+		o = s->off[k] - s->off[0]; n = s->off[k + 1] - s->off[k];
+		s->n_u[k] = 0; s->n_b[k] = 0;
+		if (n) s->n_u[k] = chain_epilogue(s->min_cnt, s->min_sc, n, s->a + s->off[k], s->f + s->off[k], s->p + s->off[k], vt, s->u + o, s->b + o, tmp, &s->n_b[k]);
+	}
+	free(vt); free(tmp);
+	return 0;
+}
+
+int mm2c_chain_epilogue_host(int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                             const int32_t *h_f, const int32_t *h_p, int n_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
+                             mm2c_anchor_t *b)
+{
+	epi_shared_t s;
+	pthread_t *th;
+	int64_t k, total, au = 0, ab = 0;
+	int i;
+	if (n_tasks < 0 || !u_off || !b_off) return MM2C_E_ARG;
+	u_off[0] = b_off[0] = 0;
+	if (n_tasks == 0) return 0;
+	if (!h_offsets || !u || !b) return MM2C_E_ARG;
+	total = h_offsets[n_tasks] - h_offsets[0];
+	s.min_cnt = min_cnt; s.min_sc = min_sc; s.n_tasks = n_tasks; s.off = h_offsets; s.a = h_anchors; s.f = h_f; s.p = h_p;
+	s.n_u = u_off + 1; s.n_b = b_off + 1; s.next = 0; s.max_n = 0;                 /* counts first, turned into offsets below */
+	s.u = (uint64_t *)malloc((size_t)(total ? total : 1) * 8);
+	s.b = (mm2c_anchor_t *)malloc((size_t)(total ? total : 1) * sizeof(mm2c_anchor_t));
+	for (k = 0; k < n_tasks; ++k) if (h_offsets[k + 1] - h_offsets[k] > s.max_n) s.max_n = h_offsets[k + 1] - h_offsets[k];
+	if (n_threads < 1) n_threads = 1;
+	th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+	for (i = 0; i < n_threads; ++i) pthread_create(&th[i], 0, epi_worker, &s);
+	for (i = 0; i < n_threads; ++i) pthread_join(th[i], 0);
+	for (k = 0; k < n_tasks; ++k) {                                               /* compact */
+		const int64_t o = h_offsets[k] - h_offsets[0], nu = u_off[k + 1], nb = b_off[k + 1];
+		memcpy(u + au, s.u + o, (size_t)nu * 8);
+		memcpy(b + ab, s.b + o, (size_t)nb * sizeof(mm2c_anchor_t));
+		au += nu; ab += nb;
+		u_off[k + 1] = au; b_off[k + 1] = ab;
+	}
+	free(th); free(s.u); free(s.b);
+	return 0;
 }

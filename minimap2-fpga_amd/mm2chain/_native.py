@@ -49,6 +49,13 @@ C_SYMBOLS = {
     "mm2c_chain_task_host": (C.c_int, [C.POINTER(Params), C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
     "mm_chain_dp": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                  C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
+    "mm2c_plan_chains_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_plan_last_epilogue_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mm2c_chain_epilogue_host": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_mm_chain_dp_batch_host": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_get_stats": (None, [C.POINTER(Stats)]),
     "mm2c_stream_write": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_stream_read": (C.c_int, [C.c_char_p, C.POINTER(Stream)]),

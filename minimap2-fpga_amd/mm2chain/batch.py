@@ -87,6 +87,28 @@ class ChainPlan:
                 "mm2c_plan_predict_device")
         return ns, ts, tt
 
+    def chains(self, anchors: torch.Tensor, f: torch.Tensor, p: torch.Tensor, min_cnt: int, min_sc: int, stream=None):
+        """the epilogue of mm_chain_dp (chain.c:106-111,348-422) on the GPU, after run() on the same stream.  Returns device
+        tensors (u_off int64 [n_tasks+1], u int64 [total], b_off int64 [n_tasks+1], b int64 [total, 2]); only the first
+        u_off[-1] / b_off[-1] entries of u / b are defined."""
+        assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.numel() == 2 * self.total
+        assert f.dtype == torch.int32 and p.dtype == torch.int32 and f.numel() == self.total and p.numel() == self.total
+        dev = anchors.device
+        u_off = torch.empty(self.n_tasks + 1, dtype=torch.int64, device=dev)
+        b_off = torch.empty(self.n_tasks + 1, dtype=torch.int64, device=dev)
+        u = torch.empty(max(self.total, 1), dtype=torch.int64, device=dev)
+        b = torch.empty((max(self.total, 1), 2), dtype=torch.int64, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.mm2c_plan_chains_device(self.handle, anchors.data_ptr(), f.data_ptr(), p.data_ptr(), min_cnt, min_sc,
+                                                 u_off.data_ptr(), u.data_ptr(), b_off.data_ptr(), b.data_ptr(), st),
+                "mm2c_plan_chains_device")
+        return u_off, u, b_off, b
+
+    def last_epilogue_ms(self):
+        ms = C.c_float(0)
+        N.check(self.lib.mm2c_plan_last_epilogue_ms(self.handle, C.byref(ms)), "mm2c_plan_last_epilogue_ms")
+        return ms.value
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")
@@ -177,6 +199,42 @@ def chain_task(params: Params, anchors, avg_qspan_scaled, tid=0):
     N.check(lib.mm2c_chain_task_host(C.byref(params), n, _np_ptr(a), float(avg_qspan_scaled), _np_ptr(f), _np_ptr(p), tid),
             "mm2c_chain_task_host")
     return f, p
+
+
+def _split_chains(n_tasks, u_off, u, b_off, b):
+    return [(u[u_off[k]:u_off[k + 1]].copy(), b[b_off[k]:b_off[k + 1]].copy()) for k in range(n_tasks)]
+
+
+def mm_chain_dp_batch(params: Params, min_cnt, min_sc, offsets, anchors, epilogue_threads=0):
+    """mm2c_mm_chain_dp_batch_host: per-task list [(u uint64 [n_u], b uint64 [n_b, 2]), ...]; epilogue_threads == 0 runs the
+    epilogue on the GPU, > 0 on that many host threads"""
+    lib = N.load()
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    n_tasks, total = off.size - 1, int(off[-1] - off[0])
+    if off[-1] > a.shape[0] or off[0] < 0:
+        raise ValueError("offsets reach beyond the anchor array")
+    u_off = np.zeros(n_tasks + 1, np.int64); b_off = np.zeros(n_tasks + 1, np.int64)
+    u = np.zeros(max(total, 1), np.uint64); b = np.zeros((max(total, 1), 2), np.uint64)
+    N.check(lib.mm2c_mm_chain_dp_batch_host(C.byref(params), min_cnt, min_sc, n_tasks, _np_ptr(off), _np_ptr(a), epilogue_threads,
+                                            _np_ptr(u_off), _np_ptr(u), _np_ptr(b_off), _np_ptr(b)), "mm2c_mm_chain_dp_batch_host")
+    return _split_chains(n_tasks, u_off, u, b_off, b)
+
+
+def chain_epilogue_host(min_cnt, min_sc, offsets, anchors, f, p, n_threads=4):
+    """mm2c_chain_epilogue_host: the epilogue on host threads from f[] / p[] (no GPU involved)"""
+    lib = N.load()
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    f = np.ascontiguousarray(f, dtype=np.int32); p = np.ascontiguousarray(p, dtype=np.int32)
+    n_tasks, total = off.size - 1, int(off[-1] - off[0])
+    if off[-1] > a.shape[0] or off[0] < 0 or f.size < off[-1] or p.size < off[-1]:
+        raise ValueError("offsets reach beyond the arrays")
+    u_off = np.zeros(n_tasks + 1, np.int64); b_off = np.zeros(n_tasks + 1, np.int64)
+    u = np.zeros(max(total, 1), np.uint64); b = np.zeros((max(total, 1), 2), np.uint64)
+    N.check(lib.mm2c_chain_epilogue_host(min_cnt, min_sc, n_tasks, _np_ptr(off), _np_ptr(a), _np_ptr(f), _np_ptr(p), n_threads,
+                                         _np_ptr(u_off), _np_ptr(u), _np_ptr(b_off), _np_ptr(b)), "mm2c_chain_epilogue_host")
+    return _split_chains(n_tasks, u_off, u, b_off, b)
 
 
 def hardware_init(buf_size=0, binary_name=b""):

@@ -202,3 +202,21 @@ def test_golden_fixtures():
         off, a = z["offsets"], z["anchors"]
         f, p, _ = ob.chain_batch(par, off, a, 2)
         assert np.array_equal(f, z["f"]) and np.array_equal(p, z["p"]), name
+
+
+def test_host_epilogue_of_the_library_equals_the_oracle_mm_chain_dp():
+    """mm2c_chain_epilogue_host (library, host threads, no GPU) on the oracle's f[] / p[] against the oracle's mm_chain_dp"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minimap2-fpga_amd"))
+    import mm2chain
+    from mm2chain import params, synth
+    P = params.map_ont()
+    for profile, seed in (("mixed", 3), ("dense", 4), ("sparse", 5)):
+        off, a = synth.make_stream(profile, 12, (1, 3000), seed=seed)
+        off = off.numpy(); a = a.numpy().view(np.uint64)
+        f, p, _ = ob.chain_batch(P, off, a, n_threads=4)
+        for min_cnt, min_sc in ((3, 40), (1, 0)):
+            res = mm2chain.chain_epilogue_host(min_cnt, min_sc, off, a, f, p, n_threads=3)
+            for k in range(off.size - 1):
+                u_ref, b_ref = ob.mm_chain_dp(P, min_cnt, min_sc, a[off[k]:off[k + 1]])
+                assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), (profile, min_cnt, k)

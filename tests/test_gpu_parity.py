@@ -295,6 +295,145 @@ def test_host_paths_and_mm_chain_dp():
     assert u.size == 0 and b.size == 0
 
 
+def _mixed_batch_with_gaps():
+    """40 mixed reads, 10 sparse reads without any chain and three empty tasks in between"""
+    off0, a0 = _stream("mixed", 40, (1, 4000), seed=77)
+    off1, a1 = _stream("sparse", 10, (1, 30), seed=78)
+    sizes = np.concatenate([np.diff(off0)[:20], [0], np.diff(off1), [0, 0], np.diff(off0)[20:]])
+    a = np.concatenate([a0[:off0[20]], a1, a0[off0[20]:]])
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64), a
+
+
+def _assert_chains(res, P, min_cnt, min_sc, off, a, what):
+    n_chains = 0
+    for k, (u, b) in enumerate(res):
+        u_ref, b_ref = ob.mm_chain_dp(P, min_cnt, min_sc, a[off[k]:off[k + 1]])
+        assert np.array_equal(u, u_ref), f"{what}: task {k}: u differs ({u.size} vs {u_ref.size} chains)"
+        assert np.array_equal(b, b_ref), f"{what}: task {k}: b differs"
+        n_chains += u.size
+    return n_chains
+
+
+@pytest.mark.parametrize("epilogue_threads", [0, 1, 5])
+def test_batched_mm_chain_dp_equals_task_by_task_calls(epilogue_threads):
+    """mm2c_mm_chain_dp_batch_host (0: DP + epilogue on the GPU; > 0: epilogue on host threads) against the oracle's
+    mm_chain_dp per task; the batch holds empty tasks, tasks without any chain and tasks of several thousand anchors"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _mixed_batch_with_gaps()
+    res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=epilogue_threads)
+    assert len(res) == off.size - 1
+    assert _assert_chains(res, P, 3, 40, off, a, f"epilogue_threads={epilogue_threads}") > 40
+
+
+@pytest.mark.parametrize("min_cnt,min_sc", [(1, 0), (1, 40), (2, 15), (3, 100), (5, 1000), (0, -5)])
+def test_device_epilogue_filter_corners(min_cnt, min_sc):
+    """chain.c:385-388 with thresholds that keep one-anchor chains (incl. chains that keep only an already taken peak) or
+    drop nearly everything"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 12, (50, 2500), seed=91)
+    res = mm2chain.mm_chain_dp_batch(P, min_cnt, min_sc, off, a, epilogue_threads=0)
+    _assert_chains(res, P, min_cnt, min_sc, off, a, f"min_cnt={min_cnt} min_sc={min_sc}")
+
+
+def test_device_epilogue_on_dense_and_colinear_streams():
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    for profile, seed in (("dense", 5), ("colinear", 6), ("sparse", 7)):
+        off, a = _stream(profile, 6, (1000, 5000), seed=seed)
+        res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
+        _assert_chains(res, P, 3, 40, off, a, profile)
+
+
+def _tandem_task(n_groups, copies, seed):
+    """n_groups loci; at each, `copies` chains of 4 anchors that share their reference positions (a tandem repeat in the query:
+    same x, query positions max_dist_y apart), so that many chains start at equal x"""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for g in range(n_groups):
+        r0 = 100000 + g * 20000
+        for c in range(int(copies[g % len(copies)])):
+            q0 = 1000 + c * 6000 + int(rng.integers(0, 50))
+            for s in range(4):
+                rows.append(mk_anchor(0, 1, r0 + 20 * s, q0 + 20 * s))
+    return pack(rows)
+
+
+def test_device_epilogue_equal_first_x_replays_the_reference_sort():
+    """more than 64 chains with equal first-anchor x: the order is that of radix_sort_128x's passes (ksort.h:101-151), which
+    is not stable; also <= 64 chains with ties (insertion sort, stable) and > 64 chains without ties"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    tasks = [_tandem_task(60, [3, 2, 1, 4], 1), _tandem_task(12, [3, 2], 2), _tandem_task(90, [1], 3), _tandem_task(150, [2, 5, 1], 4)]
+    off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tasks])]).astype(np.int64)
+    a = np.concatenate(tasks)
+    res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
+    _assert_chains(res, P, 3, 40, off, a, "tandem")
+    assert res[0][0].size > 64 and res[3][0].size > 64
+    x_first = [int(res[0][1][i, 0]) for i in np.concatenate([[0], np.cumsum(res[0][0] & np.uint64(0xffffffff))[:-1]]).astype(np.int64)]
+    assert len(set(x_first)) < len(x_first), "the test must contain chains that start at equal x"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_epilogue_on_arbitrary_forests(seed):
+    """the epilogue kernels on f[] / p[] that no DP produced (random forests: long paths, bushy trees, deep in-chunk chains,
+    equal scores) against the host epilogue (which test_cpu_oracle pins to the oracle); device-resident plan API"""
+    import mm2chain
+    from mm2chain import params
+    rng = np.random.default_rng(1000 + seed)
+    P = params.map_ont()
+    sizes = [1, 2, 63, 64, 65, 130, 1000, 3000, int(rng.integers(1, 5000)), 0, 4097]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    total = int(off[-1])
+    a = np.zeros((total, 2), np.uint64)
+    f = np.zeros(total, np.int32); p = np.full(total, -1, np.int32)
+    for k, n in enumerate(sizes):
+        if n == 0:
+            continue
+        o = int(off[k])
+        x = np.sort(rng.integers(0, 50 if seed % 2 else 1 << 30, n).astype(np.uint64)) + (np.uint64(k) << np.uint64(32))
+        a[o:o + n, 0] = x
+        a[o:o + n, 1] = (np.uint64(15) << np.uint64(32)) | rng.integers(0, 1 << 20, n).astype(np.uint64)
+        idx = np.arange(n)
+        style = (seed + k) % 4
+        if style == 0:      # mostly i-1 (long paths), some roots
+            par = np.where(rng.random(n) < 0.97, idx - 1, -1)
+        elif style == 1:    # bushy: parent anywhere before i
+            par = np.where(rng.random(n) < 0.8, (rng.random(n) * idx).astype(np.int64) - (idx == 0), -1)
+        elif style == 2:    # parents a short hop back (deep chains inside a chunk, several children per node)
+            par = idx - 1 - rng.integers(0, 4, n)
+        else:               # mixture with far parents
+            par = np.where(rng.random(n) < 0.5, idx - 1, idx - 1 - rng.integers(0, 200, n))
+        par = np.where(par < 0, -1, par)
+        p[o:o + n] = par
+        ff = np.zeros(n, np.int64)
+        gain = rng.integers(-30, 25 if seed % 3 else 16, n)
+        for i in range(n):
+            ff[i] = max(15, (ff[par[i]] if par[i] >= 0 else 0) + 15 + gain[i]) if seed % 3 != 2 else int(rng.integers(0, 60))
+        f[o:o + n] = ff
+    ref = mm2chain.chain_epilogue_host(2, 30, off, a, f, p, n_threads=4)
+    plan = mm2chain.ChainPlan(P, off)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda(); d_f = torch.from_numpy(f).cuda(); d_p = torch.from_numpy(p).cuda()
+    u_off, u, b_off, b = plan.chains(d_a, d_f, d_p, 2, 30)
+    torch.cuda.synchronize()
+    u_off = u_off.cpu().numpy(); b_off = b_off.cpu().numpy()
+    u = u.cpu().numpy().view(np.uint64); b = b.cpu().numpy().view(np.uint64)
+    assert plan.last_epilogue_ms() > 0
+    plan.close()
+    n_chains = 0
+    for k in range(len(sizes)):
+        uk, bk = u[u_off[k]:u_off[k + 1]], b[b_off[k]:b_off[k + 1]]
+        assert np.array_equal(uk, ref[k][0]), f"task {k} (n={sizes[k]}): u differs ({uk.size} vs {ref[k][0].size})"
+        assert np.array_equal(bk, ref[k][1]), f"task {k} (n={sizes[k]}): b differs"
+        n_chains += uk.size
+    assert n_chains > 10
+
+
 def test_real_anchor_lists_from_the_reference_test_data():
     """anchors that reach mm_chain_dp for test/MT-human.fa vs MT-orang.fa and t-inv.fa vs q-inv.fa (dumped through the
     reference's own host objects, tests/golden/make_ref_anchor_fixtures.py): f/p through the kernel, chains through mm_chain_dp"""
