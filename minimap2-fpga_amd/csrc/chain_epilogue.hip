@@ -40,6 +40,18 @@ __device__ __forceinline__ int lanes_before(uint64_t m)
 	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// A task is handled by one workgroup (one wave), so every atomic and every ordering below is workgroup scope: the atomics run in the
+// XCD's own L2 and nothing is written back or invalidated.  (Agent scope, the HIP default, sends them past the L2 -- the L2s of the
+// eight XCDs are not coherent with each other -- and made these kernels 3x slower.)
+__device__ __forceinline__ void wg_min(int *addr, int val)
+{
+	(void)__hip_atomic_fetch_min(addr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int wg_load(const int *addr)   // a load that sees the workgroup's L2 atomics
+{
+	return __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int wave_sum(int x)
 {
 	for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -52,48 +64,100 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane)
 	return x;
 }
 
+// The three chunked passes below walk a task in chunks of W = 64*K anchors (K per lane), because the passes are sequential from chunk
+// to chunk (a chunk needs the finished values of the chunks before it) and every step costs a global-memory round trip: wide
+// chunks mean few steps.  Links that stay inside a chunk are resolved by pointer jumping through LDS (log2 W rounds at most).
+constexpr int K = 4, W = 64 * K;
+
 // ---- kernel A: v[], child marks, chain ends -> unsorted keys (chain.c:106-111, 349-367) -------------------------------
 __global__ __launch_bounds__(64) void epi_ends(EpiArgs A)
 {
+	__shared__ int s_cur[W], s_ptr[W];
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
 	const int lane = (int)threadIdx.x;
-	const int32_t *f = A.d_f + base, *p = A.d_p + base;
-	int32_t *v = A.v + base, *mark = A.own + base;
+	const int32_t *__restrict__ f = A.d_f + base, *__restrict__ p = A.d_p + base;
+	int32_t *v = A.v + base, *mark = A.own + base, *peak = A.ctop + base;
 	if (lane == 0) A.seg_begin[task] = (uint32_t)base;
 	for (int i = lane; i < n; i += 64) mark[i] = 0;
 	__syncthreads();
-	for (int c0 = 0; c0 < n; c0 += 64) {
-		const int i = c0 + lane;
-		const bool valid = i < n;
-		const int pi = valid ? p[i] : -1;
-		int cur = valid ? f[i] : INT_MIN, ptr = pi;
-		if (pi >= 0) mark[pi] = 1;                                            // chain.c:350
-		if (ptr >= 0 && ptr < c0) { cur = max(cur, v[ptr]); ptr = -1; }       // parent in an earlier chunk: final already
-		while (__ballot(ptr >= c0)) {                                         // parents inside the chunk: pointer jumping
-			const int src = ptr >= c0 ? ptr - c0 : lane;
-			const int oc = __shfl(cur, src), op = __shfl(ptr, src);
-			if (ptr >= c0) { cur = max(cur, oc); ptr = op; }
+	if (A.debug_phases == 1) { if (lane == 0) A.seg_end1[task] = (uint32_t)base; return; }
+	for (int c0 = 0; c0 < n; c0 += W) {
+		int cur[K], ptr[K], fi[K], pi[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			pi[k] = ptr[k] = i < n ? p[i] : -1;
+			fi[k] = cur[k] = i < n ? f[i] : INT_MIN;
 		}
-		if (valid) v[i] = cur;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (ptr[k] >= 0) mark[ptr[k]] = 1;                                     // chain.c:350
+			if (ptr[k] >= 0 && ptr[k] < c0) { cur[k] = max(cur[k], v[ptr[k]]); ptr[k] = -1; }   // parent in an earlier chunk: final already
+		}
+		for (;;) {                                                               // parents inside the chunk: pointer jumping
+			bool open = false;
+#pragma unroll
+			for (int k = 0; k < K; ++k) open |= ptr[k] >= c0;
+			if (!__ballot(open)) break;
+#pragma unroll
+			for (int k = 0; k < K; ++k) { s_cur[lane + 64 * k] = cur[k]; s_ptr[lane + 64 * k] = ptr[k]; }
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				if (ptr[k] >= c0) { const int q = ptr[k] - c0; cur[k] = max(cur[k], s_cur[q]); ptr[k] = s_ptr[q]; }
+			__syncthreads();
+		}
+		// peak[i] = the nearest anchor j on the path from i towards the root with f[j] >= v[j] (what the walk of chain.c:360-361
+		// finds; v > f implies a parent, so the walk never falls off the root): same recurrence, same jumping
+		int pk[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			if (fi[k] >= cur[k]) { pk[k] = i; ptr[k] = -1; }
+			else if (pi[k] < c0) { pk[k] = peak[pi[k]]; ptr[k] = -1; }
+			else { pk[k] = -1; ptr[k] = pi[k]; }
+		}
+		for (;;) {
+			bool open = false;
+#pragma unroll
+			for (int k = 0; k < K; ++k) open |= ptr[k] >= c0;
+			if (!__ballot(open)) break;
+#pragma unroll
+			for (int k = 0; k < K; ++k) { s_cur[lane + 64 * k] = pk[k]; s_ptr[lane + 64 * k] = ptr[k]; }
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				if (ptr[k] >= c0) { const int q = ptr[k] - c0; pk[k] = s_cur[q]; ptr[k] = s_ptr[q]; }
+			__syncthreads();
+		}
+#pragma unroll
+		for (int k = 0; k < K; ++k) { const int i = c0 + lane + 64 * k; if (i < n) { v[i] = cur[k]; peak[i] = pk[k]; } }
 		__syncthreads();
 	}
-	uint64_t *keys = A.key0 + base;
+	if (A.debug_phases == 2) { if (lane == 0) A.seg_end1[task] = (uint32_t)base; return; }
+	uint64_t *__restrict__ keys = A.key0 + base;
 	int cnt = 0;
-	for (int c0 = 0; c0 < n; c0 += 64) {
-		const int i = c0 + lane;
-		const bool is_end = i < n && mark[i] == 0 && v[i] >= A.min_sc;        // chain.c:352
-		uint64_t key = 0;
-		if (is_end) {
-			int j = i;
-			while (j >= 0 && f[j] < v[j]) j = p[j];                           // chain.c:360-361
-			if (j < 0) j = i;
-			key = (uint64_t)(uint32_t)f[j] << 32 | (uint32_t)j;
+	for (int c0 = 0; c0 < n; c0 += W) {
+		bool is_end[K];
+		int pk[K], fpk[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			is_end[k] = i < n && mark[i] == 0 && v[i] >= A.min_sc;              // chain.c:352
+			pk[k] = is_end[k] ? peak[i] : 0;
 		}
-		const uint64_t m = __ballot(is_end);
-		if (is_end) keys[cnt + lanes_before(m)] = key;
-		cnt += __popcll(m);
+#pragma unroll
+		for (int k = 0; k < K; ++k) fpk[k] = is_end[k] ? f[pk[k]] : 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			if (i < n) mark[i] = NONE;                                         // from here on: the chain that takes the anchor (kernel B)
+			const uint64_t m = __ballot(is_end[k]);
+			if (is_end[k]) keys[cnt + lanes_before(m)] = (uint64_t)(uint32_t)fpk[k] << 32 | (uint32_t)pk[k];
+			cnt += __popcll(m);
+		}
 	}
 	if (lane == 0) A.seg_end1[task] = (uint32_t)(base + cnt);
 }
@@ -101,63 +165,98 @@ __global__ __launch_bounds__(64) void epi_ends(EpiArgs A)
 // ---- kernel B: owners, depths, per-chain length / score / filter (chain.c:375-390) ----------------------------------
 __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 {
-	__shared__ int s_own[64];
+	__shared__ int s_val[W], s_ptr[W];
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
 	const int lane = (int)threadIdx.x;
 	const int nu = (int)(A.seg_end1[task] - (uint32_t)base);
-	const int32_t *f = A.d_f + base, *p = A.d_p + base;
+	const int32_t *__restrict__ f = A.d_f + base, *__restrict__ p = A.d_p + base;
 	int32_t *own = A.own + base, *dep = A.v + base, *ctop = A.ctop + base, *rk2kk = A.rk2kk + base, *val0 = A.val0 + base;
 	const uint64_t *us = A.key1 + base;
 	uint64_t *u2 = A.u2 + base, *rkey = A.key0 + base;
 
-	for (int i = lane; i < n; i += 64) own[i] = NONE;
+	for (int r = lane; r < nu; r += 64) wg_min(&own[(int32_t)us[r]], r);       // own[] is NONE on entry; a peak listed twice belongs to the first listing
 	__syncthreads();
-	for (int r = lane; r < nu; r += 64) atomicMin(&own[(int32_t)us[r]], r);       // a peak listed twice belongs to the first listing
-	__threadfence();
-	__syncthreads();
+	if (A.debug_phases == 1) { if (lane == 0) { A.seg_end2[task] = (uint32_t)base; A.cnt_u[task] = 0; A.cnt_b[task] = 0; } return; }
 	// owner(x) = min over the subtree of x: children have larger indices, so chunks go from the end to the front
-	for (int c0 = n > 0 ? (n - 1) & ~63 : -64; c0 >= 0; c0 -= 64) {
-		const int i = c0 + lane;
-		const bool valid = i < n;
-		const int pi = valid ? p[i] : -1;
-		s_own[lane] = valid ? __hip_atomic_load(&own[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;   // sees the atomics of later chunks
-		int up = pi >= c0 ? pi - c0 : -1;                                         // 2^t-th ancestor, while it is inside the chunk
+	for (int c0 = n > 0 ? (n - 1) / W * W : -W; c0 >= 0; c0 -= W) {
+		int pi[K], up[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			pi[k] = i < n ? p[i] : -1;
+			s_val[lane + 64 * k] = i < n ? wg_load(&own[i]) : NONE;   // sees the atomics of later chunks
+			up[k] = pi[k] >= c0 ? pi[k] - c0 : -1;                                  // 2^t-th ancestor, while it is inside the chunk
+		}
 		__syncthreads();
-		while (__ballot(up >= 0)) {
-			const int acc = s_own[lane];
-			if (up >= 0 && acc != NONE) atomicMin(&s_own[up], acc);
-			const int nup = __shfl(up, up >= 0 ? up : lane);
-			up = up >= 0 ? nup : -1;
+		for (;;) {
+			bool open = false;
+#pragma unroll
+			for (int k = 0; k < K; ++k) open |= up[k] >= 0;
+			if (!__ballot(open)) break;
+			int acc[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) { acc[k] = s_val[lane + 64 * k]; s_ptr[lane + 64 * k] = up[k]; }
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				if (up[k] >= 0) { if (acc[k] != NONE) atomicMin(&s_val[up[k]], acc[k]); up[k] = s_ptr[up[k]]; }
 			__syncthreads();
 		}
-		const int fin = s_own[lane];
-		if (valid) {
-			own[i] = fin;
-			if (pi >= 0 && pi < c0 && fin != NONE) atomicMin(&own[pi], fin);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			if (i < n) {
+				const int fin = s_val[lane + 64 * k];
+				own[i] = fin;
+				if (pi[k] >= 0 && pi[k] < c0 && fin != NONE) wg_min(&own[pi[k]], fin);
+			}
 		}
 		__syncthreads();
 	}
-	__threadfence();
+	if (A.debug_phases == 2) { if (lane == 0) { A.seg_end2[task] = (uint32_t)base; A.cnt_u[task] = 0; A.cnt_b[task] = 0; } return; }
 	// depth inside the owner path (0 = top) and the top of every path
-	for (int c0 = 0; c0 < n; c0 += 64) {
-		const int i = c0 + lane;
-		const bool valid = i < n;
-		const int o = valid ? own[i] : NONE, pi = valid ? p[i] : -1;
-		const bool claimed = o != NONE;
-		const bool link = claimed && pi >= 0 && own[pi] == o;
-		int d = 0, ptr = -1;
-		if (link) { if (pi < c0) d = dep[pi] + 1; else { d = 1; ptr = pi; } }
-		while (__ballot(ptr >= c0)) {
-			const int src = ptr >= c0 ? ptr - c0 : lane;
-			const int od = __shfl(d, src), op = __shfl(ptr, src);
-			if (ptr >= c0) { d += od; ptr = op; }
+	for (int c0 = 0; c0 < n; c0 += W) {
+		int o[K], pi[K], d[K], ptr[K];
+		bool claimed[K], link[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			o[k] = i < n ? wg_load(&own[i]) : NONE; pi[k] = i < n ? p[i] : -1;
 		}
-		if (valid) dep[i] = d;
-		if (claimed && !link) ctop[o] = i;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			claimed[k] = o[k] != NONE;
+			link[k] = claimed[k] && pi[k] >= 0 && wg_load(&own[pi[k]]) == o[k];
+		}
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			d[k] = 0; ptr[k] = -1;
+			if (link[k]) { if (pi[k] < c0) d[k] = dep[pi[k]] + 1; else { d[k] = 1; ptr[k] = pi[k]; } }
+		}
+		for (;;) {
+			bool open = false;
+#pragma unroll
+			for (int k = 0; k < K; ++k) open |= ptr[k] >= c0;
+			if (!__ballot(open)) break;
+#pragma unroll
+			for (int k = 0; k < K; ++k) { s_val[lane + 64 * k] = d[k]; s_ptr[lane + 64 * k] = ptr[k]; }
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				if (ptr[k] >= c0) { const int q = ptr[k] - c0; d[k] += s_val[q]; ptr[k] = s_ptr[q]; }
+			__syncthreads();
+		}
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = c0 + lane + 64 * k;
+			if (i < n) dep[i] = d[k];
+			if (claimed[k] && !link[k]) ctop[o[k]] = i;
+		}
 		__syncthreads();
 	}
+	if (A.debug_phases == 3) { if (lane == 0) { A.seg_end2[task] = (uint32_t)base; A.cnt_u[task] = 0; A.cnt_b[task] = 0; } return; }
 	// one lane per chain, in rank order (chain.c:377-389)
 	int kept = 0, n_b = 0;
 	for (int r0 = 0; r0 < nu; r0 += 64) {
@@ -168,7 +267,7 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 		if (valid) {
 			const uint64_t key = us[r];
 			const int j = (int32_t)key, peak = (int32_t)(key >> 32);
-			const bool mine = own[j] == r;
+			const bool mine = wg_load(&own[j]) == r;
 			len = mine ? dep[j] + 1 : 1;
 			top = mine ? ctop[r] : j;
 			const int stop = p[top];
@@ -260,10 +359,111 @@ __device__ void flag_sort_one_lane(uint64_t *x, int32_t *c, int n, int32_t *stac
 	}
 }
 
+// ---- kernel T: tasks with more than 64 chains and equal first-x values: the order radix_sort_128x leaves (chain.c:411) ----
+// Records live in LDS.  Per pass (ksort.h:108-139): histogram and bucket bounds in parallel, the cycle-leader distribution on one
+// lane (its result depends on the order of the swaps), the insertion sorts of the sub-buckets (stable, ksort.h:89-99) as a parallel
+// stable rank sort.  A pass whose records all share the digit moves nothing and hands the whole range to the next byte, so the
+// passes down to the highest byte in which the records differ are skipped.
+constexpr int TS_MAX = 512;
+
+__global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
+{
+	__shared__ uint64_t s_x[TS_MAX], s_tx[TS_MAX];
+	__shared__ int s_c[TS_MAX], s_tc[TS_MAX], s_cur[256], s_lo[256], s_hi[256], s_stack[3 * 16], s_sp;
+	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	const int64_t base = A.d_off[task];
+	const int lane = (int)threadIdx.x;
+	const int nk = (int)(A.seg_end2[task] - (uint32_t)base);
+	if (nk <= 64) return;                                                        // insertion sort only: stable (ksort.h:141-143)
+	uint64_t *sx = A.rkey1 + base;
+	int32_t *ord = A.val1 + base;
+	bool tie = false;
+	for (int i = lane; i + 1 < nk; i += 64) tie |= sx[i] == sx[i + 1];
+	if (!__ballot(tie)) return;                                                  // distinct keys: the order is unique
+	if (nk > TS_MAX) {                                                           // does not fit the LDS: replay on one lane in global memory
+		__syncthreads();
+		for (int i = lane; i < nk; i += 64) { sx[i] = A.key0[base + i]; ord[i] = i; }
+		__syncthreads();
+		if (lane == 0) flag_sort_one_lane(sx, ord, nk, A.dest + base, s_cur, s_lo, s_hi);
+		return;
+	}
+	for (int i = lane; i < nk; i += 64) { s_x[i] = A.key0[base + i]; s_c[i] = i; }   // rank order, as chain.c:407-410 fills w[]
+	if (lane == 0) { s_stack[0] = 0; s_stack[1] = nk; s_stack[2] = 56; s_sp = 1; }
+	for (;;) {
+		__syncthreads();
+		const int sp = s_sp;
+		if (sp == 0) break;
+		const int lo = s_stack[3 * sp - 3], hi = s_stack[3 * sp - 2];
+		int shift = s_stack[3 * sp - 1];
+		__syncthreads();
+		if (lane == 0) s_sp = sp - 1;
+		const uint64_t x0 = s_x[lo];
+		uint64_t diff = 0;
+		for (int q = lo + lane; q < hi; q += 64) diff |= s_x[q] ^ x0;
+		for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
+		if (shift < 56) diff &= (1ull << (shift + 8)) - 1;
+		if (diff == 0) continue;                                                 // equal from this byte down: every later pass is a no-op
+		shift = (63 - __clzll(diff)) & ~7;
+		for (int d = lane; d < 256; d += 64) s_cur[d] = 0;
+		__syncthreads();
+		for (int q = lo + lane; q < hi; q += 64) atomicAdd(&s_cur[(int)(s_x[q] >> shift) & 255], 1);
+		__syncthreads();
+		{
+			int h[4], sum = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { h[k] = s_cur[4 * lane + k]; sum += h[k]; }
+			int at = lo + wave_incl_scan(sum, lane) - sum;
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; s_cur[4 * lane + k] = at; at += h[k]; s_hi[4 * lane + k] = at; }
+		}
+		__syncthreads();
+		if (lane == 0) {                                                         // ksort.h:117-131
+			for (int d = 0; d < 256; ) {
+				const int bl = s_cur[d];
+				if (bl == s_hi[d]) { ++d; continue; }
+				int dst = (int)(s_x[bl] >> shift) & 255;
+				if (dst == d) { s_cur[d] = bl + 1; continue; }
+				uint64_t hx = s_x[bl]; int hc = s_c[bl];
+				do {
+					const int at = s_cur[dst]++;
+					const uint64_t nx = s_x[at]; const int nc = s_c[at];
+					s_x[at] = hx; s_c[at] = hc; hx = nx; hc = nc;
+					dst = (int)(hx >> shift) & 255;
+				} while (dst != d);
+				s_x[s_cur[d]] = hx; s_c[s_cur[d]] = hc; ++s_cur[d];
+			}
+		}
+		__syncthreads();
+		if (shift == 0) continue;                                                // ksort.h:132
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int d = 4 * lane + k;
+			if (s_hi[d] - s_lo[d] > 64) {
+				const int slot = atomicAdd(&s_sp, 1);
+				s_stack[3 * slot] = s_lo[d]; s_stack[3 * slot + 1] = s_hi[d]; s_stack[3 * slot + 2] = shift - 8;
+			}
+		}
+		for (int q = lo + lane; q < hi; q += 64) {                               // sub-buckets of 2..64 records: stable sort on x
+			const uint64_t xq = s_x[q];
+			const int d = (int)(xq >> shift) & 255, bl = s_lo[d], bh = s_hi[d];
+			int at = q;
+			if (bh - bl > 1 && bh - bl <= 64) {
+				int rank = 0;
+				for (int e = bl; e < bh; ++e) { const uint64_t xe = s_x[e]; rank += (xe < xq) || (xe == xq && e < q); }
+				at = bl + rank;
+			}
+			s_tx[at] = xq; s_tc[at] = s_c[q];
+		}
+		__syncthreads();
+		for (int q = lo + lane; q < hi; q += 64) { s_x[q] = s_tx[q]; s_c[q] = s_tc[q]; }
+	}
+	for (int i = lane; i < nk; i += 64) ord[i] = s_c[i];
+}
+
 // ---- kernel C: final chain order, u[] and b[] (chain.c:397-420) -----------------------------------------------------
 __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 {
-	__shared__ int s_hist[256], s_lo[256], s_hi[256];
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
@@ -271,24 +471,13 @@ __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 	const int nu = (int)(A.seg_end1[task] - (uint32_t)base), nk = (int)(A.seg_end2[task] - (uint32_t)base);
 	if (nk == 0) return;
 	const int32_t *own = A.own + base, *dep = A.v + base, *rk2kk = A.rk2kk + base;
-	int32_t *dest = A.dest + base, *ord = A.val1 + base;
-	uint64_t *sx = A.rkey1 + base;
+	int32_t *dest = A.dest + base;
+	const int32_t *ord = A.val1 + base;
 	const uint64_t *u2 = A.u2 + base, *us = A.key1 + base;
 	uint64_t *u_out = A.u_out + A.u_off[task];
 	ulonglong2 *b_out = A.b_out + A.b_off[task];
 	const int n_b = (int)(A.b_off[task + 1] - A.b_off[task]);
 
-	if (nk > 64) {                                                               // <= 64 records: insertion sort, stable (ksort.h:141-143)
-		bool tie = false;
-		for (int i = lane; i + 1 < nk; i += 64) tie |= sx[i] == sx[i + 1];
-		if (__ballot(tie)) {
-			__syncthreads();
-			for (int i = lane; i < nk; i += 64) { sx[i] = A.key0[base + i]; ord[i] = i; }   // back to rank order
-			__syncthreads();
-			if (lane == 0) flag_sort_one_lane(sx, ord, nk, dest, s_hist, s_lo, s_hi);
-			__syncthreads();
-		}
-	}
 	int run = 0;
 	for (int i0 = 0; i0 < nk; i0 += 64) {
 		const int i = i0 + lane;
@@ -301,13 +490,19 @@ __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 		run += __shfl(incl, 63);
 	}
 	__syncthreads();
-	for (int i = lane; i < n; i += 64) {
-		const int o = own[i];
-		if (o == NONE) continue;
-		const int kk = rk2kk[o];
-		if (kk < 0) continue;
-		const int at = dest[kk] + dep[i];                                       // ascending along the chain (chain.c:399-400)
-		if (at >= 0 && at < n_b) b_out[at] = A.d_a[base + i];
+	if (A.debug_phases == 11) return;
+	for (int i0 = 0; i0 < n; i0 += W) {
+		int at[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = i0 + lane + 64 * k;
+			const int o = i < n ? own[i] : NONE;
+			const int kk = o != NONE ? rk2kk[o] : -1;
+			at[k] = kk >= 0 ? dest[kk] + dep[i] : -1;                            // ascending along the chain (chain.c:399-400)
+		}
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			if (at[k] >= 0 && at[k] < n_b) b_out[at[k]] = A.d_a[base + i0 + lane + 64 * k];
 	}
 	for (int r = lane; r < nu; r += 64) {                                        // chains that kept only their (already taken) peak
 		const int kk = rk2kk[r];
@@ -345,8 +540,10 @@ hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launch
 	tmp = A.sort_tmp_bytes;
 	e = rocprim::segmented_radix_sort_pairs(A.sort_tmp, tmp, A.key0, A.rkey1, A.val0, A.val1, tot, nt, A.seg_begin, A.seg_end2, 0, 64, st);
 	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(epi_tiesort, dim3(nt), dim3(64), 0, st, A);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_emit, dim3(nt), dim3(64), 0, st, A);
-	if (n_launches) *n_launches += 6;
+	if (n_launches) *n_launches += 7;
 	return hipGetLastError();
 }
 

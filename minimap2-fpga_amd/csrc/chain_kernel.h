@@ -49,6 +49,7 @@ struct EpiArgs {
 	const ulonglong2 *d_a;      // anchors
 	const int32_t *d_f, *d_p;   // DP result
 	int32_t min_cnt, min_sc;
+	int32_t debug_phases;       // development aid (MM2C_EPI_PHASES): kernels return after that many of their phases; 0 = run everything
 	// scratch, `total` entries each unless noted
 	int32_t *v;                 // v[] (chain.c:106-111), later the depth of an anchor inside its chain
 	int32_t *own;               // child marks, later the rank of the chain that takes the anchor

@@ -407,6 +407,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	}
 	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off; E.d_order = pl->d_order;
 	E.d_a = (const ulonglong2 *)d_anchors; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
+	{ const char *dbg = getenv("MM2C_EPI_PHASES"); E.debug_phases = dbg ? atoi(dbg) : 0; }
 	E.u_off = d_u_off; E.b_off = d_b_off; E.u_out = d_u; E.b_out = (ulonglong2 *)d_b;
 	int nl = 0;
 	HIP_TRY(hipEventRecord(pl->ev_e0, st));

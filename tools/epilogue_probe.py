@@ -16,7 +16,11 @@ profile = args[2] if len(args) > 2 else "mixed"
 device_only = "--device-only" in sys.argv
 mm2chain.init()
 P = params.map_ont()
-off_t, a_t = synth.make_stream(profile, n_reads, (per, per), seed=5)
+distinct = min(n_reads, 4096)                       # as bench.py: distinct reads tiled up to the batch size
+off_t, a_t = synth.make_stream(profile, distinct, (per, per), seed=5)
+if n_reads > distinct:
+    off_t, a_t = synth.replicate(off_t, a_t, n_reads // distinct)
+    n_reads = off_t.numel() - 1
 total = int(off_t[-1])
 
 # HBM-resident: plan.run + plan.chains
