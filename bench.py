@@ -206,6 +206,28 @@ def main():
         out["secondary"] = {"nominal_cells_per_s": float(tt) * times / (k_avg_ms * 1e-3),
                             "nominal_cells_definition": "sum over anchors of min(i - st, 1024), the reference's total_trip_count (chain.c:69)",
                             "nominal_cells_per_anchor": float(tt) / int(off1[-1])}
+        # whole mm_chain_dp: DP + the epilogue of chain.c:348-422 on the GPU, chains left in HBM
+        min_cnt, min_sc = (3, 100) if args.preset == "ava-ont" else (3, 40)     # options.c:24-25,85
+        u_off, u, b_off, b = plan.chains(anchors, d_f, d_p, min_cnt, min_sc)   # warm-up (allocates the scratch)
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        plan.run(anchors, d_f, d_p)
+        u_off, u, b_off, b = plan.chains(anchors, d_f, d_p, min_cnt, min_sc)
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - tw
+        n_chk = min(16, distinct)
+        uo, bo = u_off[: n_chk + 1].cpu().numpy(), b_off[: n_chk + 1].cpu().numpy()
+        u_h, b_h = u[: int(uo[-1])].cpu().numpy().view(np.uint64), b[: int(bo[-1])].cpu().numpy().view(np.uint64)
+        a_chk = a1[: int(off1[n_chk])].cpu().numpy().view(np.uint64)
+        ok = True
+        for k in range(n_chk):
+            u_ref, b_ref = ob.mm_chain_dp(P, min_cnt, min_sc, a_chk[int(off1[k]):int(off1[k + 1])])
+            ok = ok and np.array_equal(u_h[uo[k]:uo[k + 1]], u_ref) and np.array_equal(b_h[bo[k]:bo[k + 1]], b_ref)
+        out["whole_mm_chain_dp"] = {"value": total / tw, "unit": "anchors/s", "epilogue_ms": plan.last_epilogue_ms(),
+                                    "chains": int(u_off[-1]), "chained_anchors": int(b_off[-1]), "min_cnt": min_cnt, "min_sc": min_sc,
+                                    "what": "prepass + DP + device epilogue (v[], chain ends, backtrack, filter, chain order), HBM-resident, 1 step",
+                                    "verified_vs_oracle": bool(ok)}
+        del u, b
         n_h = min(distinct, 4096)
         a_host = a1[: int(off1[n_h])].cpu().numpy().view(np.uint64)
         off_host = off1[: n_h + 1].numpy()

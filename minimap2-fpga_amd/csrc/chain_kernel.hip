@@ -216,7 +216,7 @@ __device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int
 		if (fm != 0) {
 			int pj2 = pj;
 			asm volatile("" : "+v"(pj2));                             // keep the far addressing out of the hot loop
-			if (fm >> lane & 1) __hip_atomic_store(&t_glob[pj2], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (fm >> lane & 1) __hip_atomic_store(&t_glob[pj2], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			tgt = sel(fm, tgt, 2 * R * 2);
 		}
 	}
@@ -289,21 +289,21 @@ __device__ __forceinline__ bool older_chunk(const KParams &P, float avg, int lan
 			asm volatile("" : "+v"(j));
 			const bool fl = (far_l & valid) >> lane & 1;
 			if (fl) {
-				fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				fj = __hip_atomic_load(&f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				pj = __hip_atomic_load(&p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				if (pj >= 0) pj -= pbase;             // p[] in memory is relative to the caller's task, the scan works piece-relative
 			}
 			if (SKIP) {
 				const bool mkv = (valid >> lane & 1) && pj >= lo;
 				if (mkv) {
 					if (pj >= stamp_lo) s_t[pj & (2 * R - 1)] = (uint16_t)s16;
-					else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					else __hip_atomic_store(&t[pj], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // far stamps of this and earlier chunks have landed
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				int tj = 0;
-				if (fl && j < stamp_lo) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (fl && j < stamp_lo) tj = __hip_atomic_load(&t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				else tj = s_t[j & (2 * R - 1)] == s16 ? stamp : 0;
 				marked = BALLOT(tj == stamp);
 			}
