@@ -518,17 +518,18 @@ def test_batched_runner_on_a_stream_file(tmp_path):
     src, out = tmp_path / "in.mm2a", tmp_path / "out.bin"
     stream.write(src, P, off, a)
     exe = os.path.join(os.path.dirname(mm2chain.LIB_PATH), "tools", "mm2chain_run")
-    r = subprocess.run([exe, "-b", "20000", "-c", "-o", str(out), str(src)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    fp = np.fromfile(out, dtype=np.int32)
     f_ref, p_ref = oracle_batch(P, off, a)
-    assert_same(fp[: f_ref.size], fp[f_ref.size:], f_ref, p_ref, off, "runner")
-    got = [tuple(map(int, ln.split("\t")[1:])) for ln in r.stdout.splitlines() if ln.startswith("CH")]
     want = []
     for k in range(40):
         u, _ = ob.mm_chain_dp(P, 3, 40, a[off[k]:off[k + 1]])
         want += [(k, int(x >> np.uint64(32)), int(x & np.uint64(0xFFFFFFFF))) for x in u]
-    assert got == want
+    for extra in ([], ["-e", "2"]):                     # backtrack on the GPU / on two host threads
+        r = subprocess.run([exe, "-b", "20000", "-c", *extra, "-o", str(out), str(src)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        fp = np.fromfile(out, dtype=np.int32)
+        assert_same(fp[: f_ref.size], fp[f_ref.size:], f_ref, p_ref, off, "runner")
+        got = [tuple(map(int, ln.split("\t")[1:])) for ln in r.stdout.splitlines() if ln.startswith("CH")]
+        assert got == want, extra
 
 
 def test_big_host_batch_is_pipelined_in_chunks():
