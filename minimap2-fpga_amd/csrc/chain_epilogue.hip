@@ -7,7 +7,7 @@
 //   v[i]       = max of f over i and its ancestors in the p[] forest          -> pointer jumping inside 64-anchor chunks
 //   chain ends = anchors without a child whose v >= min_sc; each walks back to its peak (f[j] >= v[j])   -> one lane per end
 //   sort       = descending on (f[peak] << 32 | peak); the keys are compared in full, so any correct sort gives the
-//                reference's order (rocPRIM segmented radix sort, one segment per task)
+//                reference's order (wave_sort64: LSD radix sort by the task's own wave)
 //   backtrack  : chain r (rank in that order) takes its peak's ancestors up to the first anchor an earlier chain took.
 //                Equivalent closed form: owner(x) = min rank over the peaks in the subtree of x.  (If m is that minimum, chain m
 //                cannot have been stopped below x: a stop needs an earlier chain with a peak in a sub-subtree, which would have a
@@ -18,14 +18,12 @@
 //   filter     = chain.c:385-388; survivors keep their rank order
 //   final order= ascending x of the first anchor.  radix_sort_128x (ksort.h:101-151) is not stable for more than 64 records,
 //                so a task with more than 64 chains AND two equal first-x values replays that sort's passes on one lane;
-//                everywhere else the order is unique (rocPRIM segmented sort of (x, chain)).
+//                everywhere else the order is unique (stable wave_sort64 of (x, chain)).
 //
 // One 64-lane wave per task in each kernel; tasks are independent.  Outputs are compact: chains of task k are
 // u[u_off[k] .. u_off[k+1]), their anchors b[b_off[k] .. b_off[k+1]).
 
 #include <hip/hip_runtime.h>
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <climits>
 #include "chain_kernel.h"
 
@@ -62,6 +60,71 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane)
 {
 	for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
 	return x;
+}
+
+// ---- stable LSD radix sort of one task's records by one wave (8-bit digits, ping-pong between two global buffers) ----
+// Bytes in which all keys agree are skipped, so (score << 32 | index) keys cost about four passes.  Per 64 records: the lanes with
+// the same digit find each other with eight ballots; rank among them = position in lane order (stable).  `vals` may be NULL.
+// The result ends in (k1, v1).  No host involvement -- rocPRIM's segmented sort synchronises the stream on the host.
+template <bool DESC>
+__device__ void wave_sort64(uint64_t *k0, uint64_t *k1, int32_t *v0, int32_t *v1, int m, int lane, int *s_cnt /* 256 ints of LDS */)
+{
+	if (m <= 0) return;
+	uint64_t diff = 0;
+	const uint64_t first = k0[0];
+	for (int i = lane; i < m; i += 64) diff |= k0[i] ^ first;
+	for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
+	uint64_t *src = k0, *dst = k1;
+	int32_t *vsrc = v0, *vdst = v1;
+	for (int shift = 0; shift < 64; shift += 8) {
+		if (((diff >> shift) & 255) == 0) continue;
+		for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
+		__syncthreads();
+		for (int i = lane; i < m; i += 64) {
+			const int d = (int)(src[i] >> shift) & 255;
+			atomicAdd(&s_cnt[DESC ? 255 - d : d], 1);
+		}
+		__syncthreads();
+		{
+			int h[4], sum = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { h[k] = s_cnt[4 * lane + k]; sum += h[k]; }
+			int at = wave_incl_scan(sum, lane) - sum;
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { s_cnt[4 * lane + k] = at; at += h[k]; }
+		}
+		__syncthreads();
+		for (int i0 = 0; i0 < m; i0 += 64) {
+			const int i = i0 + lane;
+			const bool valid = i < m;
+			const uint64_t key = valid ? src[i] : 0;
+			const int32_t val = (valid && vsrc) ? vsrc[i] : 0;
+			int d = (int)(key >> shift) & 255;
+			if (DESC) d = 255 - d;
+			uint64_t peers = __ballot(valid);
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const uint64_t bal = __ballot((d >> b) & 1);
+				peers &= ((d >> b) & 1) ? bal : ~bal;
+			}
+			if (valid) {
+				const int rank = lanes_before(peers);
+				const int pos = s_cnt[d] + rank;
+				dst[pos] = key;
+				if (vdst) vdst[pos] = val;
+			}
+			__syncthreads();
+			if (valid && lanes_before(peers) == 0) s_cnt[d] += __popcll(peers);
+			__syncthreads();
+		}
+		{ uint64_t *t = src; src = dst; dst = t; }
+		{ int32_t *t = vsrc; vsrc = vdst; vdst = t; }
+	}
+	if (src != k1) {                                                             // even number of passes: the result is in (k0, v0)
+		for (int i = lane; i < m; i += 64) { k1[i] = src[i]; if (v1) v1[i] = vsrc[i]; }
+	}
+	__syncthreads();
 }
 
 // The three chunked passes below walk a task in chunks of W = 64*K anchors (K per lane), because the passes are sequential from chunk
@@ -175,6 +238,8 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 	int32_t *own = A.own + base, *dep = A.v + base, *ctop = A.ctop + base, *rk2kk = A.rk2kk + base, *val0 = A.val0 + base;
 	const uint64_t *us = A.key1 + base;
 	uint64_t *u2 = A.u2 + base, *rkey = A.key0 + base;
+
+	wave_sort64<true>(A.key0 + base, A.key1 + base, nullptr, nullptr, nu, lane, s_val);   // chain.c:368-372: best peak first
 
 	for (int r = lane; r < nu; r += 64) wg_min(&own[(int32_t)us[r]], r);       // own[] is NONE on entry; a peak listed twice belongs to the first listing
 	__syncthreads();
@@ -290,6 +355,9 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 		A.cnt_u[task] = kept;
 		A.cnt_b[task] = n_b;
 	}
+	__syncthreads();
+	// chain.c:406-411: chains by the x of their first anchor (stable here; kernel T replays the reference's sort where that matters)
+	wave_sort64<false>(rkey, A.rkey1 + base, val0, A.val1 + base, kept, lane, s_val);
 }
 
 // ---- exclusive scans of the per-task chain / anchor counts -> compact output offsets ---------------------------------------
@@ -381,13 +449,16 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 	for (int i = lane; i + 1 < nk; i += 64) tie |= sx[i] == sx[i + 1];
 	if (!__ballot(tie)) return;                                                  // distinct keys: the order is unique
 	if (nk > TS_MAX) {                                                           // does not fit the LDS: replay on one lane in global memory
+		uint64_t *tmp = A.key0 + base;                                          // back to rank order (chain k at index k), as chain.c:407-410 fills w[]
 		__syncthreads();
-		for (int i = lane; i < nk; i += 64) { sx[i] = A.key0[base + i]; ord[i] = i; }
+		for (int i = lane; i < nk; i += 64) tmp[ord[i]] = sx[i];
+		__syncthreads();
+		for (int i = lane; i < nk; i += 64) { sx[i] = tmp[i]; ord[i] = i; }
 		__syncthreads();
 		if (lane == 0) flag_sort_one_lane(sx, ord, nk, A.dest + base, s_cur, s_lo, s_hi);
 		return;
 	}
-	for (int i = lane; i < nk; i += 64) { s_x[i] = A.key0[base + i]; s_c[i] = i; }   // rank order, as chain.c:407-410 fills w[]
+	for (int i = lane; i < nk; i += 64) { const int kk = ord[i]; s_x[kk] = sx[i]; s_c[kk] = kk; }   // rank order, as chain.c:407-410 fills w[]
 	if (lane == 0) { s_stack[0] = 0; s_stack[1] = nk; s_stack[2] = 56; s_sp = 1; }
 	for (;;) {
 		__syncthreads();
@@ -514,36 +585,23 @@ __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 
 } // namespace
 
-size_t epilogue_sort_temp_bytes(int64_t total, int64_t n_tasks)
-{
-	size_t s1 = 0, s2 = 0;
-	uint64_t *k = nullptr; int32_t *v = nullptr; uint32_t *o = nullptr;
-	(void)rocprim::segmented_radix_sort_keys_desc(nullptr, s1, k, k, (unsigned)total, (unsigned)n_tasks, o, o, 0, 64, (hipStream_t)0);
-	(void)rocprim::segmented_radix_sort_pairs(nullptr, s2, k, k, v, v, (unsigned)total, (unsigned)n_tasks, o, o, 0, 64, (hipStream_t)0);
-	return s1 > s2 ? s1 : s2;
-}
+size_t epilogue_sort_temp_bytes(int64_t, int64_t) { return 0; }   // the sorts run inside epi_claim (wave_sort64); no library scratch
 
 hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launches)
 {
 	if (A.n_tasks <= 0) return hipSuccess;
-	const unsigned nt = (unsigned)A.n_tasks, tot = (unsigned)A.total;
+	const unsigned nt = (unsigned)A.n_tasks;
 	hipError_t e;
-	size_t tmp = A.sort_tmp_bytes;
 	hipLaunchKernelGGL(epi_ends, dim3(nt), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	e = rocprim::segmented_radix_sort_keys_desc(A.sort_tmp, tmp, A.key0, A.key1, tot, nt, A.seg_begin, A.seg_end1, 0, 64, st);
-	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_claim, dim3(nt), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_offsets, dim3(1), dim3(1024), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	tmp = A.sort_tmp_bytes;
-	e = rocprim::segmented_radix_sort_pairs(A.sort_tmp, tmp, A.key0, A.rkey1, A.val0, A.val1, tot, nt, A.seg_begin, A.seg_end2, 0, 64, st);
-	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_tiesort, dim3(nt), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_emit, dim3(nt), dim3(64), 0, st, A);
-	if (n_launches) *n_launches += 7;
+	if (n_launches) *n_launches += 5;
 	return hipGetLastError();
 }
 

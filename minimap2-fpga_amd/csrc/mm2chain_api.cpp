@@ -61,7 +61,24 @@ struct Global {
 // chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex).  One device arena for everything that is uploaded
 // ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
 // mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
+// one chunk in flight of mm2c_mm_chain_dp_batch_host (anchors up, DP, epilogue, chains down); grow-only arenas
+struct WholeSlot {
+	hipStream_t st = nullptr;
+	char *d_in = nullptr, *d_work = nullptr, *d_res = nullptr, *h_meta = nullptr;
+	size_t cap_in = 0, cap_work = 0, cap_res = 0, cap_hmeta = 0;
+	int64_t k0 = 0, k1 = 0;                    // tasks of the chunk in flight
+	size_t o_res_u = 0, o_res_b = 0, o_hres = 0;
+	bool busy = false;
+	void release()
+	{
+		if (d_in) (void)hipFree(d_in); if (d_work) (void)hipFree(d_work); if (d_res) (void)hipFree(d_res);
+		if (h_meta) (void)hipHostFree(h_meta); if (st) (void)hipStreamDestroy(st);
+		*this = WholeSlot();
+	}
+};
+
 struct ThreadCtx {
+	WholeSlot whole[2];
 	hipStream_t st = nullptr, st2 = nullptr;   // st2: second stream of the pipelined big-batch path
 	hipEvent_t ev = nullptr;
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
@@ -72,6 +89,7 @@ struct ThreadCtx {
 		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
 		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
 		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
+		whole[0].release(); whole[1].release();
 		*this = ThreadCtx();
 	}
 };
@@ -92,6 +110,17 @@ int get_thread_ctx(ThreadCtx **out)
 	tl_ctx = c; tl_epoch = G.epoch;
 	*out = c;
 	return 0;
+}
+
+// Second stream of a two-stream pipeline.  The runtime spreads streams of equal priority over a few hardware queues (4 by default)
+// in creation order, so two streams of one pipeline can end up on the same queue and then run strictly one after the other
+// (measured: no overlap at all with the default GPU_MAX_HW_QUEUES=4).  Streams of different priority never share a queue.
+hipError_t create_partner_stream(hipStream_t *st)
+{
+	int least = 0, greatest = 0;
+	hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+	if (e != hipSuccess || greatest == least) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
 }
 
 int grow_device(char **p, size_t *cap, size_t need)
@@ -157,6 +186,23 @@ int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order
 	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
 	return 0;
 }
+
+
+// carves the scratch of the device epilogue (chain_epilogue.hip) out of one allocation; returns the bytes needed (base may be NULL)
+size_t layout_epilogue(mm2c::EpiArgs &E, char *base, size_t tot, size_t nt, size_t sort_tmp)
+{
+	size_t at = 0;
+	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return base + o; };
+	E.key0 = (uint64_t *)take(tot * 8); E.key1 = (uint64_t *)take(tot * 8); E.u2 = (uint64_t *)take(tot * 8); E.rkey1 = (uint64_t *)take(tot * 8);
+	E.v = (int32_t *)take(tot * 4); E.own = (int32_t *)take(tot * 4); E.ctop = (int32_t *)take(tot * 4); E.rk2kk = (int32_t *)take(tot * 4);
+	E.dest = (int32_t *)take(tot * 4); E.val0 = (int32_t *)take(tot * 4); E.val1 = (int32_t *)take(tot * 4);
+	E.seg_begin = (uint32_t *)take(nt * 4); E.seg_end1 = (uint32_t *)take(nt * 4); E.seg_end2 = (uint32_t *)take(nt * 4);
+	E.cnt_u = (int32_t *)take(nt * 4); E.cnt_b = (int32_t *)take(nt * 4);
+	E.sort_tmp = take(sort_tmp ? sort_tmp : 1); E.sort_tmp_bytes = sort_tmp;
+	return at;
+}
+
+int epilogue_debug_phases() { const char *dbg = getenv("MM2C_EPI_PHASES"); return dbg ? atoi(dbg) : 0; }
 
 } // namespace
 
@@ -385,29 +431,16 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	mm2c::EpiArgs &E = pl->E;
 	if (!pl->d_epi) {
 		HIP_TRY(hipSetDevice(G.device));
-		const size_t tot = (size_t)pl->total, nt = (size_t)pl->n_tasks;
 		const size_t tmp = mm2c::epilogue_sort_temp_bytes(pl->total, pl->n_tasks);
-		size_t at = 0;
-		auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
-		const size_t o_key0 = take(tot * 8), o_key1 = take(tot * 8), o_u2 = take(tot * 8), o_rkey1 = take(tot * 8);
-		const size_t o_v = take(tot * 4), o_own = take(tot * 4), o_ctop = take(tot * 4), o_rk = take(tot * 4), o_dest = take(tot * 4),
-		             o_val0 = take(tot * 4), o_val1 = take(tot * 4);
-		const size_t o_sb = take(nt * 4), o_se1 = take(nt * 4), o_se2 = take(nt * 4), o_cu = take(nt * 4), o_cb = take(nt * 4);
-		const size_t o_tmp = take(tmp ? tmp : 1);
-		HIP_TRY(hipMalloc((void **)&pl->d_epi, at));
-		char *b = pl->d_epi;
-		E.key0 = (uint64_t *)(b + o_key0); E.key1 = (uint64_t *)(b + o_key1); E.u2 = (uint64_t *)(b + o_u2); E.rkey1 = (uint64_t *)(b + o_rkey1);
-		E.v = (int32_t *)(b + o_v); E.own = (int32_t *)(b + o_own); E.ctop = (int32_t *)(b + o_ctop); E.rk2kk = (int32_t *)(b + o_rk);
-		E.dest = (int32_t *)(b + o_dest); E.val0 = (int32_t *)(b + o_val0); E.val1 = (int32_t *)(b + o_val1);
-		E.seg_begin = (uint32_t *)(b + o_sb); E.seg_end1 = (uint32_t *)(b + o_se1); E.seg_end2 = (uint32_t *)(b + o_se2);
-		E.cnt_u = (int32_t *)(b + o_cu); E.cnt_b = (int32_t *)(b + o_cb);
-		E.sort_tmp = b + o_tmp; E.sort_tmp_bytes = tmp;
+		const size_t bytes = layout_epilogue(E, nullptr, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
+		HIP_TRY(hipMalloc((void **)&pl->d_epi, bytes));
+		layout_epilogue(E, pl->d_epi, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
 		HIP_TRY(hipEventCreate(&pl->ev_e0));
 		HIP_TRY(hipEventCreate(&pl->ev_e1));
 	}
 	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off; E.d_order = pl->d_order;
 	E.d_a = (const ulonglong2 *)d_anchors; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
-	{ const char *dbg = getenv("MM2C_EPI_PHASES"); E.debug_phases = dbg ? atoi(dbg) : 0; }
+	E.debug_phases = epilogue_debug_phases();
 	E.u_off = d_u_off; E.b_off = d_b_off; E.u_out = d_u; E.b_out = (ulonglong2 *)d_b;
 	int nl = 0;
 	HIP_TRY(hipEventRecord(pl->ev_e0, st));
@@ -518,7 +551,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	} else if (n_req == 1 && total >= 2 * G.pipeline_chunk_anchors) {
 		// big batch: pipeline it in chunks of whole pieces on two streams, so that the upload of chunk k+1, the kernels of chunk k
 		// and the download of chunk k-1 overlap (PCIe is full duplex); with page-locked caller buffers this runs at PCIe rate
-		if (!c->st2) HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+		if (!c->st2) HIP_TRY(create_partner_stream(&c->st2));
 		if (!c->ev) HIP_TRY(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
 		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
 		HIP_TRY(hipEventRecord(c->ev, c->st));
@@ -713,35 +746,94 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		return rc ? fail(rc, "mm2c_chain_epilogue_host failed") : 0;
 	}
 	if (total == 0) { for (int64_t k = 1; k <= n_tasks; ++k) u_off[k] = b_off[k] = 0; return 0; }
-	// everything on the GPU: anchors up, DP, epilogue, chains down
+	// everything on the GPU: anchors up, DP, epilogue, chains down; big batches in chunks of whole tasks on two streams, so that the
+	// upload of chunk k+1, the kernels of chunk k and the download of chunk k-1 overlap
+	if (total >= (int64_t)INT32_MAX && G.pipeline_chunk_anchors >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch too big for one chunk");
 	ThreadCtx *c;
 	if ((rc = get_thread_ctx(&c))) return rc;
-	mm2c_plan_t *pl = mm2c_plan_create(par, n_tasks, h_offsets);
-	if (!pl) return MM2C_E_HIP;
-	const size_t tot = (size_t)total, nt = (size_t)n_tasks;
-	const size_t o_uoff = 0, o_boff = align16((nt + 1) * 8), o_u = align16(o_boff + (nt + 1) * 8), o_b = align16(o_u + tot * 8), out_bytes = o_b + tot * 16;
-	auto body = [&]() -> int {
+	HIP_TRY(hipSetDevice(G.device));
+	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors : total;
+	const mm2c_anchor_t *a0 = h_anchors + h_offsets[0];
+	int64_t base_u = 0, base_b = 0;
+	int nl = 0;
+
+	auto enqueue = [&](WholeSlot &w, int64_t k0, int64_t k1) -> int {
 		int r;
-		if ((r = grow_device(&c->d_in, &c->cap_in, tot * 16))) return r;
-		if ((r = grow_device(&c->d_out, &c->cap_out, tot * 8))) return r;
-		if ((r = grow_device(&c->d_scratch, &c->cap_scratch, out_bytes))) return r;
-		int32_t *d_f = (int32_t *)c->d_out, *d_p = d_f + tot;
-		char *o = c->d_scratch;
-		HIP_TRY(hipMemcpyAsync(c->d_in, h_anchors + h_offsets[0], tot * 16, hipMemcpyHostToDevice, c->st));
-		if ((r = mm2c_plan_run_device(pl, c->d_in, nullptr, d_f, d_p, c->st))) return r;
-		if ((r = mm2c_plan_chains_device(pl, c->d_in, d_f, d_p, min_cnt, min_sc, (int64_t *)(o + o_uoff), (uint64_t *)(o + o_u),
-		                                 (int64_t *)(o + o_boff), o + o_b, c->st))) return r;
-		HIP_TRY(hipMemcpyAsync(u_off, o + o_uoff, (nt + 1) * 8, hipMemcpyDeviceToHost, c->st));
-		HIP_TRY(hipMemcpyAsync(b_off, o + o_boff, (nt + 1) * 8, hipMemcpyDeviceToHost, c->st));
-		HIP_TRY(hipStreamSynchronize(c->st));
-		if (u_off[nt] > 0) HIP_TRY(hipMemcpyAsync(u, o + o_u, (size_t)u_off[nt] * 8, hipMemcpyDeviceToHost, c->st));
-		if (b_off[nt] > 0) HIP_TRY(hipMemcpyAsync(b, o + o_b, (size_t)b_off[nt] * 16, hipMemcpyDeviceToHost, c->st));
-		HIP_TRY(hipStreamSynchronize(c->st));
+		const size_t nt = (size_t)(k1 - k0), tot = (size_t)(h_offsets[k1] - h_offsets[k0]);
+		if (!w.st) HIP_TRY(&w == &c->whole[1] ? create_partner_stream(&w.st) : hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+		w.k0 = k0; w.k1 = k1; w.busy = true;
+		// upload arena: [anchors | offsets | order | status]; pinned mirror of the metadata + room for the offsets that come back
+		const size_t o_off = align16(tot * 16), o_ord = align16(o_off + (nt + 1) * 8), o_stat = align16(o_ord + nt * 4), in_bytes = align16(o_stat + nt * 4);
+		const size_t meta_bytes = in_bytes - o_off;
+		w.o_hres = align16(meta_bytes);
+		if ((r = grow_device(&w.d_in, &w.cap_in, in_bytes))) return r;
+		if ((r = grow_pinned(&w.h_meta, &w.cap_hmeta, w.o_hres + 2 * (nt + 1) * 8))) return r;
+		std::vector<int32_t> order;
+		if ((r = build_order((int64_t)nt, h_offsets + k0, order))) return r;
+		int64_t *m_off = (int64_t *)w.h_meta;
+		for (size_t k = 0; k <= nt; ++k) m_off[k] = h_offsets[k0 + (int64_t)k] - h_offsets[k0];
+		memcpy(w.h_meta + (o_ord - o_off), order.data(), nt * 4);
+		memset(w.h_meta + (o_stat - o_off), 0, in_bytes - o_stat);
+		// work arena: [f | p | t | st | epilogue scratch]; result arena: [u_off | b_off | u | b]
+		mm2c::EpiArgs E;
+		const size_t tmp = mm2c::epilogue_sort_temp_bytes((int64_t)tot, (int64_t)nt);
+		const size_t o_epi = align16(tot * 16), work_bytes = o_epi + layout_epilogue(E, nullptr, tot, nt, tmp);
+		if ((r = grow_device(&w.d_work, &w.cap_work, work_bytes))) return r;
+		layout_epilogue(E, w.d_work + o_epi, tot, nt, tmp);
+		const size_t o_boff = align16((nt + 1) * 8);
+		w.o_res_u = align16(o_boff + (nt + 1) * 8); w.o_res_b = align16(w.o_res_u + tot * 8);
+		if ((r = grow_device(&w.d_res, &w.cap_res, w.o_res_b + tot * 16))) return r;
+		if (tot == 0) { memset(w.h_meta + w.o_hres, 0, 2 * (nt + 1) * 8); return 0; }
+		HIP_TRY(hipMemcpyAsync(w.d_in + o_off, w.h_meta, meta_bytes, hipMemcpyHostToDevice, w.st));
+		HIP_TRY(hipMemcpyAsync(w.d_in, a0 + (h_offsets[k0] - h_offsets[0]), tot * 16, hipMemcpyHostToDevice, w.st));
+		int32_t *d_f = (int32_t *)w.d_work, *d_p = d_f + tot;
+		mm2c::LaunchArgs L;
+		L.P = to_kparams(par);
+		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
+		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
+		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
+		L.ring_class = G.ring_class;
+		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr));
+		E.n_tasks = (int64_t)nt; E.total = (int64_t)tot; E.d_off = L.d_offsets; E.d_order = L.d_order;
+		E.d_a = (const ulonglong2 *)w.d_in; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
+		E.debug_phases = epilogue_debug_phases();
+		E.u_off = (int64_t *)w.d_res; E.b_off = (int64_t *)(w.d_res + o_boff);
+		E.u_out = (uint64_t *)(w.d_res + w.o_res_u); E.b_out = (ulonglong2 *)(w.d_res + w.o_res_b);
+		HIP_TRY(mm2c::launch_chain_epilogue(E, w.st, &nl));
+		HIP_TRY(hipMemcpyAsync(w.h_meta + w.o_hres, E.u_off, (nt + 1) * 8, hipMemcpyDeviceToHost, w.st));
+		HIP_TRY(hipMemcpyAsync(w.h_meta + w.o_hres + (nt + 1) * 8, E.b_off, (nt + 1) * 8, hipMemcpyDeviceToHost, w.st));
 		return 0;
 	};
-	rc = body();
-	mm2c_plan_destroy(pl);
-	G.passes += 1;
+	// waits for the chunk's offsets, places them behind the chunks before it and starts the download of its chains
+	auto finalize = [&](WholeSlot &w) -> int {
+		if (!w.busy) return 0;
+		w.busy = false;
+		const size_t nt = (size_t)(w.k1 - w.k0);
+		HIP_TRY(hipStreamSynchronize(w.st));
+		const int64_t *cu = (const int64_t *)(w.h_meta + w.o_hres), *cb = cu + nt + 1;
+		for (size_t k = 1; k <= nt; ++k) { u_off[w.k0 + (int64_t)k] = base_u + cu[k]; b_off[w.k0 + (int64_t)k] = base_b + cb[k]; }
+		if (cu[nt] > 0) HIP_TRY(hipMemcpyAsync(u + base_u, w.d_res + w.o_res_u, (size_t)cu[nt] * 8, hipMemcpyDeviceToHost, w.st));
+		if (cb[nt] > 0) HIP_TRY(hipMemcpyAsync(b + base_b, w.d_res + w.o_res_b, (size_t)cb[nt] * 16, hipMemcpyDeviceToHost, w.st));
+		base_u += cu[nt]; base_b += cb[nt];
+		return 0;
+	};
+	int n_chunks = 0;
+	for (int64_t k0 = 0; k0 < n_tasks && rc == 0; ++n_chunks) {
+		int64_t k1 = k0 + 1;
+		while (k1 < n_tasks && h_offsets[k1 + 1] - h_offsets[k0] <= chunk_anchors) ++k1;
+		if (h_offsets[k1] - h_offsets[k0] >= (int64_t)INT32_MAX) { rc = fail(MM2C_E_TOOBIG, "a chunk of the batch has 2^31 anchors or more"); break; }
+		WholeSlot &w = c->whole[n_chunks & 1];
+		if ((rc = finalize(w))) break;                              // the chunk before the previous one (same slot)
+		rc = enqueue(w, k0, k1);
+		k0 = k1;
+	}
+	if (rc == 0) rc = finalize(c->whole[n_chunks & 1]);             // in chunk order: the older slot first
+	if (rc == 0) rc = finalize(c->whole[(n_chunks + 1) & 1]);
+	for (int i = 0; i < 2; ++i) {
+		if (c->whole[i].st) { hipError_t e = hipStreamSynchronize(c->whole[i].st); if (e != hipSuccess && rc == 0) rc = fail(MM2C_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+		c->whole[i].busy = false;
+	}
+	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.passes += (uint64_t)n_chunks;
 	return rc;
 }
 

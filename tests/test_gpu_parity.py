@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP kernel, called through the C ABI, must equal the CPU oracle bit for bit (f[] and p[]).
 Reference path: chain.c:184-238 (V1) and device/minimap2_opencl.cl (V2)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -325,6 +326,26 @@ def test_batched_mm_chain_dp_equals_task_by_task_calls(epilogue_threads):
     res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=epilogue_threads)
     assert len(res) == off.size - 1
     assert _assert_chains(res, P, 3, 40, off, a, f"epilogue_threads={epilogue_threads}") > 40
+
+
+def test_batched_mm_chain_dp_pipelined_in_chunks():
+    """the same entry with the batch cut into many chunks of whole tasks on two streams (chunk size tuned down): offsets and
+    chains of every chunk land behind those of the chunks before it"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _mixed_batch_with_gaps()
+    from mm2chain import _native as N
+    st0, st1 = N.Stats(), N.Stats()
+    mm2chain.tune("pipeline_chunk_anchors", 6000)
+    try:
+        mm2chain.load().mm2c_get_stats(C.byref(st0))
+        res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
+        mm2chain.load().mm2c_get_stats(C.byref(st1))
+    finally:
+        mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
+    assert st1.passes - st0.passes > 8, "the batch was not cut into chunks"
+    assert _assert_chains(res, P, 3, 40, off, a, "chunked") > 40
 
 
 @pytest.mark.parametrize("min_cnt,min_sc", [(1, 0), (1, 40), (2, 15), (3, 100), (5, 1000), (0, -5)])

@@ -14,6 +14,7 @@ n_reads = int(args[0]) if len(args) > 0 else 2000
 per = int(args[1]) if len(args) > 1 else 10000
 profile = args[2] if len(args) > 2 else "mixed"
 device_only = "--device-only" in sys.argv
+pinned_only = "--pinned-only" in sys.argv
 mm2chain.init()
 P = params.map_ont()
 distinct = min(n_reads, 4096)                       # as bench.py: distinct reads tiled up to the batch size
@@ -42,7 +43,7 @@ if not device_only:
     u_off = np.zeros(n_reads + 1, np.int64); b_off = np.zeros(n_reads + 1, np.int64)
     u = np.zeros(total, np.uint64); b = np.zeros((total, 2), np.uint64)
     ptr = lambda x: x.ctypes.data_as(C.c_void_p)
-    for nt in (0, 1, 4, 16):
+    for nt in (() if pinned_only else (0, 1, 4, 16)):
         best = 1e9
         for _ in range(2):
             t0 = time.perf_counter()
@@ -50,4 +51,19 @@ if not device_only:
             best = min(best, time.perf_counter() - t0)
         assert rc == 0 and u_off[-1] == n_u and b_off[-1] == n_b
         print(f"host buffers, epilogue {'on the GPU' if nt == 0 else 'on %2d host threads' % nt}: {best*1e3:.1f} ms  {total/best/1e9:.3f} G anchors/s")
+    # page-locked caller buffers (mm2c_pinned_alloc): the pipelined path at PCIe rate
+    pa = mm2chain.PinnedArray(a.shape, np.uint64); pa.array[:] = a
+    pu = mm2chain.PinnedArray(u.shape, np.uint64); pb = mm2chain.PinnedArray(b.shape, np.uint64)
+    for chunk in (10 << 20, 20 << 20, 40 << 20, 80 << 20):
+        if chunk * 2 > total and chunk != 20 << 20:
+            continue
+        mm2chain.tune("pipeline_chunk_anchors", chunk)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = lib.mm2c_mm_chain_dp_batch_host(C.byref(P), 3, 40, n_reads, ptr(off), ptr(pa.array), 0, ptr(u_off), ptr(pu.array), ptr(b_off), ptr(pb.array))
+            best = min(best, time.perf_counter() - t0)
+        assert rc == 0 and u_off[-1] == n_u
+        print(f"page-locked host buffers, epilogue on the GPU, chunks of {chunk >> 20} Mi anchors: {best*1e3:.1f} ms  {total/best/1e9:.3f} G anchors/s")
+    mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
 mm2chain.shutdown()
