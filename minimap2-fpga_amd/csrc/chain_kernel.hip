@@ -156,9 +156,25 @@ __device__ __forceinline__ int pair_score(const KParams &P, float avg, int dr, i
 // scv: score per lane (SENT where the lane is not a candidate), marked: lanes with t[j] == i.
 // Updates the carry exactly as chain.c:226-232 would after walking the lanes in ascending order.
 // Returns true when the reference loop executes `break` inside this chunk.
+// a chunk in which no lane raises the best (chain.c:226 never taken): every marked lane is a skip event (chain.c:229-231)
 template <bool SKIP>
+__device__ __forceinline__ bool skips_only(const KParams &P, mask_t se, Carry &c)
+{
+	if (SKIP && se != 0) {
+		const int64_t need = (int64_t)P.max_skip - c.n_skip;               // the event of this 0-based rank breaks
+		if (need < (int64_t)__builtin_popcountll(se)) return true;
+		c.n_skip += (int)__builtin_popcountll(se);
+	}
+	return false;
+}
+
+template <bool SKIP, bool PRETEST>
 __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t valid, mask_t marked, int scv, Carry &c)
 {
+	// Most older chunks hold no score above the running best (the scan is nearest-first and chains grow from near predecessors): then
+	// no lane takes chain.c:226, every marked lane is a skip event, and the counter needs no scan at all.  (Not worth a test in
+	// chunk 0, which usually does raise the best.)
+	if (PRETEST && BALLOT(scv > c.best) == 0) return skips_only<SKIP>(P, marked & valid, c);
 	const int incl = prefix_max_incl(scv);
 	int last = 63;                                                    // last lane the reference visits in this chunk
 	bool broke = false;
@@ -314,7 +330,7 @@ __device__ __forceinline__ bool older_chunk(const KParams &P, float avg, int lan
 		const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + fj;
 		const int scv = sel(valid, SENT, sc);
 		if (near_stamps) marked = BALLOT(tj == s16);
-		return fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
+		return fold_chunk<SKIP, true>(P, jtop, valid, marked, scv, c);
 	}
 	return false;
 }
@@ -349,7 +365,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 				const int sc = pair_score<GEN, GS1>(P, avg, dr, dq, dd, same, span_i) + wf;   // chain.c:220
 				const int scv = sel(valid, SENT, sc);
 				const mask_t marked = SKIP ? BALLOT(tj == s16) : 0;
-				broke = fold_chunk<SKIP>(P, jtop, valid, marked, scv, c);
+				broke = fold_chunk<SKIP, false>(P, jtop, valid, marked, scv, c);
 			}
 			jtop -= 64; rem -= 64;
 		}
