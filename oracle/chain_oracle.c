@@ -349,3 +349,30 @@ double mm2o_bench_batch(const mm2o_params_t *par, int64_t n_tasks, const int64_t
 	free(th); free(args);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* map.c:215-247 (collect_seed_hits); skip_seed (map.c:122-147) always returns 0 when no NO_DIAG / NO_DUAL / FOR_ONLY / REV_ONLY
+ * flag is set, which is the map-ont case restated here */
+int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, mm2o_anchor_t *a)
+{
+	int64_t i, n_a = 0;
+	for (i = 0; i < n_m; ++i) {
+		const mm2o_match_t *q = &m[i];
+		const uint64_t *r = hits + q->cr_off;
+		uint32_t k;
+		for (k = 0; k < q->n; ++k) {
+			const int32_t rpos = (uint32_t)r[k] >> 1;
+			mm2o_anchor_t *p = &a[n_a++];
+			if ((r[k] & 1) == (q->q_pos & 1)) {                                  /* forward strand, map.c:232-234 */
+				p->x = (r[k] & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
+			} else {                                                             /* reverse strand, map.c:235-238 */
+				p->x = 1ULL << 63 | (r[k] & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - (int32_t)((q->q_pos >> 1) + 1 - q->q_span) - 1);
+			}
+			p->y |= (uint64_t)(q->seg_tandem >> 1) << 48;                        /* MM_SEED_SEG_SHIFT, map.c:239 */
+			if (q->seg_tandem & 1) p->y |= 1ULL << 42;                           /* MM_SEED_TANDEM, map.c:240 */
+		}
+	}
+	sort_128x(a, a + n_a);                                                       /* map.c:245 */
+	return n_a;
+}

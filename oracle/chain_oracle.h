@@ -69,6 +69,18 @@ int32_t mm2o_mm_chain_dp(const mm2o_params_t *par, int32_t min_cnt, int32_t min_
 double mm2o_bench_batch(const mm2o_params_t *par, int64_t n_tasks, const int64_t *offsets,
                         const mm2o_anchor_t *a, int32_t *f, int32_t *p, int n_threads);
 
+/* ---- seed hits -> anchors ----
+ * One match = one query minimizer found in the index (mm_match_t, map.c:76-81, filled by collect_matches map.c:84-120): its hits
+ * are hits[cr_off .. cr_off + n) (what mm_idx_get returns: rid<<32 | pos<<1 | strand). */
+typedef struct {
+	int64_t cr_off;
+	uint32_t n, q_pos, q_span, seg_tandem;   /* q_pos = pos<<1|strand (mm128_t.y low word); seg_tandem = seg_id<<1 | is_tandem */
+} mm2o_match_t;
+
+/* collect_seed_hits (map.c:215-247) without the name-dependent skips (flags 0): expansion in match order, anchor encoding of
+ * map.c:232-241, then radix_sort_128x.  a needs room for the sum of n; returns the number of anchors. */
+int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, mm2o_anchor_t *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,8 @@ def load():
         lib.mm2o_bench_batch.argtypes = [C.POINTER(OParams), C.c_int64, vp, vp, vp, vp, C.c_int]
         lib.mm2o_radix_sort_64.argtypes = [vp, C.c_int64]
         lib.mm2o_radix_sort_128x.argtypes = [vp, C.c_int64]
+        lib.mm2o_collect_seed_hits.restype = C.c_int64
+        lib.mm2o_collect_seed_hits.argtypes = [C.c_int64, vp, vp, C.c_int32, vp]
         _lib = lib
     return _lib
 
@@ -121,3 +123,17 @@ def mm_chain_dp(par, min_cnt, min_sc, anchors):
     b_np = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nb.value, 2)).copy()
     libc.free(u); libc.free(b)
     return u_np, b_np
+
+
+MATCH_DTYPE = np.dtype([("cr_off", "<i8"), ("n", "<u4"), ("q_pos", "<u4"), ("q_span", "<u4"), ("seg_tandem", "<u4")])   # mm2o_match_t / mm2c_match_t
+
+
+def collect_seed_hits(matches, hits, qlen):
+    """collect_seed_hits (map.c:215-247) of one read: matches (MATCH_DTYPE), hit pool (uint64) -> sorted anchors uint64 [n, 2]"""
+    m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+    h = np.ascontiguousarray(hits, dtype=np.uint64)
+    if m.size and int((m["cr_off"] + m["n"]).max()) > h.size:
+        raise ValueError("matches reach beyond the hit pool")
+    a = np.zeros((max(int(m["n"].sum()), 1), 2), np.uint64)
+    n = load().mm2o_collect_seed_hits(m.size, _ptr(m), _ptr(h), int(qlen), _ptr(a))
+    return a[:n]

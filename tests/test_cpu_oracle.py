@@ -220,3 +220,17 @@ def test_host_epilogue_of_the_library_equals_the_oracle_mm_chain_dp():
             for k in range(off.size - 1):
                 u_ref, b_ref = ob.mm_chain_dp(P, min_cnt, min_sc, a[off[k]:off[k + 1]])
                 assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), (profile, min_cnt, k)
+
+
+def test_seed_hits_oracle_equals_the_reference_anchor_lists():
+    """mm2o_collect_seed_hits (map.c:215-247 restated, incl. the unstable radix_sort_128x) on the matches of the committed fixture
+    against the anchor lists the reference's own map.o produced for the same reads (tests/golden/make_ref_seed_fixtures.py);
+    four of the reads contain anchors with equal x, where the order is that sort's"""
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz"))
+    n_ties = 0
+    for k in range(int(d["n_reads"])):
+        a = ob.collect_seed_hits(d[f"r{k}_matches"], d[f"r{k}_hits"], int(d[f"r{k}_qlen"]))
+        ref = d[f"r{k}_anchors"]
+        assert np.array_equal(a, ref), f"read {k} ({d[f'r{k}_src']}): anchors differ from the reference's"
+        n_ties += int((ref[1:, 0] == ref[:-1, 0]).sum())
+    assert n_ties > 1000
