@@ -160,6 +160,32 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
                                 const mm2c_anchor_t *h_anchors, int epilogue_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
                                 mm2c_anchor_t *b);
 
+/* ---- seed hits -> sorted anchors on the GPU (collect_seed_hits, map.c:215-247) ----
+ * One match = one query minimizer found in the index (mm_match_t, map.c:76-81, as collect_matches map.c:84-120 fills it); its hits
+ * are hits[cr_off .. cr_off + n) of a hit pool (the arrays mm_idx_get returns: rid<<32 | pos<<1 | strand).  The anchors of read r are
+ * written to anchors[anchor_off[r] .. anchor_off[r+1]) exactly as collect_seed_hits leaves them for mm_chain_dp (encoding map.c:232-241,
+ * order of radix_sort_128x including its order among equal x), ready for mm2c_plan_run_device with the same offsets.
+ * Covers the flag-free case (no MM_F_NO_DIAG / NO_DUAL / FOR_ONLY / REV_ONLY, skip_seed map.c:122-147), which is map-ont. */
+typedef struct {
+	int64_t cr_off;
+	uint32_t n;          /* mm_match_t.n */
+	uint32_t q_pos;      /* query position << 1 | strand (mm128_t.y low word of the minimizer) */
+	uint32_t q_span;     /* mm128_t.x & 0xff */
+	uint32_t seg_tandem; /* seg_id << 1 | is_tandem (map.c:112-115) */
+} mm2c_match_t;
+typedef struct mm2c_seedplan mm2c_seedplan_t;
+/* h_anchor_off[r+1] - h_anchor_off[r] must equal the sum of n over the matches of read r (checked on the device: mm2c_seedplan_check) */
+mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_off, const int64_t *h_anchor_off);
+void mm2c_seedplan_destroy(mm2c_seedplan_t *plan);
+/* asynchronous on `stream`; all pointers are device memory; d_anchors needs room for h_anchor_off[n_reads] anchors */
+int mm2c_seedplan_run_device(mm2c_seedplan_t *plan, const mm2c_match_t *d_matches, const uint64_t *d_hits, const int32_t *d_qlen,
+                             void *d_anchors, void *stream);
+int mm2c_seedplan_check(mm2c_seedplan_t *plan, int64_t *n_reads_with_ties);   /* waits; MM2C_E_ARG if a read's counts disagreed */
+int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
+/* host buffers in, anchors out (computes the anchor offsets itself): anchor_off[n_reads+1], anchors with room for the sum of all n */
+int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const mm2c_match_t *h_matches, const uint64_t *h_hits,
+                              int64_t n_hits, const int32_t *h_qlen, int64_t *anchor_off, mm2c_anchor_t *anchors);
+
 /* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
 typedef struct {
 	mm2c_params_t par;            /* scalars of the mm_chain_dp calls the tasks came from */

@@ -67,5 +67,23 @@ struct EpiArgs {
 size_t epilogue_sort_temp_bytes(int64_t total, int64_t n_tasks);
 hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launches);
 
+// ---- seed hits -> sorted anchors (collect_seed_hits, map.c:215-247), seed_hits.hip ----
+struct Match { int64_t cr_off; uint32_t n, q_pos, q_span, seg_tandem; };   // = mm2c_match_t
+struct SeedArgs {
+	int64_t n_reads;
+	const int64_t *d_match_off, *d_anchor_off;   // n_reads+1 each
+	const int32_t *d_order;                      // reads by anchor count, biggest first, or nullptr
+	const Match *d_matches;
+	const uint64_t *d_hits;                      // the hit pool the matches point into
+	const int32_t *d_qlen;
+	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
+	ulonglong2 *d_anchors;                       // out
+	int32_t *status, *has_ties;                  // per read; status must be zero on entry (1: hit counts and anchor offsets disagree)
+	int32_t *stack;                              // pending buckets of the tie replay: 3 * (total / 64 + 2 * n_reads + 2) ints
+	uint32_t *big_id; uint8_t *big_dg;           // replay arrays for reads too long for the LDS (nullptr when there is none)
+};
+int seed_tie_lds_max();
+hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches);
+
 } // namespace mm2c
 #endif

@@ -56,6 +56,12 @@ C_SYMBOLS = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_mm_chain_dp_batch_host": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_seedplan_create": (C.c_void_p, [C.c_int64, C.c_void_p, C.c_void_p]),
+    "mm2c_seedplan_destroy": (None, [C.c_void_p]),
+    "mm2c_seedplan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_seedplan_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mm2c_seedplan_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_get_stats": (None, [C.POINTER(Stats)]),
     "mm2c_stream_write": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_stream_read": (C.c_int, [C.c_char_p, C.POINTER(Stream)]),

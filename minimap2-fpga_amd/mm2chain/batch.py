@@ -237,6 +237,72 @@ def chain_epilogue_host(min_cnt, min_sc, offsets, anchors, f, p, n_threads=4):
     return _split_chains(n_tasks, u_off, u, b_off, b)
 
 
+MATCH_DTYPE = np.dtype([("cr_off", "<i8"), ("n", "<u4"), ("q_pos", "<u4"), ("q_span", "<u4"), ("seg_tandem", "<u4")])   # mm2c_match_t
+
+
+class SeedPlan:
+    """mm2c_seedplan_t: seed hits -> sorted anchors on the GPU (collect_seed_hits, map.c:215-247) for a batch of reads"""
+
+    def __init__(self, match_off, anchor_off):
+        self.lib = N.load()
+        mo = np.ascontiguousarray(np.asarray(match_off, dtype=np.int64)); ao = np.ascontiguousarray(np.asarray(anchor_off, dtype=np.int64))
+        assert mo.size == ao.size
+        self.n_reads, self.total = mo.size - 1, int(ao[-1] - ao[0])
+        self.handle = self.lib.mm2c_seedplan_create(self.n_reads, _np_ptr(mo), _np_ptr(ao))
+        if not self.handle:
+            N.check(-1, "mm2c_seedplan_create")
+
+    def run(self, matches: torch.Tensor, hits: torch.Tensor, qlen: torch.Tensor, anchors: torch.Tensor = None, stream=None):
+        """matches: uint8 view of mm2c_match_t records on the GPU; hits: int64 pool; qlen: int32 [n_reads]; returns anchors int64 [total, 2]"""
+        assert matches.is_cuda and hits.is_cuda and qlen.is_cuda and qlen.dtype == torch.int32 and qlen.numel() == self.n_reads
+        if anchors is None:
+            anchors = torch.empty((max(self.total, 1), 2), dtype=torch.int64, device=hits.device)
+        assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.numel() >= 2 * self.total
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.mm2c_seedplan_run_device(self.handle, matches.data_ptr(), hits.data_ptr(), qlen.data_ptr(), anchors.data_ptr(), st),
+                "mm2c_seedplan_run_device")
+        return anchors
+
+    def check(self):
+        """waits for the run; raises if a read's hit counts did not add up to its anchor range; returns the number of reads with equal x"""
+        n = C.c_int64(0)
+        N.check(self.lib.mm2c_seedplan_check(self.handle, C.byref(n)), "mm2c_seedplan_check")
+        return n.value
+
+    def last_ms(self):
+        ms = C.c_float(0)
+        N.check(self.lib.mm2c_seedplan_last_ms(self.handle, C.byref(ms)), "mm2c_seedplan_last_ms")
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            self.lib.mm2c_seedplan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def seed_hits_batch(match_off, matches, hits, qlen):
+    """mm2c_seed_hits_batch_host: returns (anchor_off int64 [n_reads+1], anchors uint64 [total, 2])"""
+    lib = N.load()
+    mo = np.ascontiguousarray(np.asarray(match_off, dtype=np.int64))
+    m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+    h = np.ascontiguousarray(hits, dtype=np.uint64)
+    q = np.ascontiguousarray(qlen, dtype=np.int32)
+    n_reads = mo.size - 1
+    if q.size != n_reads or mo[-1] > m.size or mo[0] < 0:
+        raise ValueError("offsets do not fit the arrays")
+    ao = np.zeros(n_reads + 1, np.int64)
+    a = np.zeros((max(int(m["n"][mo[0]:mo[-1]].sum()), 1), 2), np.uint64)
+    N.check(lib.mm2c_seed_hits_batch_host(n_reads, _np_ptr(mo), _np_ptr(m), _np_ptr(h), h.size, _np_ptr(q), _np_ptr(ao), _np_ptr(a)),
+            "mm2c_seed_hits_batch_host")
+    return ao, a[:ao[-1]]
+
+
 def hardware_init(buf_size=0, binary_name=b""):
     """the reference symbol bool hardware_init(long, char*) (chain_hardware.h:70)"""
     return bool(getattr(N.load(), "_Z13hardware_initlPc")(buf_size, binary_name))

@@ -1,0 +1,149 @@
+"""GPU parity tests of the seed-hit path: matches in, the anchor array collect_seed_hits (map.c:215-247)
+hands to mm_chain_dp out -- against anchor lists produced by the reference's own map.o (committed fixture) and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    import mm2chain
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    mm2chain.init()
+    yield
+    mm2chain.shutdown()
+
+
+def _batch(reads):
+    """reads: list of (qlen, matches with read-local cr_off, hits) -> one CSR batch with a shared hit pool"""
+    mo, ms, hs, ql, base = [0], [], [], [], 0
+    for qlen, m, hits in reads:
+        m = np.array(m, dtype=ob.MATCH_DTYPE, copy=True)
+        m["cr_off"] += base
+        base += hits.size
+        ms.append(m); hs.append(np.asarray(hits, np.uint64)); ql.append(qlen); mo.append(mo[-1] + m.size)
+    return (np.array(mo, np.int64), np.concatenate(ms) if ms else np.zeros(0, ob.MATCH_DTYPE),
+            np.concatenate(hs) if hs else np.zeros(0, np.uint64), np.array(ql, np.int32))
+
+
+def _random_read(rng, n_matches, max_n, rid_count, pos_range, qlen=12000, dup_frac=0.0):
+    """matches with random hit lists; a small pos_range or dup_frac > 0 (the same hit list under two query minimizers, as a repeat in
+    the query gives) makes anchors with equal x"""
+    m = np.zeros(n_matches, ob.MATCH_DTYPE)
+    m["n"] = rng.integers(0, max_n + 1, n_matches)
+    m["q_pos"] = (np.sort(rng.integers(15, qlen, n_matches)).astype(np.uint32) << 1) | rng.integers(0, 2, n_matches).astype(np.uint32)
+    m["q_span"] = 15
+    m["seg_tandem"] = rng.integers(0, 2, n_matches)
+    lists = []
+    for k in range(n_matches):
+        n = int(m["n"][k])
+        if k > 0 and dup_frac > 0 and rng.random() < dup_frac and lists[-1].size == n:
+            lists.append(lists[-1].copy())
+            continue
+        rid = rng.integers(0, rid_count, n).astype(np.uint64)
+        pos = np.sort(rng.integers(0, pos_range, n)).astype(np.uint64)
+        lists.append((rid << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, n).astype(np.uint64))
+    m["n"] = [x.size for x in lists]
+    m["cr_off"] = np.concatenate([[0], np.cumsum(m["n"].astype(np.int64))[:-1]])
+    return qlen, m, (np.concatenate(lists) if lists else np.zeros(0, np.uint64))
+
+
+def _check(reads, what):
+    import mm2chain
+    mo, m, h, ql = _batch(reads)
+    ao, a = mm2chain.seed_hits_batch(mo, m, h, ql)
+    n_ties = 0
+    for r, (qlen, mr, hr) in enumerate(reads):
+        ref = ob.collect_seed_hits(mr, hr, qlen)
+        got = a[ao[r]:ao[r + 1]]
+        assert got.shape == ref.shape, f"{what}: read {r}: {got.shape[0]} anchors, expected {ref.shape[0]}"
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert bad.size == 0, f"{what}: read {r}: {bad.size} of {ref.shape[0]} anchors differ, first at {bad[0]}"
+        n_ties += int((ref[1:, 0] == ref[:-1, 0]).sum())
+    return n_ties
+
+
+def test_anchor_lists_of_the_reference_map_o():
+    """every read of tests/golden/ref_seed_hits.npz (reference test FASTA pairs + synthetic genome with repeats; four reads with equal x,
+    where the order is radix_sort_128x's) through mm2c_seed_hits_batch_host, against what the reference's map.o gave mm_chain_dp"""
+    import mm2chain
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz"))
+    reads = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"]) for k in range(int(d["n_reads"]))]
+    mo, m, h, ql = _batch(reads)
+    ao, a = mm2chain.seed_hits_batch(mo, m, h, ql)
+    n_ties = 0
+    for k in range(len(reads)):
+        ref = d[f"r{k}_anchors"]
+        assert np.array_equal(a[ao[k]:ao[k + 1]], ref), f"read {k} ({d[f'r{k}_src']}): anchors differ from the reference's"
+        n_ties += int((ref[1:, 0] == ref[:-1, 0]).sum())
+    assert n_ties > 1000
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_matches_against_the_oracle(seed):
+    rng = np.random.default_rng(500 + seed)
+    reads = [_random_read(rng, 900, 6, 3, 1 << 26),                       # no ties to speak of
+             _random_read(rng, 700, 8, 2, 3000),                          # many equal x, several thousand anchors
+             _random_read(rng, 40, 3, 1, 50),                             # <= 64 anchors with ties (insertion sort only)
+             _random_read(rng, 0, 0, 1, 10),                              # a read without matches
+             _random_read(rng, 300, 0, 1, 10),                            # matches without hits
+             _random_read(rng, 1500, 5, 24, 1 << 27, dup_frac=0.3),       # duplicated hit lists: pairs of equal x across the genome
+             _random_read(rng, 100, 2, 1, 1 << 20),
+             _random_read(rng, 2000, 3, 2, 200)]                          # nearly everything ties
+    assert _check(reads, f"seed {seed}") > 1000
+
+
+def test_reads_too_long_for_the_lds_replay():
+    """more than 12 288 anchors with equal x: the replay runs through global memory"""
+    rng = np.random.default_rng(77)
+    reads = [_random_read(rng, 4000, 8, 2, 20000, qlen=60000), _random_read(rng, 3000, 10, 1, 1 << 24, qlen=60000, dup_frac=0.2)]
+    assert reads[0][1]["n"].sum() > 12288 and reads[1][1]["n"].sum() > 12288
+    assert _check(reads, "long") > 1000
+
+
+def test_anchor_offsets_that_do_not_match_the_hit_counts_are_reported():
+    import mm2chain
+    rng = np.random.default_rng(3)
+    qlen, m, h = _random_read(rng, 50, 4, 1, 1 << 20)
+    mo = np.array([0, m.size], np.int64)
+    ao = np.array([0, int(m["n"].sum()) + 3], np.int64)
+    plan = mm2chain.SeedPlan(mo, ao)
+    d_m = torch.from_numpy(m.view(np.uint8)).cuda(); d_h = torch.from_numpy(h.view(np.int64)).cuda()
+    d_q = torch.tensor([qlen], dtype=torch.int32, device="cuda")
+    plan.run(d_m, d_h, d_q)
+    with pytest.raises(mm2chain.Mm2cError):
+        plan.check()
+    plan.close()
+
+
+def test_seeds_to_chains_without_leaving_the_device():
+    """matches -> anchors -> f/p -> chains on the GPU (SeedPlan, ChainPlan.run, ChainPlan.chains on one stream) against the oracle's
+    collect_seed_hits + mm_chain_dp per read"""
+    import mm2chain
+    from mm2chain import params
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz"))
+    reads = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"]) for k in range(int(d["n_reads"]))]
+    mo, m, h, ql = _batch(reads)
+    ao = np.concatenate([[0], np.cumsum([int(r[1]["n"].sum()) for r in reads])]).astype(np.int64)
+    P = params.map_ont()
+    sp = mm2chain.SeedPlan(mo, ao)
+    cp = mm2chain.ChainPlan(P, ao)
+    d_a = sp.run(torch.from_numpy(m.view(np.uint8)).cuda(), torch.from_numpy(h.view(np.int64)).cuda(), torch.from_numpy(ql).cuda())
+    d_f = torch.empty(int(ao[-1]), dtype=torch.int32, device="cuda"); d_p = torch.empty_like(d_f)
+    cp.run(d_a, d_f, d_p)
+    u_off, u, b_off, b = cp.chains(d_a, d_f, d_p, 3, 40)
+    torch.cuda.synchronize()
+    assert sp.check() >= 4 and sp.last_ms() > 0
+    uo, bo = u_off.cpu().numpy(), b_off.cpu().numpy()
+    u, b = u.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64)
+    for k in range(len(reads)):
+        u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, d[f"r{k}_anchors"])
+        assert np.array_equal(u[uo[k]:uo[k + 1]], u_ref) and np.array_equal(b[bo[k]:bo[k + 1]], b_ref), f"read {k}: chains differ"
+    sp.close(); cp.close()
