@@ -79,11 +79,14 @@ struct SeedArgs {
 	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
 	ulonglong2 *d_anchors;                       // out
 	int32_t *status, *has_ties;                  // per read; status must be zero on entry (1: hit counts and anchor offsets disagree)
-	int32_t *stack;                              // pending buckets of the tie replay: 3 * (total / 64 + 2 * n_reads + 2) ints
+	int32_t *tiecnt;                             // per anchor: equal-x neighbours before this position of the sorted read
+	int64_t biggest;                             // anchors of the longest read
+	int32_t *stack;                              // pending buckets of the tie replay: 2 * (total / 64 + 2 * n_reads + 2) ints
 	uint32_t *big_id; uint8_t *big_dg;           // replay arrays for reads too long for the LDS (nullptr when there is none)
 };
 int seed_tie_lds_max();
-hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches);
+// aux: three helper streams (or nullptr: everything on st), ev: four events without timing
+hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev);
 
 } // namespace mm2c
 #endif

@@ -468,6 +468,8 @@ struct mm2c_seedplan {
 	char *d_mem = nullptr;                 // [match_off | anchor_off | order | status | has_ties | stack | unsorted | scratch | big_id | big_dg]
 	mm2c::SeedArgs S;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipStream_t aux[3] = {};               // helper streams: the size classes of the tie replay run side by side
+	hipEvent_t fork[4] = {};
 	bool ran = false;
 };
 
@@ -493,7 +495,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	size_t at = 0;
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
-	             o_stack = take(3 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16),
+	             o_stack = take(2 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4),
 	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1);
 	hipError_t e = hipSetDevice(G.device);
 	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_mem, at);
@@ -507,11 +509,20 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	}
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
+	{	// helper streams on hardware queues of their own: different priorities never share a queue (see create_partner_stream)
+		int least = 0, greatest = 0;
+		if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+		const int prio[3] = { greatest, least, (least + greatest) / 2 };
+		for (int i = 0; i < 3 && e == hipSuccess; ++i)
+			e = least != greatest ? hipStreamCreateWithPriority(&pl->aux[i], hipStreamNonBlocking, prio[i]) : hipStreamCreateWithFlags(&pl->aux[i], hipStreamNonBlocking);
+	}
+	for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pl->fork[i], hipEventDisableTiming);
 	if (e != hipSuccess) { fail(MM2C_E_HIP, "mm2c_seedplan_create: %s", hipGetErrorString(e)); mm2c_seedplan_destroy(pl); return nullptr; }
 	mm2c::SeedArgs &S = pl->S;
 	char *b = pl->d_mem;
 	S.n_reads = n_reads; S.d_match_off = (const int64_t *)(b + o_moff); S.d_anchor_off = (const int64_t *)(b + o_aoff);
 	S.d_order = (const int32_t *)(b + o_ord); S.status = (int32_t *)(b + o_stat); S.has_ties = (int32_t *)(b + o_ties);
+	S.tiecnt = (int32_t *)(b + o_tc); S.biggest = biggest;
 	S.stack = (int32_t *)(b + o_stack); S.unsorted = (ulonglong2 *)(b + o_un); S.scratch = (ulonglong2 *)(b + o_scr);
 	S.big_id = big ? (uint32_t *)(b + o_bid) : nullptr; S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
 	return pl;
@@ -522,6 +533,8 @@ void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
 	if (!pl) return;
 	if (pl->d_mem) (void)hipFree(pl->d_mem);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+	for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
+	for (int i = 0; i < 4; ++i) if (pl->fork[i]) (void)hipEventDestroy(pl->fork[i]);
 	delete pl;
 }
 
@@ -540,7 +553,7 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	HIP_TRY(hipMemsetAsync(S.has_ties, 0, (size_t)pl->n_reads * 4, st));
 	HIP_TRY(hipEventRecord(pl->ev0, st));
 	int nl = 0;
-	HIP_TRY(mm2c::launch_seed_hits(S, st, &nl));
+	HIP_TRY(mm2c::launch_seed_hits(S, st, &nl, pl->aux, pl->fork));
 	HIP_TRY(hipEventRecord(pl->ev1, st));
 	pl->ran = true;
 	G.launches += (uint64_t)nl;

@@ -86,19 +86,30 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 }
 
 // ---- stable LSD radix sort of one read's anchors on x by one wave; the result ends in `dst` ------------------------
-__device__ void wave_sort_anchors(ulonglong2 *src, ulonglong2 *dst, int n, int lane, int *s_cnt /* 256 ints of LDS */)
+// `src` is only read; the passes write alternately to `alt` and `dst`, arranged so that the last one writes `dst` (alt may be src)
+__device__ void wave_sort_anchors(const ulonglong2 *src, ulonglong2 *alt, ulonglong2 *dst, int n, int lane, int *s_cnt /* 256 ints of LDS */)
 {
 	if (n <= 0) return;
 	uint64_t diff = 0;
 	const uint64_t first = src[0].x;
 	for (int i = lane; i < n; i += 64) diff |= src[i].x ^ first;
 	diff = wave_or(diff);
-	ulonglong2 *from = src, *to = dst;
+	int passes = 0;
+	for (int shift = 0; shift < 64; shift += 8) passes += ((diff >> shift) & 255) != 0;
+	if (passes == 0) { if (src != dst) for (int i = lane; i < n; i += 64) dst[i] = src[i]; __syncthreads(); return; }
+	const ulonglong2 *from = src;
+	ulonglong2 *to = (passes & 1) ? dst : alt;                                   // an odd number of passes: dst, alt, dst, ...
 	for (int shift = 0; shift < 64; shift += 8) {
 		if (((diff >> shift) & 255) == 0) continue;
 		for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
 		__syncthreads();
-		for (int i = lane; i < n; i += 64) atomicAdd(&s_cnt[(int)(from[i].x >> shift) & 255], 1);
+		for (int i0 = 0; i0 < n; i0 += 256) {                                    // four loads in flight per lane
+			uint64_t x[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int i = i0 + 64 * k + lane; x[k] = i < n ? from[i].x : 0; }
+#pragma unroll
+			for (int k = 0; k < 4; ++k) if (i0 + 64 * k + lane < n) atomicAdd(&s_cnt[(int)(x[k] >> shift) & 255], 1);
+		}
 		__syncthreads();
 		{
 			int h[4], sum = 0;
@@ -110,27 +121,30 @@ __device__ void wave_sort_anchors(ulonglong2 *src, ulonglong2 *dst, int n, int l
 			for (int k = 0; k < 4; ++k) { s_cnt[4 * lane + k] = at; at += h[k]; }
 		}
 		__syncthreads();
-		for (int i0 = 0; i0 < n; i0 += 64) {
-			const int i = i0 + lane;
-			const bool valid = i < n;
-			ulonglong2 rec = {};
-			if (valid) rec = from[i];
-			const int d = (int)(rec.x >> shift) & 255;
-			uint64_t peers = __ballot(valid);
+		for (int i0 = 0; i0 < n; i0 += 256) {                                    // 256 records per step: one round trip to memory for four chunks
+			ulonglong2 rec[4];
 #pragma unroll
-			for (int b = 0; b < 8; ++b) {
-				const uint64_t bal = __ballot((d >> b) & 1);
-				peers &= ((d >> b) & 1) ? bal : ~bal;
+			for (int k = 0; k < 4; ++k) { const int i = i0 + 64 * k + lane; rec[k] = ulonglong2{0, 0}; if (i < n) rec[k] = from[i]; }
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const bool valid = i0 + 64 * k + lane < n;
+				const int d = (int)(rec[k].x >> shift) & 255;
+				uint64_t peers = __ballot(valid);
+#pragma unroll
+				for (int b = 0; b < 8; ++b) {
+					const uint64_t bal = __ballot((d >> b) & 1);
+					peers &= ((d >> b) & 1) ? bal : ~bal;
+				}
+				const int rank = lanes_before(peers);
+				if (valid) to[s_cnt[d] + rank] = rec[k];
+				__syncthreads();
+				if (valid && rank == 0) s_cnt[d] += __popcll(peers);
+				__syncthreads();
 			}
-			const int rank = lanes_before(peers);
-			if (valid) to[s_cnt[d] + rank] = rec;
-			__syncthreads();
-			if (valid && rank == 0) s_cnt[d] += __popcll(peers);
-			__syncthreads();
 		}
-		{ ulonglong2 *t = from; from = to; to = t; }
+		from = to;
+		to = to == dst ? alt : dst;
 	}
-	if (from != dst) for (int i = lane; i < n; i += 64) dst[i] = from[i];
 	__syncthreads();
 }
 
@@ -143,50 +157,55 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	const int64_t a0 = A.d_anchor_off[read];
 	const int na = (int)(A.d_anchor_off[read + 1] - a0);
 	if (A.status[read] != 0) return;
-	// the unsorted array must survive (the replay of kernel 3 starts from it): sort a copy
-	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
-	for (int i = lane; i < na; i += 64) tmp[i] = un[i];
-	__syncthreads();
-	wave_sort_anchors(tmp, out, na, lane, s_cnt);
-	bool tie = false;
-	for (int i = lane; i + 1 < na; i += 64) tie |= out[i].x == out[i + 1].x;
-	if (lane == 0) A.has_ties[read] = 0;
-	if (__ballot(tie) && lane == 0) A.has_ties[read] = 1;
+	// the unsorted array must survive (the replay of kernel 3 starts from it): it is only read
+	const ulonglong2 *un = A.unsorted + a0;
+	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + a0;
+	wave_sort_anchors(un, tmp, out, na, lane, s_cnt);
+	// tiecnt[i] = number of positions j < i with x[j] == x[j+1]: tells in O(1) whether a range of positions (= a bucket of the
+	// reference's sort, before and after it) holds equal keys
+	int32_t *tiecnt = A.tiecnt + a0;
+	int run = 0;
+	for (int i0 = 0; i0 < na; i0 += 64) {
+		const int i = i0 + lane;
+		const int flag = (i + 1 < na && out[i].x == out[i + 1].x) ? 1 : 0;
+		const int incl = wave_incl_scan(flag, lane);
+		if (i < na) tiecnt[i] = run + incl - flag;
+		run += __shfl(incl, 63);
+	}
+	if (lane == 0) A.has_ties[read] = run > 0;
 }
 
 // ---- kernel 3: replay of radix_sort_128x for reads with equal x ----------------------------------------------------
 // The arrangement is an index array id[] (position -> anchor of the unsorted array) with the current digit dg[] beside it.
 template <typename IdT>
-__device__ void replay_passes(const ulonglong2 *un, const ulonglong2 *sorted, int n, IdT *id, uint8_t *dg, int32_t *stack, int lane,
-                              int *s_cur, int *s_lo, int *s_hi, int *s_sp)
+__device__ void replay_passes(const ulonglong2 *un, const ulonglong2 *sorted, const int32_t *tiecnt, int n, IdT *id, uint8_t *dg, int32_t *stack,
+                              int32_t *work, int lane, int *s_cur, int *s_lo, int *s_hi, int *s_sp)
 {
 	for (int i = lane; i < n; i += 64) id[i] = (IdT)i;
-	if (lane == 0) { stack[0] = 0; stack[1] = n; stack[2] = 56; *s_sp = 1; }
+	if (lane == 0) { stack[0] = 0; stack[1] = n; *s_sp = 1; }                  // only buckets that hold equal keys are ever pushed
 	for (;;) {
 		__syncthreads();
 		const int sp = *s_sp;
 		if (sp == 0) break;
-		const int lo = stack[3 * sp - 3], hi = stack[3 * sp - 2];
-		int shift = stack[3 * sp - 1];
+		const int lo = stack[2 * sp - 2], hi = stack[2 * sp - 1];
 		__syncthreads();
 		if (lane == 0) *s_sp = sp - 1;
-		// a bucket is a range of positions, before and after the sort: equal keys inside it show in the sorted output
-		bool tie = false;
-		for (int q = lo + lane; q + 1 < hi; q += 64) tie |= sorted[q].x == sorted[q + 1].x;
-		if (!__ballot(tie)) continue;                                            // all keys differ: the order inside is the sorted one
-		const uint64_t x0 = un[id[lo]].x;
-		uint64_t diff = 0;
-		for (int q = lo + lane; q < hi; q += 64) diff |= un[id[q]].x ^ x0;
-		diff = wave_or(diff);
-		if (shift < 56) diff &= (1ull << (shift + 8)) - 1;
-		if (diff == 0) continue;                                                 // equal from this byte down: every later pass is a no-op
-		shift = (63 - __clzll(diff)) & ~7;                                       // passes above it move nothing (one bucket each)
+		// the keys of a bucket are the keys of the same positions of the sorted array: smallest and largest differ first in the
+		// highest byte in which any two differ; the passes above that byte move nothing (one bucket each, ksort.h:117-131)
+		const uint64_t diff = sorted[lo].x ^ sorted[hi - 1].x;
+		if (diff == 0) continue;                                                 // all equal: every pass is a no-op
+		const int shift = (63 - __clzll(diff)) & ~7;
 		for (int d = lane; d < 256; d += 64) s_cur[d] = 0;
 		__syncthreads();
-		for (int q = lo + lane; q < hi; q += 64) {
-			const int d = (int)(un[id[q]].x >> shift) & 255;
-			dg[q] = (uint8_t)d;
-			atomicAdd(&s_cur[d], 1);
+		for (int q0 = lo; q0 < hi; q0 += 256) {                                  // four gathers in flight per lane
+			uint64_t x[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; x[k] = q < hi ? un[id[q]].x : 0; }
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = q0 + 64 * k + lane;
+				if (q < hi) { const int d = (int)(x[k] >> shift) & 255; dg[q] = (uint8_t)d; atomicAdd(&s_cur[d], 1); }
+			}
 		}
 		__syncthreads();
 		{
@@ -199,7 +218,47 @@ __device__ void replay_passes(const ulonglong2 *un, const ulonglong2 *sorted, in
 			for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; s_cur[4 * lane + k] = at; at += h[k]; s_hi[4 * lane + k] = at; }
 		}
 		__syncthreads();
-		if (lane == 0) {                                                         // ksort.h:117-131
+		int n_buckets = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) n_buckets += s_hi[4 * lane + k] > s_lo[4 * lane + k];
+		for (int o = 32; o > 0; o >>= 1) n_buckets += __shfl_xor(n_buckets, o);
+		if (n_buckets == 2) {
+			// Two buckets A | B (the strand byte, often the top position byte): the distribution has a closed form, no lane has to walk.
+			// Bucket A is filled first (ksort.h:118).  Its t-th misplaced record starts a cycle: it is dropped at B's cursor, the records
+			// of B that follow are pushed one place on until B's t-th misplaced record falls out, and that one comes back to the slot the
+			// cycle started from.  So A's misplaced slot t gets B's t-th misplaced record; in B the t-th record from A lands right after
+			// B's misplaced slot t-1 (at B's start for t = 0) and the B-records before misplaced slot t move one place up.
+			const int da = (int)(sorted[lo].x >> shift) & 255, db = (int)(sorted[hi - 1].x >> shift) & 255;
+			const int mid = s_hi[da], sz = hi - lo, half = (sz + 1) / 2 + 1;
+			int32_t *g = work + 4 * (int64_t)lo;                                // 4 ints of scratch per position of the bucket
+			int32_t *fposA = g, *fidA = g + half, *fposB = g + 2 * half, *fidB = g + 3 * half, *newB = g + 4 * half;
+			int F = 0;
+			for (int q0 = lo; q0 < mid; q0 += 64) {
+				const int q = q0 + lane;
+				const bool foreign = q < mid && dg[q] != da;
+				const uint64_t m = __ballot(foreign);
+				if (foreign) { const int t = F + lanes_before(m); fposA[t] = q; fidA[t] = (int32_t)id[q]; }
+				F += __popcll(m);
+			}
+			int FB = 0;
+			for (int q0 = mid; q0 < hi; q0 += 64) {
+				const int q = q0 + lane;
+				const bool in = q < hi, foreign = in && dg[q] != db;
+				const uint64_t m = __ballot(foreign);
+				const int t = FB + lanes_before(m);                              // misplaced slots of B before q
+				if (foreign) { fposB[t] = q; fidB[t] = (int32_t)id[q]; }
+				else if (in) newB[q + (t < F ? 1 : 0) - mid] = (int32_t)id[q];
+				FB += __popcll(m);
+			}
+			__syncthreads();
+			for (int t = lane; t < F; t += 64) {
+				id[fposA[t]] = (IdT)fidB[t];
+				newB[(t == 0 ? mid : fposB[t - 1] + 1) - mid] = fidA[t];
+			}
+			__syncthreads();
+			for (int q = mid + lane; q < hi; q += 64) id[q] = (IdT)newB[q - mid];
+			__syncthreads();
+		} else if (lane == 0) {                                                  // ksort.h:117-131
 			for (int d = 0; d < 256; ) {
 				const int bl = s_cur[d];
 				if (bl == s_hi[d]) { ++d; continue; }
@@ -219,47 +278,55 @@ __device__ void replay_passes(const ulonglong2 *un, const ulonglong2 *sorted, in
 		if (shift == 0) continue;                                                // ksort.h:132
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const int d = 4 * lane + k;
-			if (s_hi[d] - s_lo[d] > 64) {                                       // ksort.h:143; smaller ones: insertion sort = the final stable sort
+			const int d = 4 * lane + k, bl = s_lo[d], bh = s_hi[d];
+			// ksort.h:143: buckets of more than 64 records get the next pass (smaller ones an insertion sort = the final stable sort);
+			// those without equal keys end up in their one sorted order whatever happens inside
+			if (bh - bl > 64 && tiecnt[bh - 1] - tiecnt[bl] > 0) {
 				const int slot = atomicAdd(s_sp, 1);
-				stack[3 * slot] = s_lo[d]; stack[3 * slot + 1] = s_hi[d]; stack[3 * slot + 2] = shift - 8;
+				stack[2 * slot] = bl; stack[2 * slot + 1] = bh;
 			}
 		}
 	}
 }
 
-constexpr int TIE_LDS_MAX = 12288;   // anchors of a read whose replay runs in LDS (3 bytes each)
+// The replay of a read needs 3 bytes of LDS per anchor; four size classes keep the occupancy of the common (short) reads high.
+// CAP = 0: reads beyond the largest class, arrays in global memory.
+constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 20480;   // the last one: 60 of the 64 KB a block may take
 
+template <int CAP, int PREV>
 __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 {
-	__shared__ uint16_t s_id[TIE_LDS_MAX];
-	__shared__ uint8_t s_dg[TIE_LDS_MAX];
+	__shared__ uint16_t s_id[CAP ? CAP : 1];
+	__shared__ uint8_t s_dg[CAP ? CAP : 1];
 	__shared__ int s_cur[256], s_lo[256], s_hi[256], s_sp;
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
 	const int lane = (int)threadIdx.x;
 	const int64_t a0 = A.d_anchor_off[read];
 	const int na = (int)(A.d_anchor_off[read + 1] - a0);
-	if (na <= 64) return;                                                        // insertion sort only: stable (ksort.h:149)
+	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
-	int32_t *stack = A.stack + 3 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice
-	if (na <= TIE_LDS_MAX) {
-		replay_passes<uint16_t>(un, out, na, s_id, s_dg, stack, lane, s_cur, s_lo, s_hi, &s_sp);
+	int32_t *stack = A.stack + 2 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice
+	if (CAP) {
+		replay_passes<uint16_t>(un, out, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
+#pragma unroll 4
 		for (int i = lane; i < na; i += 64) tmp[i] = un[s_id[i]];
-	} else {                                                                     // does not fit the LDS: same replay through global memory
+	} else {
 		uint32_t *g_id = A.big_id + a0; uint8_t *g_dg = A.big_dg + a0;
-		replay_passes<uint32_t>(un, out, na, g_id, g_dg, stack, lane, s_cur, s_lo, s_hi, &s_sp);
+		replay_passes<uint32_t>(un, out, A.tiecnt + a0, na, g_id, g_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
 		for (int i = lane; i < na; i += 64) tmp[i] = un[g_id[i]];
 	}
 	__syncthreads();
-	wave_sort_anchors(tmp, out, na, lane, s_cur);                                // stable: keeps the replayed order among equal x
+	wave_sort_anchors(tmp, un, out, na, lane, s_cur);                            // stable: keeps the replayed order among equal x; `un` is free now
 }
 
 } // namespace
 
-int seed_tie_lds_max() { return TIE_LDS_MAX; }
+int seed_tie_lds_max() { return TIE_CAP3; }
 
-hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches)
+// The tie replay of one read is a long dependent chain on one wave, so each size class ends in a tail of a few long reads; the classes
+// handle disjoint reads and run side by side on the caller's stream and three helper streams (fork after the sort, join at the end).
+hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev)
 {
 	if (A.n_reads <= 0) return hipSuccess;
 	const unsigned nr = (unsigned)A.n_reads;
@@ -268,9 +335,34 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches)
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(seed_sort, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	hipLaunchKernelGGL(seed_ties, dim3(nr), dim3(64), 0, st, A);
-	if (n_launches) *n_launches += 3;
-	return hipGetLastError();
+	if (n_launches) *n_launches += 2;
+	// the grid is in order of decreasing read length: each class covers a contiguous range of blocks, the others exit at once
+	const bool use[5] = { true, A.biggest > TIE_CAP0, A.biggest > TIE_CAP1, A.biggest > TIE_CAP2, A.biggest > TIE_CAP3 };
+	if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+	int helper = 0;
+	for (int c = 4; c >= 0; --c) {                                              // the longest reads first
+		if (!use[c]) continue;
+		hipStream_t s = st;
+		if (c != 0 && aux && helper < 3) {                                       // class 0 (and whatever exceeds the helpers) stays on the caller's stream
+			s = aux[helper];
+			if ((e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e;
+		}
+		switch (c) {
+		case 4: hipLaunchKernelGGL((seed_ties<0, TIE_CAP3>), dim3(nr), dim3(64), 0, s, A); break;
+		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2>), dim3(nr), dim3(64), 0, s, A); break;
+		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1>), dim3(nr), dim3(64), 0, s, A); break;
+		case 1: hipLaunchKernelGGL((seed_ties<TIE_CAP1, TIE_CAP0>), dim3(nr), dim3(64), 0, s, A); break;
+		default: hipLaunchKernelGGL((seed_ties<TIE_CAP0, 0>), dim3(nr), dim3(64), 0, s, A); break;
+		}
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (n_launches) ++*n_launches;
+		if (s != st) {
+			if ((e = hipEventRecord(ev[1 + helper], s)) != hipSuccess) return e;
+			if ((e = hipStreamWaitEvent(st, ev[1 + helper], 0)) != hipSuccess) return e;
+			++helper;
+		}
+	}
+	return hipSuccess;
 }
 
 } // namespace mm2c
