@@ -110,6 +110,13 @@ got = d_a[: int(ao[4])].cpu().numpy().view(np.uint64)
 for k in range(4):
     mk = ms[k].copy(); mk["cr_off"] -= ao[k]
     ok = ok and np.array_equal(got[ao[k]:ao[k + 1]], ob.collect_seed_hits(mk, hs[k], qlens[k]))
+# CPU baseline beside it: the oracle's collect_seed_hits (expansion + radix_sort_128x restated) on one host core, distinct reads only
+t0 = time.perf_counter(); n_cpu = 0
+for k in range(min(distinct, 256)):
+    mk = ms[k].copy(); mk["cr_off"] -= ao[k]
+    n_cpu += ob.collect_seed_hits(mk, hs[k], qlens[k]).shape[0]
+t_cpu = time.perf_counter() - t0
+print(f"CPU oracle, 1 thread (incl. the ctypes call per read): {n_cpu / t_cpu / 1e6:.1f} M anchors/s")
 print(f"seed hits -> anchors: {sp.last_ms():.2f} ms (wall {t_seed*1e3:.2f}) = {total / (sp.last_ms()*1e-3) / 1e9:.2f} G anchors/s; reads with equal x: {n_ties} of {n_reads}; first reads equal the oracle: {ok}")
 print(f"matches -> anchors -> f/p -> chains on the device: {t_all*1e3:.2f} ms = {total / t_all / 1e9:.3f} G anchors/s (DP {cp.last_kernel_ms():.2f} + prepass {cp.last_prepass_ms():.2f} + epilogue {cp.last_epilogue_ms():.2f} ms); "
       f"input {mt.nbytes / total:.1f} B of matches + {ht.nbytes / total:.1f} B of hits per anchor")
