@@ -186,6 +186,13 @@ int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
 int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const mm2c_match_t *h_matches, const uint64_t *h_hits,
                               int64_t n_hits, const int32_t *h_qlen, int64_t *anchor_off, mm2c_anchor_t *anchors);
 
+/* matches in, chains out: collect_seed_hits + mm_chain_dp for a batch of reads (map.c:295-316) with the anchors staying on the GPU.
+ * anchor_off[n_reads+1] is filled with the anchor counts' prefix sums (= the sum of n per read); u / b as mm2c_mm_chain_dp_batch_host
+ * (room for one entry per anchor of the batch). */
+int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                               const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const int32_t *h_qlen,
+                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b);
+
 /* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
 typedef struct {
 	mm2c_params_t par;            /* scalars of the mm_chain_dp calls the tasks came from */

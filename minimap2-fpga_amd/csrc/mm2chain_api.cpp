@@ -632,6 +632,70 @@ int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const
 	return rc;
 }
 
+// matches in, chains out: collect_seed_hits + mm_chain_dp for a batch of reads (map.c:295-316) without the anchors leaving the GPU
+int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                               const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const int32_t *h_qlen,
+                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b)
+{
+	int rc;
+	if ((rc = check_params(par))) return rc;
+	if (n_reads < 0 || !anchor_off || !u_off || !b_off) return fail(MM2C_E_ARG, "bad argument");
+	anchor_off[0] = 0; u_off[0] = b_off[0] = 0;
+	if (n_reads == 0) return 0;
+	if (!h_match_off || !h_qlen) return fail(MM2C_E_ARG, "host pointer is NULL");
+	const int64_t mb = h_match_off[0], n_m = h_match_off[n_reads] - mb;
+	if (n_m > 0 && !h_matches) return fail(MM2C_E_ARG, "matches is NULL");
+	for (int64_t r = 0; r < n_reads; ++r) {
+		int64_t sum = 0;
+		if (h_match_off[r + 1] < h_match_off[r]) return fail(MM2C_E_ARG, "match offsets not monotone at read %lld", (long long)r);
+		for (int64_t i = h_match_off[r]; i < h_match_off[r + 1]; ++i) {
+			if (h_matches[i].cr_off < 0 || h_matches[i].cr_off + (int64_t)h_matches[i].n > n_hits)
+				return fail(MM2C_E_ARG, "match %lld reaches beyond the hit pool", (long long)i);
+			sum += h_matches[i].n;
+		}
+		anchor_off[r + 1] = anchor_off[r] + sum;
+	}
+	const int64_t total = anchor_off[n_reads];
+	if (total == 0) { for (int64_t r = 1; r <= n_reads; ++r) u_off[r] = b_off[r] = 0; return 0; }
+	if (!h_hits || !u || !b) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch of %lld anchors; the limit of one call is 2^31-1", (long long)total);
+	mm2c_seedplan_t *sp = mm2c_seedplan_create(n_reads, h_match_off, anchor_off);
+	if (!sp) return MM2C_E_HIP;
+	mm2c_plan_t *pl = mm2c_plan_create(par, n_reads, anchor_off);
+	if (!pl) { mm2c_seedplan_destroy(sp); return MM2C_E_HIP; }
+	char *d = nullptr;
+	size_t at = 0;
+	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+	const size_t nr = (size_t)n_reads, tot = (size_t)total;
+	const size_t o_m = take((size_t)n_m * sizeof(mm2c_match_t)), o_h = take((size_t)n_hits * 8), o_q = take(nr * 4), o_a = take(tot * 16),
+	             o_f = take(tot * 4), o_p = take(tot * 4), o_uo = take((nr + 1) * 8), o_bo = take((nr + 1) * 8), o_u = take(tot * 8), o_b = take(tot * 16);
+	hipStream_t st = G.stream;
+	auto body = [&]() -> int {
+		int r;
+		HIP_TRY(hipMalloc((void **)&d, at));
+		HIP_TRY(hipMemcpyAsync(d + o_m, h_matches + mb, (size_t)n_m * sizeof(mm2c_match_t), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d + o_h, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d + o_q, h_qlen, nr * 4, hipMemcpyHostToDevice, st));
+		if ((r = mm2c_seedplan_run_device(sp, (const mm2c_match_t *)(d + o_m), (const uint64_t *)(d + o_h), (const int32_t *)(d + o_q), d + o_a, st))) return r;
+		if ((r = mm2c_plan_run_device(pl, d + o_a, nullptr, (int32_t *)(d + o_f), (int32_t *)(d + o_p), st))) return r;
+		if ((r = mm2c_plan_chains_device(pl, d + o_a, (int32_t *)(d + o_f), (int32_t *)(d + o_p), min_cnt, min_sc, (int64_t *)(d + o_uo), (uint64_t *)(d + o_u),
+		                                 (int64_t *)(d + o_bo), d + o_b, st))) return r;
+		HIP_TRY(hipMemcpyAsync(u_off, d + o_uo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(b_off, d + o_bo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (u_off[nr] > 0) HIP_TRY(hipMemcpyAsync(u, d + o_u, (size_t)u_off[nr] * 8, hipMemcpyDeviceToHost, st));
+		if (b_off[nr] > 0) HIP_TRY(hipMemcpyAsync(b, d + o_b, (size_t)b_off[nr] * 16, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		return mm2c_seedplan_check(sp, nullptr);
+	};
+	rc = body();
+	if (d) (void)hipFree(d);
+	mm2c_plan_destroy(pl);
+	mm2c_seedplan_destroy(sp);
+	G.passes += 1;
+	return rc;
+}
+
 // ------------------------------------------------------------------------------------------------ host-buffer paths
 } // extern "C"
 

@@ -62,6 +62,8 @@ C_SYMBOLS = {
     "mm2c_seedplan_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mm2c_seedplan_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_seed_chain_batch_host": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_get_stats": (None, [C.POINTER(Stats)]),
     "mm2c_stream_write": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_stream_read": (C.c_int, [C.c_char_p, C.POINTER(Stream)]),

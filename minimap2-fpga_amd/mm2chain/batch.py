@@ -303,6 +303,24 @@ def seed_hits_batch(match_off, matches, hits, qlen):
     return ao, a[:ao[-1]]
 
 
+def seed_chain_batch(params: Params, min_cnt, min_sc, match_off, matches, hits, qlen):
+    """mm2c_seed_chain_batch_host: matches in, per-read chains out [(u, b), ...] (anchors never leave the GPU)"""
+    lib = N.load()
+    mo = np.ascontiguousarray(np.asarray(match_off, dtype=np.int64))
+    m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+    h = np.ascontiguousarray(hits, dtype=np.uint64)
+    q = np.ascontiguousarray(qlen, dtype=np.int32)
+    n_reads = mo.size - 1
+    if q.size != n_reads or mo[-1] > m.size or mo[0] < 0:
+        raise ValueError("offsets do not fit the arrays")
+    total = max(int(m["n"][mo[0]:mo[-1]].sum()), 1)
+    ao = np.zeros(n_reads + 1, np.int64); u_off = np.zeros(n_reads + 1, np.int64); b_off = np.zeros(n_reads + 1, np.int64)
+    u = np.zeros(total, np.uint64); b = np.zeros((total, 2), np.uint64)
+    N.check(lib.mm2c_seed_chain_batch_host(C.byref(params), min_cnt, min_sc, n_reads, _np_ptr(mo), _np_ptr(m), _np_ptr(h), h.size, _np_ptr(q),
+                                           _np_ptr(ao), _np_ptr(u_off), _np_ptr(u), _np_ptr(b_off), _np_ptr(b)), "mm2c_seed_chain_batch_host")
+    return _split_chains(n_reads, u_off, u, b_off, b)
+
+
 def hardware_init(buf_size=0, binary_name=b""):
     """the reference symbol bool hardware_init(long, char*) (chain_hardware.h:70)"""
     return bool(getattr(N.load(), "_Z13hardware_initlPc")(buf_size, binary_name))

@@ -58,6 +58,7 @@ int main(int argc, char *argv[])
 	if (getenv("MM2_PRINT_SEEDS")) mm_dbg_flag |= MM_DBG_PRINT_SEED;   /* main.c:193 --print-seeds */
 	mm_realtime0 = realtime();
 	defaults(&io, &mo);
+	if (getenv("MM2_MINI_BATCH")) mo.mini_batch_size = atoll(getenv("MM2_MINI_BATCH"));   /* main.c -K */
 	io.flag = 0; io.k = 15;                              /* -x map-ont, options.c:93-94 */
 	io.flag |= MM_I_NO_SEQ;                              /* main.c:286-287: no -d, no CIGAR */
 	r = mm_idx_reader_open(argv[1], &io, 0);

@@ -42,3 +42,25 @@ def test_inversion_pair_with_gpu_chaining():
 
 def test_short_pair_with_gpu_chaining():
     assert _run("t2.fa", "q2.fa") == ""
+
+
+# ---- the batched host: worker_for restructured as seed all -> ONE GPU call (matches in, chains out) -> post all;
+# oracle/ref_host/batch_driver.c over the reference's own objects and mm2c_seed_chain_batch_host
+BATCH_EXE = os.path.join(ROOT, "oracle", "_ref", "mm2_batchhost")
+
+
+def _run_batch(ref, qry, threads=2):
+    if not os.path.exists(BATCH_EXE):
+        pytest.skip("oracle/_ref/mm2_batchhost not built (needs /root/reference at build time: __graft_entry__.build())")
+    r = subprocess.run([BATCH_EXE, "-t", str(threads), os.path.join(DATA, ref), os.path.join(DATA, qry)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_batched_host_prints_the_reference_paf():
+    out = _run_batch("MT-human.fa", "MT-orang.fa")
+    assert hashlib.md5(out.encode()).hexdigest() == MT_MD5, out
+    lines = _run_batch("t-inv.fa", "q-inv.fa")
+    want = open(os.path.join(ROOT, "tests", "golden", "ref_host_paf_observed.txt")).read().split("# t-inv.fa q-inv.fa\n")[1].split("#")[0]
+    assert lines == want
+    assert _run_batch("t2.fa", "q2.fa") == ""

@@ -147,3 +147,20 @@ def test_seeds_to_chains_without_leaving_the_device():
         u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, d[f"r{k}_anchors"])
         assert np.array_equal(u[uo[k]:uo[k + 1]], u_ref) and np.array_equal(b[bo[k]:bo[k + 1]], b_ref), f"read {k}: chains differ"
     sp.close(); cp.close()
+
+
+def test_matches_in_chains_out_host_entry():
+    """mm2c_seed_chain_batch_host on the fixture: chains of every read against the oracle's mm_chain_dp on the reference's anchors"""
+    import mm2chain
+    from mm2chain import params
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz"))
+    reads = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"]) for k in range(int(d["n_reads"]))]
+    mo, m, h, ql = _batch(reads)
+    P = params.map_ont()
+    res = mm2chain.seed_chain_batch(P, 3, 40, mo, m, h, ql)
+    n_chains = 0
+    for k in range(len(reads)):
+        u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, d[f"r{k}_anchors"])
+        assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), f"read {k}: chains differ"
+        n_chains += u_ref.size
+    assert n_chains > 27
