@@ -61,6 +61,76 @@ struct Global {
 // chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex).  One device arena for everything that is uploaded
 // ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
 // mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
+// Device memory of plans and one-shot calls goes through a small cache: a batched caller creates and destroys plans of similar size
+// for every mini-batch, and hipMalloc / hipFree of gigabytes cost milliseconds each (hipFree also waits for the device).  A freed
+// block is kept and handed to the next request it fits (size within 1x..1.5x); the cache is bounded and emptied by mm2c_shutdown.
+struct DevCache {
+	std::mutex mu;
+	struct Block { void *p; size_t size; };
+	std::vector<Block> free_blocks;                 // cached, not in use
+	std::vector<Block> live;                        // handed out (to know their size on free)
+	size_t cached_bytes = 0;
+	static constexpr size_t MAX_CACHED = (size_t)64 << 30;
+} DC;
+
+hipError_t dev_alloc(void **out, size_t bytes)
+{
+	if (bytes == 0) bytes = 1;
+	{
+		std::lock_guard<std::mutex> lk(DC.mu);
+		size_t best = (size_t)-1;
+		for (size_t i = 0; i < DC.free_blocks.size(); ++i) {
+			const size_t sz = DC.free_blocks[i].size;
+			if (sz >= bytes && sz <= bytes + bytes / 2 + 4096 && (best == (size_t)-1 || sz < DC.free_blocks[best].size)) best = i;
+		}
+		if (best != (size_t)-1) {
+			DevCache::Block b = DC.free_blocks[best];
+			DC.free_blocks.erase(DC.free_blocks.begin() + (long)best);
+			DC.cached_bytes -= b.size;
+			DC.live.push_back(b);
+			*out = b.p;
+			return hipSuccess;
+		}
+	}
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) {                                     // out of memory with blocks parked in the cache: release them and retry
+		std::vector<DevCache::Block> drop;
+		{ std::lock_guard<std::mutex> lk(DC.mu); drop.swap(DC.free_blocks); DC.cached_bytes = 0; }
+		for (auto &b : drop) (void)hipFree(b.p);
+		(void)hipGetLastError();
+		e = hipMalloc(&p, bytes);
+		if (e != hipSuccess) return e;
+	}
+	std::lock_guard<std::mutex> lk(DC.mu);
+	DC.live.push_back({p, bytes});
+	*out = p;
+	return hipSuccess;
+}
+
+void dev_free(void *p)
+{
+	if (!p) return;
+	DevCache::Block b{p, 0};
+	bool park = false;
+	{
+		std::lock_guard<std::mutex> lk(DC.mu);
+		for (size_t i = 0; i < DC.live.size(); ++i)
+			if (DC.live[i].p == p) { b = DC.live[i]; DC.live.erase(DC.live.begin() + (long)i); break; }
+		if (b.size != 0 && DC.cached_bytes + b.size <= DevCache::MAX_CACHED && DC.free_blocks.size() < 64) {
+			DC.free_blocks.push_back(b); DC.cached_bytes += b.size; park = true;
+		}
+	}
+	if (!park) (void)hipFree(p);
+}
+
+void dev_cache_release()
+{
+	std::vector<DevCache::Block> drop;
+	{ std::lock_guard<std::mutex> lk(DC.mu); drop.swap(DC.free_blocks); DC.cached_bytes = 0; DC.live.clear(); }
+	for (auto &b : drop) (void)hipFree(b.p);
+}
+
 // one chunk in flight of mm2c_mm_chain_dp_batch_host (anchors up, DP, epilogue, chains down); grow-only arenas
 struct WholeSlot {
 	hipStream_t st = nullptr;
@@ -248,6 +318,7 @@ void mm2c_shutdown(void)
 	(void)hipDeviceSynchronize();
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
 	release_combiner();
+	dev_cache_release();
 	G.thread_ctxs.clear();
 	if (G.stream) (void)hipStreamDestroy(G.stream);
 	G.stream = nullptr;
@@ -322,11 +393,11 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	pl->total = n_tasks > 0 ? h_offsets[n_tasks] - h_offsets[0] : 0;
 	hipError_t e = hipSetDevice(G.device);
 	const size_t nt = (size_t)std::max<int64_t>(n_tasks, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_off, (nt + 1) * 8);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_order, nt * 4);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_status, nt * 4);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_t, tot * 4);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_st, tot * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_off, (nt + 1) * 8);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_order, nt * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_status, nt * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -348,12 +419,12 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 void mm2c_plan_destroy(mm2c_plan_t *pl)
 {
 	if (!pl) return;
-	if (pl->d_off) (void)hipFree(pl->d_off); if (pl->d_order) (void)hipFree(pl->d_order);
-	if (pl->d_status) (void)hipFree(pl->d_status); if (pl->d_t) (void)hipFree(pl->d_t); if (pl->d_st) (void)hipFree(pl->d_st);
+	if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // as hipFree would: the blocks go back to the cache and may be reused at once
+	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st);
 	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
-	if (pl->d_epi) (void)hipFree(pl->d_epi);
+	dev_free(pl->d_epi);
 	delete pl;
 }
 
@@ -433,7 +504,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 		HIP_TRY(hipSetDevice(G.device));
 		const size_t tmp = mm2c::epilogue_sort_temp_bytes(pl->total, pl->n_tasks);
 		const size_t bytes = layout_epilogue(E, nullptr, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
-		HIP_TRY(hipMalloc((void **)&pl->d_epi, bytes));
+		HIP_TRY(dev_alloc((void **)&pl->d_epi, bytes));
 		layout_epilogue(E, pl->d_epi, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
 		HIP_TRY(hipEventCreate(&pl->ev_e0));
 		HIP_TRY(hipEventCreate(&pl->ev_e1));
@@ -498,7 +569,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	             o_stack = take(2 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4),
 	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1);
 	hipError_t e = hipSetDevice(G.device);
-	if (e == hipSuccess) e = hipMalloc((void **)&pl->d_mem, at);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_mem, at);
 	if (e == hipSuccess && n_reads > 0) {
 		std::vector<int64_t> off((size_t)n_reads + 1);
 		for (int64_t k = 0; k <= n_reads; ++k) off[(size_t)k] = h_match_off[k] - h_match_off[0];
@@ -531,7 +602,8 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
 {
 	if (!pl) return;
-	if (pl->d_mem) (void)hipFree(pl->d_mem);
+	if (pl->ran) (void)hipDeviceSynchronize();
+	dev_free(pl->d_mem);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
 	for (int i = 0; i < 4; ++i) if (pl->fork[i]) (void)hipEventDestroy(pl->fork[i]);
@@ -617,7 +689,7 @@ int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const
 	const size_t o_m = take((size_t)n_m * sizeof(mm2c_match_t)), o_h = take((size_t)n_hits * 8), o_q = take((size_t)n_reads * 4), o_a = take((size_t)total * 16);
 	auto body = [&]() -> int {
 		int r;
-		HIP_TRY(hipMalloc((void **)&d, at));
+		HIP_TRY(dev_alloc((void **)&d, at));
 		HIP_TRY(hipMemcpyAsync(d + o_m, h_matches + mb, (size_t)n_m * sizeof(mm2c_match_t), hipMemcpyHostToDevice, G.stream));
 		HIP_TRY(hipMemcpyAsync(d + o_h, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice, G.stream));
 		HIP_TRY(hipMemcpyAsync(d + o_q, h_qlen, (size_t)n_reads * 4, hipMemcpyHostToDevice, G.stream));
@@ -627,7 +699,7 @@ int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const
 		return mm2c_seedplan_check(pl, nullptr);
 	};
 	const int rc = body();
-	if (d) (void)hipFree(d);
+	dev_free(d);
 	mm2c_seedplan_destroy(pl);
 	return rc;
 }
@@ -672,7 +744,7 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 	hipStream_t st = G.stream;
 	auto body = [&]() -> int {
 		int r;
-		HIP_TRY(hipMalloc((void **)&d, at));
+		HIP_TRY(dev_alloc((void **)&d, at));
 		HIP_TRY(hipMemcpyAsync(d + o_m, h_matches + mb, (size_t)n_m * sizeof(mm2c_match_t), hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(d + o_h, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(d + o_q, h_qlen, nr * 4, hipMemcpyHostToDevice, st));
@@ -689,7 +761,7 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 		return mm2c_seedplan_check(sp, nullptr);
 	};
 	rc = body();
-	if (d) (void)hipFree(d);
+	dev_free(d);
 	mm2c_plan_destroy(pl);
 	mm2c_seedplan_destroy(sp);
 	G.passes += 1;
