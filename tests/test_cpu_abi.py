@@ -60,6 +60,18 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.ChainPlan(params.map_ont(), [0, 4])
     assert mm2chain.hardware_init() is False          # main.c:367-369 then returns -1
+    # the whole-function and seed-hit entries: no device, no result (there is no host path behind them)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.mm_chain_dp_batch(params.map_ont(), 3, 40, [0, 4], a, epilogue_threads=0)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.mm_chain_dp_batch(params.map_ont(), 3, 40, [0, 4], a, epilogue_threads=2)      # the DP still needs the GPU
+    m = np.zeros(1, mm2chain.MATCH_DTYPE); m["n"] = 2
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.seed_hits_batch([0, 1], m, np.zeros(2, np.uint64), [100])
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.seed_chain_batch(params.map_ont(), 3, 40, [0, 1], m, np.zeros(2, np.uint64), [100])
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.SeedPlan([0, 1], [0, 2])
 
 
 def test_argument_validation_happens_before_any_device_work():
@@ -70,3 +82,8 @@ def test_argument_validation_happens_before_any_device_work():
         mm2chain.ChainPlan(bad, [0, 4])
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.chain_batch_host(params.map_ont(), [0, 4, 2], np.zeros((4, 2), np.uint64))
+    m = np.zeros(1, mm2chain.MATCH_DTYPE); m["n"] = 5                       # a match that reaches beyond the hit pool
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.seed_hits_batch([0, 1], m, np.zeros(2, np.uint64), [100])
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.seed_chain_batch(bad, 3, 40, [0, 1], m, np.zeros(8, np.uint64), [100])
