@@ -87,3 +87,16 @@ def test_argument_validation_happens_before_any_device_work():
         mm2chain.seed_hits_batch([0, 1], m, np.zeros(2, np.uint64), [100])
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.seed_chain_batch(bad, 3, 40, [0, 1], m, np.zeros(8, np.uint64), [100])
+
+
+def test_header_is_self_contained_c99_and_cxx11(tmp_path):
+    """include/mm2chain.h compiles alone as C99 (pedantic) and as C++11, and the record layouts are the documented ones"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "mm2chain.h"\n'
+                   'typedef char anchor_is_16_bytes[sizeof(mm2c_anchor_t) == 16 ? 1 : -1];\n'
+                   'typedef char match_is_24_bytes[sizeof(mm2c_match_t) == 24 ? 1 : -1];\n'
+                   'int main(void) { mm2c_params_t p; mm2c_params_map_ont(&p); return p.bw != 500; }\n')
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "cxx.o")])
