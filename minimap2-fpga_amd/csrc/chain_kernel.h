@@ -79,6 +79,7 @@ struct SeedArgs {
 	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
 	ulonglong2 *d_anchors;                       // out
 	int32_t *status, *has_ties;                  // per read; status must be zero on entry (1: hit counts and anchor offsets disagree)
+	uint64_t *xdiff;                             // per read: the bits of x that differ among its anchors (written by seed_expand)
 	int32_t *tiecnt;                             // per anchor: equal-x neighbours before this position of the sorted read
 	int64_t biggest;                             // anchors of the longest read
 	int32_t *stack;                              // pending buckets of the tie replay: 2 * (total / 64 + 2 * n_reads + 2) ints

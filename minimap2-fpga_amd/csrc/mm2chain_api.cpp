@@ -566,7 +566,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	size_t at = 0;
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
-	             o_stack = take(2 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4),
+	             o_stack = take(2 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
 	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1);
 	hipError_t e = hipSetDevice(G.device);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_mem, at);
@@ -593,7 +593,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	char *b = pl->d_mem;
 	S.n_reads = n_reads; S.d_match_off = (const int64_t *)(b + o_moff); S.d_anchor_off = (const int64_t *)(b + o_aoff);
 	S.d_order = (const int32_t *)(b + o_ord); S.status = (int32_t *)(b + o_stat); S.has_ties = (int32_t *)(b + o_ties);
-	S.tiecnt = (int32_t *)(b + o_tc); S.biggest = biggest;
+	S.tiecnt = (int32_t *)(b + o_tc); S.xdiff = (uint64_t *)(b + o_xd); S.biggest = biggest;
 	S.stack = (int32_t *)(b + o_stack); S.unsorted = (ulonglong2 *)(b + o_un); S.scratch = (ulonglong2 *)(b + o_scr);
 	S.big_id = big ? (uint32_t *)(b + o_bid) : nullptr; S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
 	return pl;

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 	const Match *m = A.d_matches + m0;
 	ulonglong2 *out = A.unsorted + a0;
 	int run = 0;                                                                // anchors written so far (wave uniform)
+	uint64_t x_or = 0, x_and = ~0ull;                                           // -> the bits of x that are not the same in every anchor of the read
 	for (int c0 = 0; c0 < nm; c0 += 64) {
 		const int i = c0 + lane;
 		Match q = {};
@@ -79,10 +80,13 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 			a.y |= (uint64_t)(segt >> 1) << 48;                                 // MM_SEED_SEG_SHIFT, map.c:239
 			if (segt & 1) a.y |= 1ULL << 42;                                    // MM_SEED_TANDEM, map.c:240
 			out[run + t] = a;
+			x_or |= a.x; x_and &= a.x;
 		}
 		run += total;
 	}
 	if (run != na && lane == 0) A.status[read] = 1;
+	x_or = wave_or(x_or); x_and = ~wave_or(~x_and);
+	if (lane == 0) A.xdiff[read] = na > 0 ? x_or ^ x_and : 0;
 }
 
 // ---- stable LSD radix sort of one read's anchors on x by one wave; the result ends in `dst` ------------------------
@@ -148,7 +152,65 @@ __device__ void wave_sort_anchors(const ulonglong2 *src, ulonglong2 *alt, ulongl
 	__syncthreads();
 }
 
+// ---- stable LSD radix sort of 8-byte keys on the bits [bit_lo, bit_lo + n_bits), ping-pong between a and b; returns the buffer that holds
+// the result ----
+__device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo, int n_bits, int lane, int *s_cnt /* 256 ints of LDS */)
+{
+	uint64_t *from = a, *to = b;
+	for (int shift = bit_lo; shift < bit_lo + n_bits; shift += 8) {
+		const int mask = bit_lo + n_bits - shift >= 8 ? 255 : (1 << (bit_lo + n_bits - shift)) - 1;
+		for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
+		__syncthreads();
+		for (int i0 = 0; i0 < n; i0 += 256) {
+			uint64_t k[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; k[u] = i < n ? from[i] : 0; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) if (i0 + 64 * u + lane < n) atomicAdd(&s_cnt[(int)(k[u] >> shift) & mask], 1);
+		}
+		__syncthreads();
+		{
+			int h[4], sum = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { h[u] = s_cnt[4 * lane + u]; sum += h[u]; }
+			int at = wave_incl_scan(sum, lane) - sum;
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { s_cnt[4 * lane + u] = at; at += h[u]; }
+		}
+		__syncthreads();
+		for (int i0 = 0; i0 < n; i0 += 256) {
+			uint64_t k[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; k[u] = i < n ? from[i] : 0; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const bool valid = i0 + 64 * u + lane < n;
+				const int d = (int)(k[u] >> shift) & mask;
+				uint64_t peers = __ballot(valid);
+#pragma unroll
+				for (int bb = 0; bb < 8; ++bb) {
+					const uint64_t bal = __ballot((d >> bb) & 1);
+					peers &= ((d >> bb) & 1) ? bal : ~bal;
+				}
+				const int rank = lanes_before(peers);
+				if (valid) to[s_cnt[d] + rank] = k[u];
+				__syncthreads();
+				if (valid && rank == 0) s_cnt[d] += __popcll(peers);
+				__syncthreads();
+			}
+		}
+		{ uint64_t *t = from; from = to; to = t; }
+	}
+	__syncthreads();
+	return from;
+}
+
 // ---- kernel 2: sort + tie detection ---------------------------------------------------------------------------------
+// The anchors are not moved pass by pass: each becomes one 8-byte key = (the bits of x that differ inside the read, squeezed
+// together) << id_bits | position in the unsorted array.  Sorting the keys on the x bits with a stable sort and gathering the anchors
+// once at the end moves 8 bytes per pass instead of 16 and needs ceil(differing bits / 8) passes (4 for one chromosome-sized target,
+// against 6 byte positions of the full x).  Falls back to sorting the anchors themselves if the squeezed bits do not fit.
 __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 {
 	__shared__ int s_cnt[256];
@@ -156,21 +218,47 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	const int lane = (int)threadIdx.x;
 	const int64_t a0 = A.d_anchor_off[read];
 	const int na = (int)(A.d_anchor_off[read + 1] - a0);
-	if (A.status[read] != 0) return;
+	if (A.status[read] != 0 || na == 0) { if (lane == 0) A.has_ties[read] = 0; return; }
 	// the unsorted array must survive (the replay of kernel 3 starts from it): it is only read
 	const ulonglong2 *un = A.unsorted + a0;
 	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + a0;
-	wave_sort_anchors(un, tmp, out, na, lane, s_cnt);
-	// tiecnt[i] = number of positions j < i with x[j] == x[j+1]: tells in O(1) whether a range of positions (= a bucket of the
-	// reference's sort, before and after it) holds equal keys
 	int32_t *tiecnt = A.tiecnt + a0;
+	const uint64_t diff = A.xdiff[read];
+	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
+	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
+	const int kb = b0 + b1 + bs, idb = na > 1 ? 32 - __clz(na - 1) : 1;
 	int run = 0;
-	for (int i0 = 0; i0 < na; i0 += 64) {
-		const int i = i0 + lane;
-		const int flag = (i + 1 < na && out[i].x == out[i + 1].x) ? 1 : 0;
-		const int incl = wave_incl_scan(flag, lane);
-		if (i < na) tiecnt[i] = run + incl - flag;
-		run += __shfl(incl, 63);
+	if (kb + idb <= 64) {
+		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;                        // the two halves of the 16-byte-per-anchor scratch
+		const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+		for (int i = lane; i < na; i += 64) {
+			const uint64_t x = un[i].x;
+			const uint64_t sq = (x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0);   // order preserving: the dropped bits are constant
+			ka[i] = sq << idb | (uint64_t)i;
+		}
+		__syncthreads();
+		const uint64_t *ks = wave_sort_keys(ka, kbuf, na, idb, kb, lane, s_cnt);
+		const uint64_t idm = (1ull << idb) - 1;
+		// gather, and tiecnt[i] = number of positions j < i with x[j] == x[j+1]: tells in O(1) whether a range of positions (= a bucket
+		// of the reference's sort, before and after it) holds equal keys
+		for (int i0 = 0; i0 < na; i0 += 64) {
+			const int i = i0 + lane;
+			const uint64_t k = i < na ? ks[i] : 0, kn = i + 1 < na ? ks[i + 1] : ~0ull;
+			if (i < na) out[i] = un[(int)(k & idm)];
+			const int flag = (i + 1 < na && (k >> idb) == (kn >> idb)) ? 1 : 0;
+			const int incl = wave_incl_scan(flag, lane);
+			if (i < na) tiecnt[i] = run + incl - flag;
+			run += __shfl(incl, 63);
+		}
+	} else {
+		wave_sort_anchors(un, tmp, out, na, lane, s_cnt);
+		for (int i0 = 0; i0 < na; i0 += 64) {
+			const int i = i0 + lane;
+			const int flag = (i + 1 < na && out[i].x == out[i + 1].x) ? 1 : 0;
+			const int incl = wave_incl_scan(flag, lane);
+			if (i < na) tiecnt[i] = run + incl - flag;
+			run += __shfl(incl, 63);
+		}
 	}
 	if (lane == 0) A.has_ties[read] = run > 0;
 }

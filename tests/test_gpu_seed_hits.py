@@ -96,6 +96,7 @@ def test_random_matches_against_the_oracle(seed):
              _random_read(rng, 300, 0, 1, 10),                            # matches without hits
              _random_read(rng, 1500, 5, 24, 1 << 27, dup_frac=0.3),       # duplicated hit lists: pairs of equal x across the genome
              _random_read(rng, 100, 2, 1, 1 << 20),
+             _random_read(rng, 600, 4, 1 << 30, (1 << 31) - 1, dup_frac=0.3),   # x differs in more bits than the squeezed sort keys hold: anchors sorted as they are
              _random_read(rng, 2000, 3, 2, 200)]                          # nearly everything ties
     assert _check(reads, f"seed {seed}") > 1000
 
