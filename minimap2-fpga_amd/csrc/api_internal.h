@@ -1,0 +1,100 @@
+// api_internal.h -- shared between the translation units of the C-ABI shim (mm2chain_api.cpp: init, plans; mm2chain_host.cpp: host-buffer
+// paths; mm2chain_seeds.cpp: seed-hit entries).  Not installed; include/mm2chain.h is the public interface.
+#ifndef MM2C_API_INTERNAL_H
+#define MM2C_API_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <vector>
+#include "mm2chain.h"
+#include "chain_kernel.h"
+
+namespace mm2c_api {
+
+extern thread_local char g_err[512];
+int fail(int code, const char *fmt, ...);      // records the message mm2c_last_error() returns, hands back `code`
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	return ::mm2c_api::fail(MM2C_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct ThreadCtx;
+
+struct Global {
+	std::mutex mu;
+	bool ready = false;
+	int device = -1;
+	int ring_class = 0;
+	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
+	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
+	int64_t pipeline_chunk_anchors = 20 << 20;  // host paths: batches of at least twice this size are pipelined in chunks of this size
+	int64_t cut_below_tasks = 4096;         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
+	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
+	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
+	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
+	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0}, passes{0};
+	uint64_t epoch = 0;                     // bumped by shutdown so stale thread-local pointers are dropped
+};
+extern Global G;
+
+// one chunk in flight of mm2c_mm_chain_dp_batch_host (anchors up, DP, epilogue, chains down); grow-only arenas
+struct WholeSlot {
+	hipStream_t st = nullptr;
+	char *d_in = nullptr, *d_work = nullptr, *d_res = nullptr, *h_meta = nullptr;
+	size_t cap_in = 0, cap_work = 0, cap_res = 0, cap_hmeta = 0;
+	int64_t k0 = 0, k1 = 0;                    // tasks of the chunk in flight
+	size_t o_res_u = 0, o_res_b = 0, o_hres = 0;
+	bool busy = false;
+	void release()
+	{
+		if (d_in) (void)hipFree(d_in); if (d_work) (void)hipFree(d_work); if (d_res) (void)hipFree(d_res);
+		if (h_meta) (void)hipHostFree(h_meta); if (st) (void)hipStreamDestroy(st);
+		*this = WholeSlot();
+	}
+};
+
+// per host thread: stream + grow-only buffers (the reference keeps one buffer set per FPGA kernel,
+// chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex).  One device arena for everything that is uploaded
+// ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
+// mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
+struct ThreadCtx {
+	WholeSlot whole[2];
+	hipStream_t st = nullptr, st2 = nullptr;   // st2: second stream of the pipelined big-batch path
+	hipEvent_t ev = nullptr;
+	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
+	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
+	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
+	void release()
+	{
+		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
+		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
+		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
+		whole[0].release(); whole[1].release();
+		*this = ThreadCtx();
+	}
+};
+
+int get_thread_ctx(ThreadCtx **out);
+hipError_t create_partner_stream(hipStream_t *st);
+int grow_device(char **p, size_t *cap, size_t need);
+int grow_pinned(char **p, size_t *cap, size_t need);
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+int check_params(const mm2c_params_t *p);
+mm2c::KParams to_kparams(const mm2c_params_t *p);
+int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order);
+size_t layout_epilogue(mm2c::EpiArgs &E, char *base, size_t tot, size_t nt, size_t sort_tmp);
+int epilogue_debug_phases();
+hipError_t dev_alloc(void **out, size_t bytes);   // cached device memory for plans and one-shot calls
+void dev_free(void *p);
+void dev_cache_release();
+void release_combiner();                            // mm2chain_host.cpp
+
+} // namespace mm2c_api
+#endif

@@ -1,0 +1,393 @@
+// mm2chain_host.cpp -- C-ABI entries that take host buffers (include/mm2chain.h): the reference's call pattern (one blocking call per
+// read from many threads, chain_hardware.cpp:27-197) and the batched ones; passes over staged / pipelined copies, the combiner of small
+// concurrent calls, the whole-function batch entry.
+#include "api_internal.h"
+
+using namespace mm2c_api;
+
+
+namespace mm2c_api {
+
+// one caller's batch: CSR tasks in pageable host memory
+struct HostReq {
+	const mm2c_params_t *par; int64_t n_tasks; const int64_t *off; const mm2c_anchor_t *a; const float *avg;
+	int32_t *f, *p;
+	int rc = 0; bool done = false; char err[256];
+};
+
+// Runs one GPU pass over the union of the requests (all with the same scalars).
+//  * every task is split at empty-window cut points: where x_i > x_{i-1} + max_dist_x no anchor at or
+//    after i can chain to, stamp or be stamped by an anchor before i (chain.c:192 pushes st to i), so the pieces are
+//    independent tasks for f[]/p[] and run as parallel waves.  Real reads hit many loci: this is what gives one mm_chain_dp
+//    call more than one wave of work.  Pieces shorter than seg_min anchors are merged with their successor.
+//  * avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
+//  * one upload arena [anchors | piece offsets | launch order | p base | avg | status(0)] and one download arena [f | p],
+//    mirrored in pinned memory for small passes: one H2D copy, the kernels, one D2H copy, one sync.
+int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
+{
+	int rc;
+	const mm2c_params_t *par = reqs[0]->par;
+	const uint64_t D = (uint64_t)(int64_t)par->max_dist_x;
+	int64_t total = 0, n_tasks_all = 0;
+	for (int r = 0; r < n_req; ++r) { total += reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]; n_tasks_all += reqs[r]->n_tasks; }
+	if (total == 0) return 0;
+	// cutting costs a host pass over the anchors: only worth it when the pass has too few tasks to fill the GPU on its own
+	const int64_t seg_min = n_tasks_all < G.cut_below_tasks ? G.seg_min : 0;
+	// uncut tasks without a caller-supplied avg_qspan_scaled: the kernel sums the spans itself (chain.c:48-49), no host pass
+	bool kernel_avg = seg_min == 0;
+	for (int r = 0; r < n_req; ++r) if (reqs[r]->avg) kernel_avg = false;
+	std::vector<int64_t> seg_off; std::vector<int32_t> pbase, order; std::vector<float> seg_avg;
+	seg_off.reserve((size_t)n_tasks_all + 16); pbase.reserve((size_t)n_tasks_all + 16); seg_avg.reserve((size_t)n_tasks_all + 16);
+	int64_t g0 = 0;                                                // where this request's anchors start in the arena
+	for (int r = 0; r < n_req; ++r) {
+		const HostReq &q = *reqs[r];
+		const int64_t base = q.off[0];
+		const mm2c_anchor_t *a = q.a + base;
+		for (int64_t k = 0; k < q.n_tasks; ++k) {
+			const int64_t t0 = q.off[k] - base, t1 = q.off[k + 1] - base;
+			if (t1 == t0) continue;
+			float avg = 0.f;
+			if (q.avg) avg = q.avg[k];
+			else if (!kernel_avg) {
+				uint64_t sum = 0;
+				for (int64_t i = t0; i < t1; ++i) sum += a[i].y >> 32 & 0xff;
+				avg = (float)(.01 * (float)sum / (t1 - t0));
+			}
+			int64_t s0 = t0;
+			for (int64_t i = t0 + 1; i < t1; ++i)
+				if (seg_min > 0 && i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
+					seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+					s0 = i;
+				}
+			seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+		}
+		g0 += q.off[q.n_tasks] - base;
+	}
+	const int64_t n_seg = (int64_t)seg_off.size();
+	seg_off.push_back(total);
+	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
+
+	HIP_TRY(hipSetDevice(G.device));
+	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
+	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
+	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
+	const size_t meta_bytes = in_bytes - o_off;
+	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
+	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
+	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
+	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
+	if ((rc = grow_pinned(&c->h_in, &c->cap_hin, staged ? in_bytes : meta_bytes))) return rc;
+	char *hm = staged ? c->h_in + o_off : c->h_in;                 // where the metadata block starts in the staging buffer
+	memcpy(hm, seg_off.data(), ((size_t)n_seg + 1) * 8);
+	memcpy(hm + (o_ord - o_off), order.data(), (size_t)n_seg * 4);
+	memcpy(hm + (o_pb - o_off), pbase.data(), (size_t)n_seg * 4);
+	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
+	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);
+	if (staged) {
+		size_t at = o_a;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t nb = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]) * 16;
+			memcpy(c->h_in + at, reqs[r]->a + reqs[r]->off[0], nb);
+			at += nb;
+		}
+		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
+	} else if (n_req == 1 && total >= 2 * G.pipeline_chunk_anchors) {
+		// big batch: pipeline it in chunks of whole pieces on two streams, so that the upload of chunk k+1, the kernels of chunk k
+		// and the download of chunk k-1 overlap (PCIe is full duplex); with page-locked caller buffers this runs at PCIe rate
+		if (!c->st2) HIP_TRY(create_partner_stream(&c->st2));
+		if (!c->ev) HIP_TRY(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
+		HIP_TRY(hipEventRecord(c->ev, c->st));
+		HIP_TRY(hipStreamWaitEvent(c->st2, c->ev, 0));
+		const HostReq &q = *reqs[0];
+		const mm2c_anchor_t *src = q.a + q.off[0];
+		int32_t *dst_f = q.f + q.off[0], *dst_p = q.p + q.off[0];
+		const int64_t chunk_anchors = G.pipeline_chunk_anchors;      // big enough for one chunk to fill the GPU on its own
+		int nl = 0, k = 0;
+		for (int64_t s0 = 0; s0 < n_seg; ++k) {
+			int64_t s1 = s0 + 1;
+			while (s1 < n_seg && seg_off[(size_t)s1 + 1] - seg_off[(size_t)s0] <= chunk_anchors) ++s1;
+			const int64_t a0 = seg_off[(size_t)s0], a1 = seg_off[(size_t)s1];
+			hipStream_t st = (k & 1) ? c->st2 : c->st;
+			HIP_TRY(hipMemcpyAsync(c->d_in + o_a + (size_t)a0 * 16, src + a0, (size_t)(a1 - a0) * 16, hipMemcpyHostToDevice, st));
+			mm2c::LaunchArgs L;
+			L.P = to_kparams(par);
+			L.n_tasks = s1 - s0; L.d_offsets = (const int64_t *)(c->d_in + o_off) + s0; L.d_order = nullptr;
+			L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg) + s0;
+			L.d_pbase = (const int32_t *)(c->d_in + o_pb) + s0; L.d_status = (int32_t *)(c->d_in + o_stat) + s0;
+			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
+			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
+			L.ring_class = G.ring_class;
+			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
+			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
+			s0 = s1;
+		}
+		HIP_TRY(hipStreamSynchronize(c->st));
+		HIP_TRY(hipStreamSynchronize(c->st2));
+		G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
+		G.passes += 1;
+		return 0;
+	} else {
+		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st));
+		size_t at = o_a;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t nb = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]) * 16;
+			HIP_TRY(hipMemcpyAsync(c->d_in + at, reqs[r]->a + reqs[r]->off[0], nb, hipMemcpyHostToDevice, c->st));
+			at += nb;
+		}
+	}
+	mm2c::LaunchArgs L;
+	L.P = to_kparams(par);
+	L.n_tasks = n_seg; L.d_offsets = (const int64_t *)(c->d_in + o_off); L.d_order = (const int32_t *)(c->d_in + o_ord);
+	L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
+	L.d_status = (int32_t *)(c->d_in + o_stat);
+	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
+	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
+	L.ring_class = G.ring_class;
+	int nl = 0;
+	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
+	if (staged) {
+		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
+		HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
+		size_t at = 0;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t n = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]);
+			memcpy(reqs[r]->f + reqs[r]->off[0], c->h_out + at * 4, n * 4);
+			memcpy(reqs[r]->p + reqs[r]->off[0], c->h_out + (size_t)total * 4 + at * 4, n * 4);
+			at += n;
+		}
+	} else {
+		size_t at = 0;
+		for (int r = 0; r < n_req; ++r) {
+			const size_t n = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]);
+			HIP_TRY(hipMemcpyAsync(reqs[r]->f + reqs[r]->off[0], L.d_f + at, n * 4, hipMemcpyDeviceToHost, c->st));
+			HIP_TRY(hipMemcpyAsync(reqs[r]->p + reqs[r]->off[0], L.d_p + at, n * 4, hipMemcpyDeviceToHost, c->st));
+			at += n;
+		}
+		HIP_TRY(hipStreamSynchronize(c->st));
+	}
+	G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
+	G.passes += 1;
+	return 0;
+}
+
+// Combiner for small synchronous calls (the reference's call pattern: up to n_threads host threads, each blocking in
+// run_chaining_on_hw / mm_chain_dp, map.c:561).  A caller that finds no pass in flight becomes the leader: it takes every
+// pending request with the same scalars, runs ONE GPU pass for all of them and wakes their owners; callers that arrive
+// meanwhile queue up and are served by the next leader.  (The reference instead serialises callers on a mutex and a FIFO,
+// chain_hardware.cpp:54-93.)  Big requests skip the combiner and run on the caller's own stream.
+struct Combiner {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<HostReq *> pending;
+	bool leader_active = false;
+	ThreadCtx ctx;                      // stream + arenas of the pass in flight (leader-exclusive)
+	uint64_t epoch = ~0ull;
+} CB;
+
+void release_combiner()
+{
+	std::lock_guard<std::mutex> lk(CB.mu);
+	CB.ctx.release();
+	CB.epoch = ~0ull;
+}
+
+int submit_combined(HostReq *me)
+{
+	std::unique_lock<std::mutex> lk(CB.mu);
+	CB.pending.push_back(me);
+	for (;;) {
+		if (me->done) return me->rc;
+		if (!CB.leader_active) break;
+		CB.cv.wait(lk);
+	}
+	// leader: collect the pending requests that share my scalars, up to the staging size
+	CB.leader_active = true;
+	std::vector<HostReq *> batch, rest;
+	size_t tot = 0;
+	for (HostReq *q : CB.pending) {
+		const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
+		if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; }
+		else rest.push_back(q);
+	}
+	CB.pending.swap(rest);
+	lk.unlock();
+	int rc = 0;
+	{
+		std::lock_guard<std::mutex> gl(G.mu);
+		if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+		else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
+			CB.ctx = ThreadCtx();
+			hipError_t e = hipSetDevice(G.device);
+			if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
+			if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
+			else CB.epoch = G.epoch;
+		}
+	}
+	if (rc == 0) rc = run_requests(&CB.ctx, batch.data(), (int)batch.size());
+	lk.lock();
+	for (HostReq *q : batch) {
+		q->rc = rc; q->done = true;
+		if (rc != 0) { strncpy(q->err, g_err, sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
+	}
+	CB.leader_active = false;
+	CB.cv.notify_all();
+	return me->rc;
+}
+
+} // namespace mm2c_api
+
+extern "C" {
+
+int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+{
+	int rc;
+	const auto t_begin = std::chrono::steady_clock::now();
+	if ((rc = check_params(par))) return rc;
+	std::vector<int32_t> order;
+	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;      // validates the offsets
+	if (n_tasks == 0) return 0;
+	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
+	if (total == 0) return 0;
+	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
+	HostReq req;
+	req.par = par; req.n_tasks = n_tasks; req.off = h_offsets; req.a = h_anchors; req.avg = h_avg_qspan; req.f = h_f; req.p = h_p;
+	req.err[0] = 0;
+	if ((size_t)total <= G.combine_max_anchors) {
+		rc = submit_combined(&req);
+		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
+	} else {
+		ThreadCtx *c;
+		if ((rc = get_thread_ctx(&c))) return rc;
+		HostReq *one = &req;
+		rc = run_requests(c, &one, 1);
+	}
+	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	return rc;
+}
+
+int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets,
+                                const mm2c_anchor_t *h_anchors, int epilogue_threads, int64_t *u_off, uint64_t *u, int64_t *b_off,
+                                mm2c_anchor_t *b)
+{
+	int rc;
+	if ((rc = check_params(par))) return rc;
+	if (n_tasks < 0 || !u_off || !b_off) return fail(MM2C_E_ARG, "bad argument");
+	u_off[0] = b_off[0] = 0;
+	if (n_tasks == 0) return 0;
+	if (!h_offsets) return fail(MM2C_E_ARG, "offsets is NULL");
+	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
+	if (total > 0 && (!h_anchors || !u || !b)) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (epilogue_threads > 0) {
+		std::vector<int32_t> f((size_t)std::max<int64_t>(total, 1)), p((size_t)std::max<int64_t>(total, 1));
+		if ((rc = mm2c_chain_batch_host(par, n_tasks, h_offsets, h_anchors, nullptr, f.data() - h_offsets[0], p.data() - h_offsets[0]))) return rc;
+		rc = mm2c_chain_epilogue_host(min_cnt, min_sc, n_tasks, h_offsets, h_anchors, f.data() - h_offsets[0], p.data() - h_offsets[0],
+		                              epilogue_threads, u_off, u, b_off, b);
+		return rc ? fail(rc, "mm2c_chain_epilogue_host failed") : 0;
+	}
+	if (total == 0) { for (int64_t k = 1; k <= n_tasks; ++k) u_off[k] = b_off[k] = 0; return 0; }
+	// everything on the GPU: anchors up, DP, epilogue, chains down; big batches in chunks of whole tasks on two streams, so that the
+	// upload of chunk k+1, the kernels of chunk k and the download of chunk k-1 overlap
+	if (total >= (int64_t)INT32_MAX && G.pipeline_chunk_anchors >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch too big for one chunk");
+	ThreadCtx *c;
+	if ((rc = get_thread_ctx(&c))) return rc;
+	HIP_TRY(hipSetDevice(G.device));
+	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors : total;
+	const mm2c_anchor_t *a0 = h_anchors + h_offsets[0];
+	int64_t base_u = 0, base_b = 0;
+	int nl = 0;
+
+	auto enqueue = [&](WholeSlot &w, int64_t k0, int64_t k1) -> int {
+		int r;
+		const size_t nt = (size_t)(k1 - k0), tot = (size_t)(h_offsets[k1] - h_offsets[k0]);
+		if (!w.st) HIP_TRY(&w == &c->whole[1] ? create_partner_stream(&w.st) : hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+		w.k0 = k0; w.k1 = k1; w.busy = true;
+		// upload arena: [anchors | offsets | order | status]; pinned mirror of the metadata + room for the offsets that come back
+		const size_t o_off = align16(tot * 16), o_ord = align16(o_off + (nt + 1) * 8), o_stat = align16(o_ord + nt * 4), in_bytes = align16(o_stat + nt * 4);
+		const size_t meta_bytes = in_bytes - o_off;
+		w.o_hres = align16(meta_bytes);
+		if ((r = grow_device(&w.d_in, &w.cap_in, in_bytes))) return r;
+		if ((r = grow_pinned(&w.h_meta, &w.cap_hmeta, w.o_hres + 2 * (nt + 1) * 8))) return r;
+		std::vector<int32_t> order;
+		if ((r = build_order((int64_t)nt, h_offsets + k0, order))) return r;
+		int64_t *m_off = (int64_t *)w.h_meta;
+		for (size_t k = 0; k <= nt; ++k) m_off[k] = h_offsets[k0 + (int64_t)k] - h_offsets[k0];
+		memcpy(w.h_meta + (o_ord - o_off), order.data(), nt * 4);
+		memset(w.h_meta + (o_stat - o_off), 0, in_bytes - o_stat);
+		// work arena: [f | p | t | st | epilogue scratch]; result arena: [u_off | b_off | u | b]
+		mm2c::EpiArgs E;
+		const size_t tmp = mm2c::epilogue_sort_temp_bytes((int64_t)tot, (int64_t)nt);
+		const size_t o_epi = align16(tot * 16), work_bytes = o_epi + layout_epilogue(E, nullptr, tot, nt, tmp);
+		if ((r = grow_device(&w.d_work, &w.cap_work, work_bytes))) return r;
+		layout_epilogue(E, w.d_work + o_epi, tot, nt, tmp);
+		const size_t o_boff = align16((nt + 1) * 8);
+		w.o_res_u = align16(o_boff + (nt + 1) * 8); w.o_res_b = align16(w.o_res_u + tot * 8);
+		if ((r = grow_device(&w.d_res, &w.cap_res, w.o_res_b + tot * 16))) return r;
+		if (tot == 0) { memset(w.h_meta + w.o_hres, 0, 2 * (nt + 1) * 8); return 0; }
+		HIP_TRY(hipMemcpyAsync(w.d_in + o_off, w.h_meta, meta_bytes, hipMemcpyHostToDevice, w.st));
+		HIP_TRY(hipMemcpyAsync(w.d_in, a0 + (h_offsets[k0] - h_offsets[0]), tot * 16, hipMemcpyHostToDevice, w.st));
+		int32_t *d_f = (int32_t *)w.d_work, *d_p = d_f + tot;
+		mm2c::LaunchArgs L;
+		L.P = to_kparams(par);
+		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
+		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
+		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
+		L.ring_class = G.ring_class;
+		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr));
+		E.n_tasks = (int64_t)nt; E.total = (int64_t)tot; E.d_off = L.d_offsets; E.d_order = L.d_order;
+		E.d_a = (const ulonglong2 *)w.d_in; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
+		E.debug_phases = epilogue_debug_phases();
+		E.u_off = (int64_t *)w.d_res; E.b_off = (int64_t *)(w.d_res + o_boff);
+		E.u_out = (uint64_t *)(w.d_res + w.o_res_u); E.b_out = (ulonglong2 *)(w.d_res + w.o_res_b);
+		HIP_TRY(mm2c::launch_chain_epilogue(E, w.st, &nl));
+		HIP_TRY(hipMemcpyAsync(w.h_meta + w.o_hres, E.u_off, (nt + 1) * 8, hipMemcpyDeviceToHost, w.st));
+		HIP_TRY(hipMemcpyAsync(w.h_meta + w.o_hres + (nt + 1) * 8, E.b_off, (nt + 1) * 8, hipMemcpyDeviceToHost, w.st));
+		return 0;
+	};
+	// waits for the chunk's offsets, places them behind the chunks before it and starts the download of its chains
+	auto finalize = [&](WholeSlot &w) -> int {
+		if (!w.busy) return 0;
+		w.busy = false;
+		const size_t nt = (size_t)(w.k1 - w.k0);
+		HIP_TRY(hipStreamSynchronize(w.st));
+		const int64_t *cu = (const int64_t *)(w.h_meta + w.o_hres), *cb = cu + nt + 1;
+		for (size_t k = 1; k <= nt; ++k) { u_off[w.k0 + (int64_t)k] = base_u + cu[k]; b_off[w.k0 + (int64_t)k] = base_b + cb[k]; }
+		if (cu[nt] > 0) HIP_TRY(hipMemcpyAsync(u + base_u, w.d_res + w.o_res_u, (size_t)cu[nt] * 8, hipMemcpyDeviceToHost, w.st));
+		if (cb[nt] > 0) HIP_TRY(hipMemcpyAsync(b + base_b, w.d_res + w.o_res_b, (size_t)cb[nt] * 16, hipMemcpyDeviceToHost, w.st));
+		base_u += cu[nt]; base_b += cb[nt];
+		return 0;
+	};
+	int n_chunks = 0;
+	for (int64_t k0 = 0; k0 < n_tasks && rc == 0; ++n_chunks) {
+		int64_t k1 = k0 + 1;
+		while (k1 < n_tasks && h_offsets[k1 + 1] - h_offsets[k0] <= chunk_anchors) ++k1;
+		if (h_offsets[k1] - h_offsets[k0] >= (int64_t)INT32_MAX) { rc = fail(MM2C_E_TOOBIG, "a chunk of the batch has 2^31 anchors or more"); break; }
+		WholeSlot &w = c->whole[n_chunks & 1];
+		if ((rc = finalize(w))) break;                              // the chunk before the previous one (same slot)
+		rc = enqueue(w, k0, k1);
+		k0 = k1;
+	}
+	if (rc == 0) rc = finalize(c->whole[n_chunks & 1]);             // in chunk order: the older slot first
+	if (rc == 0) rc = finalize(c->whole[(n_chunks + 1) & 1]);
+	for (int i = 0; i < 2; ++i) {
+		if (c->whole[i].st) { hipError_t e = hipStreamSynchronize(c->whole[i].st); if (e != hipSuccess && rc == 0) rc = fail(MM2C_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+		c->whole[i].busy = false;
+	}
+	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.passes += (uint64_t)n_chunks;
+	return rc;
+}
+
+int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
+                         int32_t *f, int32_t *p, int tid)
+{
+	(void)tid;  // the reference uses tid for its FIFO (chain_hardware.cpp:65,83); each host thread owns a stream here
+	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
+	if (n < 0) return fail(MM2C_E_ARG, "n < 0");
+	const int64_t off[2] = { 0, n };
+	return mm2c_chain_batch_host(par, 1, off, a, &avg_qspan_scaled, f, p);
+}
+
+} // extern "C"
