@@ -1,4 +1,4 @@
-// chain_kernel.h -- internal interface between the C-ABI shim (mm2chain_api.cpp) and the HIP kernels.
+// chain_kernel.h -- internal interface between the C-ABI shim (mm2chain_api.cpp, mm2chain_host.cpp, mm2chain_seeds.cpp) and the HIP kernels.
 #ifndef MM2C_CHAIN_KERNEL_H
 #define MM2C_CHAIN_KERNEL_H
 #include <hip/hip_runtime.h>
