@@ -228,6 +228,37 @@ def main():
                                     "what": "prepass + DP + device epilogue (v[], chain ends, backtrack, filter, chain order), HBM-resident, 1 step",
                                     "verified_vs_oracle": bool(ok)}
         del u, b
+        # seed hits -> sorted anchors on the GPU: matches derived from the first reads of this batch (their anchors,
+        # regrouped by query position), tiled; the anchors that come out are checked against the oracle's collect_seed_hits
+        n_s = min(distinct, 256)
+        qlen_s = 1 << 20
+        ms_, hs_, mo_, ao_ = [], [], [0], [0]
+        a_s = a1[: int(off1[n_s])].cpu().numpy().view(np.uint64)
+        for k in range(n_s):
+            m_k, h_k = synth.matches_from_anchors(a_s[int(off1[k]):int(off1[k + 1])], qlen_s)
+            m_k["cr_off"] += ao_[-1]
+            ms_.append(m_k); hs_.append(h_k); mo_.append(mo_[-1] + m_k.size); ao_.append(ao_[-1] + h_k.size)
+        rep = 32
+        m1_, h1_ = np.concatenate(ms_), np.concatenate(hs_)
+        mt_ = np.tile(m1_, rep); mt_["cr_off"] += np.repeat(np.arange(rep, dtype=np.int64) * h1_.size, m1_.size)
+        mo_t = np.concatenate([[0], np.tile(np.diff(mo_), rep).cumsum()]).astype(np.int64)
+        ao_t = np.concatenate([[0], np.tile(np.diff(ao_), rep).cumsum()]).astype(np.int64)
+        sp = mm2chain.SeedPlan(mo_t, ao_t)
+        d_m = torch.from_numpy(mt_.view(np.uint8)).cuda(); d_h = torch.from_numpy(np.tile(h1_, rep).view(np.int64)).cuda()
+        d_q = torch.full((n_s * rep,), qlen_s, dtype=torch.int32, device="cuda")
+        d_as = sp.run(d_m, d_h, d_q)
+        d_as = sp.run(d_m, d_h, d_q, d_as)
+        n_tie_reads = sp.check()
+        got = d_as[: int(ao_[4])].cpu().numpy().view(np.uint64)
+        ok_s = True
+        for k in range(4):
+            mk = ms_[k].copy(); mk["cr_off"] -= ao_[k]
+            ok_s = ok_s and np.array_equal(got[ao_[k]:ao_[k + 1]], ob.collect_seed_hits(mk, hs_[k], qlen_s))
+        out["seed_hits"] = {"value": int(ao_t[-1]) / (sp.last_ms() * 1e-3), "unit": "anchors/s", "ms": sp.last_ms(),
+                            "reads": n_s * rep, "anchors": int(ao_t[-1]), "matches": int(mt_.size), "reads_with_equal_x": int(n_tie_reads),
+                            "what": "matches -> anchors as collect_seed_hits leaves them (map.c:215-247, incl. radix_sort_128x's order among equal x), HBM-resident",
+                            "verified_vs_oracle": bool(ok_s)}
+        sp.close(); del d_m, d_h, d_as
         n_h = min(distinct, 4096)
         a_host = a1[: int(off1[n_h])].cpu().numpy().view(np.uint64)
         off_host = off1[: n_h + 1].numpy()

@@ -112,3 +112,30 @@ def replicate(offsets, anchors, times):
     off = torch.zeros(n.numel() * times + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(n.repeat(times), 0)
     return off, anchors.repeat(times, 1).contiguous()
+
+
+def matches_from_anchors(a, qlen=1 << 20):
+    """anchors of one read (uint64 [n, 2], any order) -> (matches, hits) that collect_seed_hits (map.c:215-247) expands back into
+    exactly these anchors: one match per (query position, span), its hit list = the reference positions at that query position.
+    Used to drive the seed-hit path with the bench's synthetic streams.  matches: numpy structured array with the fields of
+    mm2c_match_t (cr_off relative to the returned hit array)."""
+    import numpy as np
+    dt = np.dtype([("cr_off", "<i8"), ("n", "<u4"), ("q_pos", "<u4"), ("q_span", "<u4"), ("seg_tandem", "<u4")])
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 2)
+    x, y = a[:, 0], a[:, 1]
+    rev = (x >> np.uint64(63)).astype(np.uint64)
+    span = ((y >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64)
+    q = (y & np.uint64(0xffffffff)).astype(np.int64)
+    qp = np.where(rev == 1, qlen - 1 - q - 1 + span, q)                       # map.c:237 inverted
+    r = (x & np.uint64(0x7fffffff00000000)) | ((x & np.uint64(0xffffffff)) << np.uint64(1)) | rev   # strand bit != q_pos bit 0 <=> reverse
+    key = qp * 256 + span
+    order = np.lexsort((r, key))
+    key, r = key[order], r[order]
+    first = np.concatenate([[True], key[1:] != key[:-1]]) if key.size else np.zeros(0, bool)
+    starts = np.nonzero(first)[0]
+    m = np.zeros(starts.size, dt)
+    m["cr_off"] = starts
+    m["n"] = np.diff(np.concatenate([starts, [key.size]]))
+    m["q_pos"] = (key[starts] // 256).astype(np.uint32) << 1
+    m["q_span"] = key[starts] % 256
+    return m, r

@@ -27,22 +27,7 @@ if not real_like:
 
 
 def matches_of(a):
-    """anchors of one read -> (matches, hits) that collect_seed_hits expands back into them"""
-    x, y = a[:, 0], a[:, 1]
-    rev = (x >> np.uint64(63)).astype(np.uint64)
-    span = ((y >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64)
-    q = (y & np.uint64(0xffffffff)).astype(np.int64)
-    qp = np.where(rev == 1, QLEN - 1 - q - 1 + span, q)                       # map.c:237 inverted
-    r = (x & np.uint64(0x7fffffff00000000)) | ((x & np.uint64(0xffffffff)) << np.uint64(1)) | rev   # strand bit != q_pos bit 0 <=> reverse
-    key = qp * 256 + span
-    order = np.lexsort((r, key))
-    key, r = key[order], r[order]
-    first = np.concatenate([[True], key[1:] != key[:-1]])
-    starts = np.nonzero(first)[0]
-    m = np.zeros(starts.size, ob.MATCH_DTYPE)
-    m["cr_off"] = starts; m["n"] = np.diff(np.concatenate([starts, [key.size]]))
-    m["q_pos"] = (key[starts] // 256).astype(np.uint32) << 1; m["q_span"] = key[starts] % 256
-    return m, r
+    return synth.matches_from_anchors(a, QLEN)
 
 
 def real_like_reads(genome_mb, n):
