@@ -89,6 +89,8 @@ def main():
                     help="chaining scalars + stream shape: map-ont (BASELINE config 2, default), asm20 (config 4 stand-in: span 19, "
                          "7500 anchors/read), ava-ont (config 5 stand-in: bw 2000, max_gap 10000, 20000 anchors/read)")
     ap.add_argument("--ring-class", type=int, default=None)
+    ap.add_argument("--general", action="store_true", help="run the general kernel variant (segment ids / cDNA branches, chain.c:206,211-217) on the same stream")
+    ap.add_argument("--gap-scale", type=float, default=None, help="chain_gap_scale other than 1 (the f64 path of chain.c:219)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     args = ap.parse_args()
 
@@ -129,6 +131,10 @@ def main():
         if args.reads == 65536:
             args.reads, args.distinct = 16384, min(args.distinct, 2048)
 
+    if args.general:
+        P.flags |= mm2chain.MM2C_F_FORCE_GENERAL
+    if args.gap_scale is not None:
+        P.gap_scale = args.gap_scale
     # ---- synthetic batch of this rank, generated on the device (deterministic: splitmix64 of seed + rank)
     distinct = min(args.distinct, args.reads)
     times = max(1, args.reads // distinct)
