@@ -60,8 +60,9 @@ void mm2c_shutdown(void);                     /* not while another thread is ins
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
 /* tuning knobs (key, value): "ring_class" 0/1/2 = 256/512/1024 anchors of LDS ring per task (default 0, or env
- * MM2C_RING_CLASS); "seg_min" = shortest piece (anchors) the host-buffer paths cut a task into at empty-window positions
- * (default 256, 0 = never cut); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for host batches of at least
+ * MM2C_RING_CLASS); "seg_min" = shortest piece (anchors) a task is cut into at empty-window positions (default 256, 0 = never
+ * cut); "plan_cut" 0/1 = plans cut their tasks of at least "plan_cut_min" anchors (default 8192) into such pieces on the device before
+ * the DP (default 1); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for host batches of at least
  * twice that size (default 20 Mi anchors).  Results never depend on a knob. */
 int  mm2c_tune(const char *key, int value);
 

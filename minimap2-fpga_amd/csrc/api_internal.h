@@ -36,7 +36,9 @@ struct Global {
 	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
 	int64_t pipeline_chunk_anchors = 20 << 20;  // host paths: batches of at least twice this size are pipelined in chunks of this size
 	int64_t cut_below_tasks = 4096;         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
-	int seg_min = 256;                      // host paths: shortest piece a task is cut into at empty-window positions (0 = never cut)
+	int seg_min = 256;                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
+	int plan_cut = 1;                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
+	int plan_cut_min = 8192;                // ... tasks of at least this many anchors (the ones that make the tail of a batch)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
 	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
 	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0}, passes{0};

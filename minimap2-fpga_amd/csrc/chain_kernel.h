@@ -19,6 +19,18 @@ struct KParams {
 	float gap_scale;
 };
 
+// pieces cut on the device (chain_cut): every array has room for max_pieces = n_tasks + total / seg_min entries; d_count and d_status must
+// be zero on entry.  max_pieces == 0: tasks are run as they are.
+struct CutArgs {
+	int64_t max_pieces = 0;
+	int32_t seg_min = 256;
+	int32_t min_anchors = 8192;     // only tasks at least this long are cut: the others do not make the tail
+	int64_t *d_start = nullptr, *d_end = nullptr;
+	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;
+	int32_t *d_has_cut = nullptr;   // per task (n_tasks entries), zero on entry: set by the prepass where a window is empty
+	float *d_avg = nullptr;
+};
+
 struct LaunchArgs {
 	KParams P;
 	int64_t n_tasks;
@@ -32,6 +44,7 @@ struct LaunchArgs {
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
 	int ring_class;             // 0: 256, 1: 512, 2: 1024 anchors of LDS ring per task
+	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
 };
 
 int chain_ring_anchors(int ring_class);

@@ -387,7 +387,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 // each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
 __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-                   const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all)
+                   const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -405,6 +405,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;       // chain.c:192 condition for "++st"
 		}
 		st[i] = lo;
+		if (has_cut && lo == i && i > 0) has_cut[task] = 1;          // an empty window: the task can be cut here (chain_cut)
 	}
 }
 
@@ -442,13 +443,78 @@ chain_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *__restrict__ o
 	if (lane == 0) { if (total_sub) total_sub[task] = s_sub; if (total_trip) total_trip[task] = s_trip; }
 }
 
+// ---------------------------------------------------------------- pieces of a task, cut on the device
+// Where st[i] == i (empty window, chain.c:192: x_i > x_{i-1} + max_dist_x) no anchor at or after i can chain to, stamp or be stamped by an
+// anchor before i, so [.., i) and [i, ..) are independent for f[] / p[].  A long read made of many loci becomes many
+// short pieces = many waves instead of one long dependent chain.  Pieces shorter than seg_min are merged with their successor.  One wave
+// per task: count the pieces, reserve a contiguous range of piece slots, write them in order.  avg_qspan_scaled is a whole-task quantity
+// (chain.c:48-49): computed here (or taken from the caller) and copied to every piece.
+__global__ void __launch_bounds__(64)
+chain_cut(int seg_min, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order, const uint4 *__restrict__ a_all,
+          const float *__restrict__ avg_in, const int32_t *__restrict__ st_all, CutArgs C)
+{
+	const int lane = threadIdx.x;
+	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
+	if (task >= n_tasks) return;
+	const int64_t base = offsets[task];
+	const int n = (int)(offsets[task + 1] - base);
+	if (n <= 0) return;
+	const int32_t *st = st_all + base;
+	if (n < C.min_anchors || C.d_has_cut[task] == 0) {
+		// a short task, or no empty window inside it (the prepass saw none): one piece; its avg is left to the DP kernel (negative = "not computed")
+		if (lane == 0) {
+			const int k = atomicAdd(C.d_count, 1);
+			C.d_start[k] = base; C.d_end[k] = base + n; C.d_pbase[k] = 0; C.d_avg[k] = avg_in ? avg_in[task] : -1.0f;
+		}
+		return;
+	}
+	float avg;
+	if (avg_in) avg = avg_in[task];
+	else {
+		uint64_t sum = 0;
+		for (int k = lane; k < n; k += 64) sum += (a_all[base + k].w & 0xffu);
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
+	}
+	int slot0 = 0;
+	for (int pass = 0; pass < 2; ++pass) {                      // pass 0 counts, pass 1 writes
+		int s0 = 0, cnt = 0;
+		for (int i0 = 0; i0 < n; i0 += 64) {
+			const int i = i0 + lane;
+			uint64_t m = __ballot(i > 0 && i < n && st[i] == i);
+			for (;;) {                                            // the first candidate that leaves >= seg_min anchors behind, then again from there
+				const int from = s0 + seg_min - i0;
+				if (from >= 64) break;
+				if (from > 0) m &= ~0ull << from;
+				if (m == 0) break;
+				const int c = i0 + (int)__builtin_ctzll(m);
+				if (pass == 1 && lane == 0) {
+					const int k = slot0 + cnt;
+					C.d_start[k] = base + s0; C.d_end[k] = base + c; C.d_pbase[k] = s0; C.d_avg[k] = avg;
+				}
+				++cnt; s0 = c;
+				m &= m - 1;
+			}
+		}
+		if (pass == 1 && lane == 0) {
+			const int k = slot0 + cnt;
+			C.d_start[k] = base + s0; C.d_end[k] = base + n; C.d_pbase[k] = s0; C.d_avg[k] = avg;
+		}
+		++cnt;                                                    // the last piece
+		if (pass == 0) {
+			if (lane == 0) slot0 = atomicAdd(C.d_count, cnt);
+			slot0 = __shfl(slot0, 0);
+		}
+	}
+}
+
 // ---------------------------------------------------------------- the kernel: one wave per task
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 __global__ void __launch_bounds__(64)
 chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
 {
 	static_assert(R >= 128 && (R & (R - 1)) == 0, "ring must be a power of two >= 128");
 	__shared__ uint2 s_xq[R];        // x low word, query position
@@ -459,9 +525,10 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int64_t)blockIdx.x;
 	if (task >= n_tasks) return;
+	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut): the grid is sized for the worst case
 	if (only_flagged && status[task] == 0) return;
 	const int64_t base = offsets[task];
-	const int n = __builtin_amdgcn_readfirstlane((int)(offsets[task + 1] - base));   // wave-uniform: loop bounds stay on the scalar unit
+	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base));   // wave-uniform: loop bounds stay on the scalar unit
 	if (n <= 0) return;
 	const uint4 *a = a_all + base;         // {x lo, x hi, y lo (= query pos), y hi (span | flags | seg)}
 	const int32_t *st = st_all + base;
@@ -469,11 +536,11 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 
 	for (int s = lane; s < 2 * R + 2; s += 64) s_t[s] = 0;
 	const int pbase = pbase_in ? pbase_in[task] : 0;
+	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative)
 
 	// avg_qspan_scaled, chain.c:48-49
-	float avg;
-	if (avg_in) avg = avg_in[task];
-	else {
+	float avg = avg_in ? avg_in[task] : -1.0f;
+	if (avg < 0.f) {                                          // not handed in (chain_cut leaves uncut tasks to this kernel)
 		uint64_t sum = 0;
 		for (int k = lane; k < n; k += 64) sum += (a[k].w & 0xffu);
 		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -491,12 +558,12 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const char *const xq_bytes = (const char *)s_xq, *const fp_bytes = (const char *)s_fp;
 
 	uint4 cur = (lane < n) ? a[lane] : make_uint4(0, 0, 0, 0);
-	int cur_st = (lane < n) ? st[lane] : 0;
+	int cur_st = (lane < n) ? st[lane] - st_sub : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int idx = i0 + lane;
 		const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - i0));   // keep the anchor loop bound on the scalar unit
 		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
-		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64]; }   // prefetch the next tile
+		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64] - st_sub; }   // prefetch the next tile
 		const int g_l = (cur.w >> 16) & 0xff;                                 // MM_SEED_SEG_MASK mmpriv.h:22-23
 		if (!GEN && !(P.flags & KF_IGNORE_SEG)) {
 			// the simple variant assumes one segment id per task; anything else is redone by the general one
@@ -568,9 +635,16 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 template <int R, bool SKIP, bool GEN, bool GS1, bool FAR>
 static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagged)
 {
+	if (L.cut.max_pieces > 0) {
+		// pieces cut on the device: starts / ends / p base / avg per piece, st[] relative to the task
+		hipLaunchKernelGGL((chain_dp_wave<R, SKIP, GEN, GS1, FAR>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
+		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,
+		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL((chain_dp_wave<R, SKIP, GEN, GS1, FAR>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
 	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, L.d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t,
-	                   L.d_status, only_flagged);
+	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr);
 	return hipGetLastError();
 }
 
@@ -610,9 +684,15 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const int R = chain_ring_anchors(L.ring_class);
 	const bool far_ = (int64_t)P.max_iter > (int64_t)R;   // the ring always holds the R anchors before the current tile
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
-	                   (const ulonglong2 *)L.d_anchors, L.d_st);
+	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
+	if (e == hipSuccess && L.cut.max_pieces > 0) {
+		hipLaunchKernelGGL(chain_cut, dim3((unsigned)L.n_tasks), dim3(64), 0, st, L.cut.seg_min, L.n_tasks, L.d_offsets, L.d_order,
+		                   (const uint4 *)L.d_anchors, L.d_avg, L.d_st, L.cut);
+		e = hipGetLastError();
+		if (n_launches) ++*n_launches;
+	}
 	if (e == hipSuccess && ev_dp_begin) e = hipEventRecord(ev_dp_begin, st);
 	for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
 		// pass 0: the variant the parameters ask for; pass 1 (simple variant only, segments not ignored): redo the

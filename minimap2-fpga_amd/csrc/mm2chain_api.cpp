@@ -211,6 +211,9 @@ struct mm2c_plan {
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
 	bool ran = false, epi_ran = false;
+	std::vector<int32_t> sizes_desc;        // task sizes, longest first (host copy: bounds the number of pieces of the device-side cut)
+	char *d_cut = nullptr;                  // piece arrays of the device-side cut (chain_cut), allocated by the first run that cuts
+	mm2c::CutArgs cut;
 	char *d_epi = nullptr;                  // scratch of the device epilogue, allocated by the first mm2c_plan_chains_device
 	mm2c::EpiArgs E;
 };
@@ -279,6 +282,16 @@ int mm2c_tune(const char *key, int value)
 		G.pipeline_chunk_anchors = value;
 		return 0;
 	}
+	if (strcmp(key, "plan_cut") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "plan_cut must be 0 or 1");
+		G.plan_cut = value;
+		return 0;
+	}
+	if (strcmp(key, "plan_cut_min") == 0) {
+		if (value < 1) return fail(MM2C_E_ARG, "plan_cut_min must be >= 1");
+		G.plan_cut_min = value;
+		return 0;
+	}
 	if (strcmp(key, "seg_min") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "seg_min must be >= 0");
 		G.seg_min = value;
@@ -320,6 +333,8 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	mm2c_plan *pl = new mm2c_plan();
 	pl->par = *par; pl->n_tasks = n_tasks;
 	pl->total = n_tasks > 0 ? h_offsets[n_tasks] - h_offsets[0] : 0;
+	pl->sizes_desc.resize((size_t)n_tasks);
+	for (int64_t k = 0; k < n_tasks; ++k) pl->sizes_desc[(size_t)k] = (int32_t)(h_offsets[order[(size_t)k] + 1] - h_offsets[order[(size_t)k]]);
 	hipError_t e = hipSetDevice(G.device);
 	const size_t nt = (size_t)std::max<int64_t>(n_tasks, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_off, (nt + 1) * 8);
@@ -354,6 +369,7 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
 	dev_free(pl->d_epi);
+	dev_free(pl->d_cut);
 	delete pl;
 }
 
@@ -372,6 +388,32 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.ring_class = G.ring_class;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
+	if (G.plan_cut && G.seg_min > 0) {
+		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
+		// plan_cut_min anchors or more (they make the tail of the batch); a batch without any runs exactly as before.
+		int64_t extra = 0;
+		for (size_t k = 0; k < pl->sizes_desc.size() && pl->sizes_desc[k] >= G.plan_cut_min; ++k) extra += pl->sizes_desc[k] / G.seg_min;
+		const int64_t max_pieces = pl->n_tasks + extra;
+		if (extra > 0 && max_pieces <= (int64_t)INT32_MAX) {
+			if (!pl->d_cut || pl->cut.max_pieces != max_pieces || pl->cut.seg_min != G.seg_min) {
+				dev_free(pl->d_cut); pl->d_cut = nullptr;
+				const size_t mp = (size_t)max_pieces;
+				size_t at = 0;
+				auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+				const size_t o_cnt = take(4), o_stat = take(mp * 4), o_hc = take((size_t)pl->n_tasks * 4), o_start = take(mp * 8), o_end = take(mp * 8),
+				             o_pb = take(mp * 4), o_avg = take(mp * 4);
+				HIP_TRY(dev_alloc((void **)&pl->d_cut, at));
+				char *b = pl->d_cut;
+				pl->cut.max_pieces = max_pieces; pl->cut.seg_min = G.seg_min;
+				pl->cut.d_count = (int32_t *)(b + o_cnt); pl->cut.d_status = (int32_t *)(b + o_stat); pl->cut.d_has_cut = (int32_t *)(b + o_hc);
+				pl->cut.d_start = (int64_t *)(b + o_start); pl->cut.d_end = (int64_t *)(b + o_end);
+				pl->cut.d_pbase = (int32_t *)(b + o_pb); pl->cut.d_avg = (float *)(b + o_avg);
+			}
+			pl->cut.min_anchors = G.plan_cut_min;
+			HIP_TRY(hipMemsetAsync(pl->d_cut, 0, 256 + (((size_t)max_pieces * 4 + 255) & ~(size_t)255) + (((size_t)pl->n_tasks * 4 + 255) & ~(size_t)255), st));   // count + status + has_cut
+			L.cut = pl->cut;
+		}
+	}
 	HIP_TRY(hipEventRecord(pl->ev_pre, st));
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, pl->ev0));

@@ -238,6 +238,67 @@ def test_host_paths_cut_tasks_at_empty_windows():
         mm2chain.tune("seg_min", 256)
 
 
+def _multi_locus_tasks(seed, n_tasks, loci=(3, 30), per_locus=(1, 700), seg_ids=False):
+    rng = np.random.default_rng(seed)
+    tasks = []
+    for _ in range(n_tasks):
+        rows = []
+        for _ in range(int(rng.integers(*loci))):
+            strand, rid = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+            pos = int(rng.integers(0, 1 << 26)); q = int(rng.integers(0, 3000))
+            for _ in range(int(rng.integers(*per_locus))):
+                pos += int(rng.integers(1, 9)); q += int(rng.integers(-3, 12))
+                rows.append(mk_anchor(strand, rid, pos, max(q, 0), seg=int(rng.integers(0, 2)) if seg_ids else 0))
+        tasks.append(pack(rows))
+    return tasks
+
+
+@pytest.mark.parametrize("seg_min,cut_min", [(1, 1), (64, 300), (256, 2000), (1000, 1)])
+def test_plans_cut_long_tasks_on_the_device(seg_min, cut_min):
+    """device-resident plans cut tasks of plan_cut_min anchors or more at empty windows into pieces (chain_cut); f/p, the chains of the
+    device epilogue, the avg_qspan of cut and uncut tasks, and the general-variant redo pass must not notice"""
+    import mm2chain
+    from mm2chain import params
+    tasks = _multi_locus_tasks(123, 9) + [_stream("mixed", 1, (700, 700), seed=5)[1], np.zeros((0, 2), np.uint64)] + _multi_locus_tasks(124, 3, seg_ids=True)
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    try:
+        mm2chain.tune("seg_min", seg_min); mm2chain.tune("plan_cut_min", cut_min)
+        for P in (params.map_ont(), params.make_params(max_skip=300), params.make_params(n_segs=2)):
+            f_ref, p_ref = oracle_batch(P, off, a)
+            f, p = gpu_batch(P, off, a)
+            assert_same(f, p, f_ref, p_ref, off, f"seg_min {seg_min} cut_min {cut_min}")
+        P = params.map_ont()
+        plan = mm2chain.ChainPlan(P, off)
+        d_a = torch.from_numpy(a.view(np.int64)).cuda()
+        d_f = torch.empty(a.shape[0], dtype=torch.int32, device="cuda"); d_p = torch.empty_like(d_f)
+        plan.run(d_a, d_f, d_p)
+        u_off, u, b_off, b = plan.chains(d_a, d_f, d_p, 3, 40)
+        torch.cuda.synchronize()
+        uo, bo = u_off.cpu().numpy(), b_off.cpu().numpy()
+        u, b = u.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64)
+        plan.close()
+        for k in range(off.size - 1):
+            u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, a[off[k]:off[k + 1]])
+            assert np.array_equal(u[uo[k]:uo[k + 1]], u_ref) and np.array_equal(b[bo[k]:bo[k + 1]], b_ref), f"task {k}: chains differ"
+    finally:
+        mm2chain.tune("seg_min", 256); mm2chain.tune("plan_cut_min", 8192)
+
+
+def test_plan_with_one_very_long_task_is_cut_by_default():
+    """default knobs: a 60 000-anchor read made of many loci among short reads"""
+    import mm2chain
+    from mm2chain import params
+    tasks = _multi_locus_tasks(7, 1, loci=(150, 151), per_locus=(300, 500)) + _multi_locus_tasks(8, 6)
+    assert tasks[0].shape[0] > 45000
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    P = params.map_ont()
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, "long task")
+
+
 def test_concurrent_callers_are_combined_into_shared_passes():
     """the reference's call pattern (map.c:561): many host threads, each blocking in a per-read chaining call"""
     import threading

@@ -13,6 +13,8 @@ INT32_MAX = 2**31 - 1
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 mm2chain.init()
+if os.environ.get("MM2C_SOAK_CUT"):          # exercise the device-side cut of plans on small tasks as well
+    mm2chain.tune("plan_cut_min", 100); mm2chain.tune("seg_min", int(os.environ["MM2C_SOAK_CUT"]))
 t0 = time.time(); n_anchor = 0; bad = 0
 for r in range(rounds):
     rng = np.random.default_rng(seed0 + r)
