@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include "chain_kernel.h"
+#include "radix_replay.h"
 
 namespace mm2c {
 
@@ -380,156 +381,47 @@ __global__ __launch_bounds__(1024) void epi_offsets(EpiArgs A)
 	for (int64_t t = t0; t < t1; ++t) { A.u_off[t] = su; A.b_off[t] = sb; su += A.cnt_u[t]; sb += A.cnt_b[t]; }
 }
 
-// ---- the passes of radix_sort_128x (ksort.h:101-151) on (x, chain) records, one lane -------------------------------
-__device__ void insertion_pass(uint64_t *x, int32_t *c, int lo, int hi)
-{
-	for (int q = lo + 1; q < hi; ++q) {
-		if (x[q] >= x[q - 1]) continue;
-		const uint64_t kx = x[q]; const int32_t kc = c[q];
-		int r = q;
-		for (; r > lo && kx < x[r - 1]; --r) { x[r] = x[r - 1]; c[r] = c[r - 1]; }
-		x[r] = kx; c[r] = kc;
-	}
-}
-
-__device__ void flag_sort_one_lane(uint64_t *x, int32_t *c, int n, int32_t *stack, int *hist, int *blo, int *bhi)
-{
-	if (n <= 64) { insertion_pass(x, c, 0, n); return; }
-	int sp = 0;
-	stack[0] = 0; stack[1] = n; stack[2] = 56; sp = 3;
-	while (sp > 0) {
-		sp -= 3;
-		const int lo = stack[sp], hi = stack[sp + 1], shift = stack[sp + 2];
-		for (int d = 0; d < 256; ++d) hist[d] = 0;
-		for (int q = lo; q < hi; ++q) ++hist[(int)(x[q] >> shift) & 255];
-		for (int d = 0, q = lo; d < 256; ++d) { blo[d] = q; q += hist[d]; bhi[d] = q; }
-		for (int d = 0; d < 256; ) {
-			if (blo[d] == bhi[d]) { ++d; continue; }
-			int dst = (int)(x[blo[d]] >> shift) & 255;
-			if (dst == d) { ++blo[d]; continue; }
-			uint64_t hx = x[blo[d]]; int32_t hc = c[blo[d]];
-			do {
-				const int at = blo[dst]++;
-				const uint64_t nx = x[at]; const int32_t nc = c[at];
-				x[at] = hx; c[at] = hc; hx = nx; hc = nc;
-				dst = (int)(hx >> shift) & 255;
-			} while (dst != d);
-			x[blo[d]] = hx; c[blo[d]] = hc; ++blo[d];
-		}
-		if (shift == 0) continue;
-		const int ns = shift > 8 ? shift - 8 : 0;
-		for (int d = 0, q = lo; d < 256; ++d) {
-			const int e = bhi[d];
-			if (e - q > 64) { stack[sp] = q; stack[sp + 1] = e; stack[sp + 2] = ns; sp += 3; }
-			else if (e - q > 1) insertion_pass(x, c, q, e);
-			q = e;
-		}
-	}
-}
-
 // ---- kernel T: tasks with more than 64 chains and equal first-x values: the order radix_sort_128x leaves (chain.c:411) ----
-// Records live in LDS.  Per pass (ksort.h:108-139): histogram and bucket bounds in parallel, the cycle-leader distribution on one
-// lane (its result depends on the order of the swaps), the insertion sorts of the sub-buckets (stable, ksort.h:89-99) as a parallel
-// stable rank sort.  A pass whose records all share the digit moves nothing and hands the whole range to the next byte, so the
-// passes down to the highest byte in which the records differ are skipped.
-constexpr int TS_MAX = 512;
+// radix_replay.h on the chain records (x of the first anchor, chain) in rank order; only buckets that hold equal keys are replayed, then a
+// stable sort of the replayed arrangement gives the reference's array.  The index array lives in LDS for up to TS_MAX chains.
+constexpr int TS_MAX = 4096;
 
 __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 {
-	__shared__ uint64_t s_x[TS_MAX], s_tx[TS_MAX];
-	__shared__ int s_c[TS_MAX], s_tc[TS_MAX], s_cur[256], s_lo[256], s_hi[256], s_stack[3 * 16], s_sp;
+	__shared__ uint16_t s_id[TS_MAX];
+	__shared__ uint8_t s_dg[TS_MAX];
+	__shared__ int s_cur[256], s_lo[256], s_hi[256], s_sp;
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int lane = (int)threadIdx.x;
 	const int nk = (int)(A.seg_end2[task] - (uint32_t)base);
 	if (nk <= 64) return;                                                        // insertion sort only: stable (ksort.h:141-143)
-	uint64_t *sx = A.rkey1 + base;
-	int32_t *ord = A.val1 + base;
-	bool tie = false;
-	for (int i = lane; i + 1 < nk; i += 64) tie |= sx[i] == sx[i + 1];
-	if (!__ballot(tie)) return;                                                  // distinct keys: the order is unique
-	if (nk > TS_MAX) {                                                           // does not fit the LDS: replay on one lane in global memory
-		uint64_t *tmp = A.key0 + base;                                          // back to rank order (chain k at index k), as chain.c:407-410 fills w[]
-		__syncthreads();
-		for (int i = lane; i < nk; i += 64) tmp[ord[i]] = sx[i];
-		__syncthreads();
-		for (int i = lane; i < nk; i += 64) { sx[i] = tmp[i]; ord[i] = i; }
-		__syncthreads();
-		if (lane == 0) flag_sort_one_lane(sx, ord, nk, A.dest + base, s_cur, s_lo, s_hi);
-		return;
+	uint64_t *sx = A.rkey1 + base, *rank_x = A.key0 + base;                      // first-x keys: sorted / in rank order (chain k at index k)
+	int32_t *ord = A.val1 + base, *ids = A.val0 + base, *tiecnt = A.dest + base, *stack = A.ctop + base;
+	// tiecnt[i] = equal neighbours before position i of the sorted keys
+	int run = 0;
+	for (int i0 = 0; i0 < nk; i0 += 64) {
+		const int i = i0 + lane;
+		const int flag = (i + 1 < nk && sx[i] == sx[i + 1]) ? 1 : 0;
+		const int incl = wave_incl_scan(flag, lane);
+		if (i < nk) tiecnt[i] = run + incl - flag;
+		run += __shfl(incl, 63);
 	}
-	for (int i = lane; i < nk; i += 64) { const int kk = ord[i]; s_x[kk] = sx[i]; s_c[kk] = kk; }   // rank order, as chain.c:407-410 fills w[]
-	if (lane == 0) { s_stack[0] = 0; s_stack[1] = nk; s_stack[2] = 56; s_sp = 1; }
-	for (;;) {
-		__syncthreads();
-		const int sp = s_sp;
-		if (sp == 0) break;
-		const int lo = s_stack[3 * sp - 3], hi = s_stack[3 * sp - 2];
-		int shift = s_stack[3 * sp - 1];
-		__syncthreads();
-		if (lane == 0) s_sp = sp - 1;
-		const uint64_t x0 = s_x[lo];
-		uint64_t diff = 0;
-		for (int q = lo + lane; q < hi; q += 64) diff |= s_x[q] ^ x0;
-		for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
-		if (shift < 56) diff &= (1ull << (shift + 8)) - 1;
-		if (diff == 0) continue;                                                 // equal from this byte down: every later pass is a no-op
-		shift = (63 - __clzll(diff)) & ~7;
-		for (int d = lane; d < 256; d += 64) s_cur[d] = 0;
-		__syncthreads();
-		for (int q = lo + lane; q < hi; q += 64) atomicAdd(&s_cur[(int)(s_x[q] >> shift) & 255], 1);
-		__syncthreads();
-		{
-			int h[4], sum = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { h[k] = s_cur[4 * lane + k]; sum += h[k]; }
-			int at = lo + wave_incl_scan(sum, lane) - sum;
-			__syncthreads();
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; s_cur[4 * lane + k] = at; at += h[k]; s_hi[4 * lane + k] = at; }
-		}
-		__syncthreads();
-		if (lane == 0) {                                                         // ksort.h:117-131
-			for (int d = 0; d < 256; ) {
-				const int bl = s_cur[d];
-				if (bl == s_hi[d]) { ++d; continue; }
-				int dst = (int)(s_x[bl] >> shift) & 255;
-				if (dst == d) { s_cur[d] = bl + 1; continue; }
-				uint64_t hx = s_x[bl]; int hc = s_c[bl];
-				do {
-					const int at = s_cur[dst]++;
-					const uint64_t nx = s_x[at]; const int nc = s_c[at];
-					s_x[at] = hx; s_c[at] = hc; hx = nx; hc = nc;
-					dst = (int)(hx >> shift) & 255;
-				} while (dst != d);
-				s_x[s_cur[d]] = hx; s_c[s_cur[d]] = hc; ++s_cur[d];
-			}
-		}
-		__syncthreads();
-		if (shift == 0) continue;                                                // ksort.h:132
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int d = 4 * lane + k;
-			if (s_hi[d] - s_lo[d] > 64) {
-				const int slot = atomicAdd(&s_sp, 1);
-				s_stack[3 * slot] = s_lo[d]; s_stack[3 * slot + 1] = s_hi[d]; s_stack[3 * slot + 2] = shift - 8;
-			}
-		}
-		for (int q = lo + lane; q < hi; q += 64) {                               // sub-buckets of 2..64 records: stable sort on x
-			const uint64_t xq = s_x[q];
-			const int d = (int)(xq >> shift) & 255, bl = s_lo[d], bh = s_hi[d];
-			int at = q;
-			if (bh - bl > 1 && bh - bl <= 64) {
-				int rank = 0;
-				for (int e = bl; e < bh; ++e) { const uint64_t xe = s_x[e]; rank += (xe < xq) || (xe == xq && e < q); }
-				at = bl + rank;
-			}
-			s_tx[at] = xq; s_tc[at] = s_c[q];
-		}
-		__syncthreads();
-		for (int q = lo + lane; q < hi; q += 64) { s_x[q] = s_tx[q]; s_c[q] = s_tc[q]; }
+	if (run == 0) return;                                                        // distinct keys: the order is unique
+	__syncthreads();
+	for (int i = lane; i < nk; i += 64) rank_x[ord[i]] = sx[i];                  // back to rank order, as chain.c:407-410 fills w[]
+	__syncthreads();
+	if (nk <= TS_MAX) {
+		replay_passes<uint16_t, false>(rank_x, 1, sx, 1, tiecnt, nk, s_id, s_dg, stack, nullptr, lane, s_cur, s_lo, s_hi, &s_sp);
+		for (int i = lane; i < nk; i += 64) ids[i] = (int32_t)s_id[i];
+	} else {                                                                     // does not fit the LDS: same replay through global memory
+		uint8_t *g_dg = (uint8_t *)(stack + 2 * (nk / 64 + 2));
+		replay_passes<uint32_t, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, nullptr, lane, s_cur, s_lo, s_hi, &s_sp);
 	}
-	for (int i = lane; i < nk; i += 64) ord[i] = s_c[i];
+	__syncthreads();
+	for (int i = lane; i < nk; i += 64) sx[i] = rank_x[ids[i]];                  // keys of the replayed arrangement
+	__syncthreads();
+	wave_sort64<false>(sx, rank_x, ids, ord, nk, lane, s_cur);                   // stable: = the insertion sorts of ksort.h:144, sorted order elsewhere
 }
 
 // ---- kernel C: final chain order, u[] and b[] (chain.c:397-420) -----------------------------------------------------

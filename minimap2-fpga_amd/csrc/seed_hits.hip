@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include "chain_kernel.h"
+#include "radix_replay.h"
 
 namespace mm2c {
 
@@ -263,120 +264,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	if (lane == 0) A.has_ties[read] = run > 0;
 }
 
-// ---- kernel 3: replay of radix_sort_128x for reads with equal x ----------------------------------------------------
-// The arrangement is an index array id[] (position -> anchor of the unsorted array) with the current digit dg[] beside it.
-template <typename IdT>
-__device__ void replay_passes(const ulonglong2 *un, const ulonglong2 *sorted, const int32_t *tiecnt, int n, IdT *id, uint8_t *dg, int32_t *stack,
-                              int32_t *work, int lane, int *s_cur, int *s_lo, int *s_hi, int *s_sp)
-{
-	for (int i = lane; i < n; i += 64) id[i] = (IdT)i;
-	if (lane == 0) { stack[0] = 0; stack[1] = n; *s_sp = 1; }                  // only buckets that hold equal keys are ever pushed
-	for (;;) {
-		__syncthreads();
-		const int sp = *s_sp;
-		if (sp == 0) break;
-		const int lo = stack[2 * sp - 2], hi = stack[2 * sp - 1];
-		__syncthreads();
-		if (lane == 0) *s_sp = sp - 1;
-		// the keys of a bucket are the keys of the same positions of the sorted array: smallest and largest differ first in the
-		// highest byte in which any two differ; the passes above that byte move nothing (one bucket each, ksort.h:117-131)
-		const uint64_t diff = sorted[lo].x ^ sorted[hi - 1].x;
-		if (diff == 0) continue;                                                 // all equal: every pass is a no-op
-		const int shift = (63 - __clzll(diff)) & ~7;
-		for (int d = lane; d < 256; d += 64) s_cur[d] = 0;
-		__syncthreads();
-		for (int q0 = lo; q0 < hi; q0 += 256) {                                  // four gathers in flight per lane
-			uint64_t x[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; x[k] = q < hi ? un[id[q]].x : 0; }
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int q = q0 + 64 * k + lane;
-				if (q < hi) { const int d = (int)(x[k] >> shift) & 255; dg[q] = (uint8_t)d; atomicAdd(&s_cur[d], 1); }
-			}
-		}
-		__syncthreads();
-		{
-			int h[4], sum = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { h[k] = s_cur[4 * lane + k]; sum += h[k]; }
-			int at = lo + wave_incl_scan(sum, lane) - sum;
-			__syncthreads();
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; s_cur[4 * lane + k] = at; at += h[k]; s_hi[4 * lane + k] = at; }
-		}
-		__syncthreads();
-		int n_buckets = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) n_buckets += s_hi[4 * lane + k] > s_lo[4 * lane + k];
-		for (int o = 32; o > 0; o >>= 1) n_buckets += __shfl_xor(n_buckets, o);
-		if (n_buckets == 2) {
-			// Two buckets A | B (the strand byte, often the top position byte): the distribution has a closed form, no lane has to walk.
-			// Bucket A is filled first (ksort.h:118).  Its t-th misplaced record starts a cycle: it is dropped at B's cursor, the records
-			// of B that follow are pushed one place on until B's t-th misplaced record falls out, and that one comes back to the slot the
-			// cycle started from.  So A's misplaced slot t gets B's t-th misplaced record; in B the t-th record from A lands right after
-			// B's misplaced slot t-1 (at B's start for t = 0) and the B-records before misplaced slot t move one place up.
-			const int da = (int)(sorted[lo].x >> shift) & 255, db = (int)(sorted[hi - 1].x >> shift) & 255;
-			const int mid = s_hi[da], sz = hi - lo, half = (sz + 1) / 2 + 1;
-			int32_t *g = work + 4 * (int64_t)lo;                                // 4 ints of scratch per position of the bucket
-			int32_t *fposA = g, *fidA = g + half, *fposB = g + 2 * half, *fidB = g + 3 * half, *newB = g + 4 * half;
-			int F = 0;
-			for (int q0 = lo; q0 < mid; q0 += 64) {
-				const int q = q0 + lane;
-				const bool foreign = q < mid && dg[q] != da;
-				const uint64_t m = __ballot(foreign);
-				if (foreign) { const int t = F + lanes_before(m); fposA[t] = q; fidA[t] = (int32_t)id[q]; }
-				F += __popcll(m);
-			}
-			int FB = 0;
-			for (int q0 = mid; q0 < hi; q0 += 64) {
-				const int q = q0 + lane;
-				const bool in = q < hi, foreign = in && dg[q] != db;
-				const uint64_t m = __ballot(foreign);
-				const int t = FB + lanes_before(m);                              // misplaced slots of B before q
-				if (foreign) { fposB[t] = q; fidB[t] = (int32_t)id[q]; }
-				else if (in) newB[q + (t < F ? 1 : 0) - mid] = (int32_t)id[q];
-				FB += __popcll(m);
-			}
-			__syncthreads();
-			for (int t = lane; t < F; t += 64) {
-				id[fposA[t]] = (IdT)fidB[t];
-				newB[(t == 0 ? mid : fposB[t - 1] + 1) - mid] = fidA[t];
-			}
-			__syncthreads();
-			for (int q = mid + lane; q < hi; q += 64) id[q] = (IdT)newB[q - mid];
-			__syncthreads();
-		} else if (lane == 0) {                                                  // ksort.h:117-131
-			for (int d = 0; d < 256; ) {
-				const int bl = s_cur[d];
-				if (bl == s_hi[d]) { ++d; continue; }
-				int dst = dg[bl];
-				if (dst == d) { s_cur[d] = bl + 1; continue; }
-				IdT hid = id[bl]; uint8_t hd = (uint8_t)dst;
-				do {
-					const int at = s_cur[dst]++;
-					const IdT nid = id[at]; const uint8_t nd = dg[at];
-					id[at] = hid; dg[at] = hd; hid = nid; hd = nd;
-					dst = hd;
-				} while (dst != d);
-				id[s_cur[d]] = hid; dg[s_cur[d]] = hd; ++s_cur[d];
-			}
-		}
-		__syncthreads();
-		if (shift == 0) continue;                                                // ksort.h:132
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int d = 4 * lane + k, bl = s_lo[d], bh = s_hi[d];
-			// ksort.h:143: buckets of more than 64 records get the next pass (smaller ones an insertion sort = the final stable sort);
-			// those without equal keys end up in their one sorted order whatever happens inside
-			if (bh - bl > 64 && tiecnt[bh - 1] - tiecnt[bl] > 0) {
-				const int slot = atomicAdd(s_sp, 1);
-				stack[2 * slot] = bl; stack[2 * slot + 1] = bh;
-			}
-		}
-	}
-}
-
+// ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
 // The replay of a read needs 3 bytes of LDS per anchor; four size classes keep the occupancy of the common (short) reads high.
 // CAP = 0: reads beyond the largest class, arrays in global memory.
 constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 20480;   // the last one: 60 of the 64 KB a block may take
@@ -396,12 +284,12 @@ __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
 	int32_t *stack = A.stack + 2 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice
 	if (CAP) {
-		replay_passes<uint16_t>(un, out, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
+		replay_passes<uint16_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
 #pragma unroll 4
 		for (int i = lane; i < na; i += 64) tmp[i] = un[s_id[i]];
 	} else {
 		uint32_t *g_id = A.big_id + a0; uint8_t *g_dg = A.big_dg + a0;
-		replay_passes<uint32_t>(un, out, A.tiecnt + a0, na, g_id, g_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
+		replay_passes<uint32_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, g_id, g_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
 		for (int i = lane; i < na; i += 64) tmp[i] = un[g_id[i]];
 	}
 	__syncthreads();
