@@ -95,7 +95,7 @@ struct SeedArgs {
 	uint64_t *xdiff;                             // per read: the bits of x that differ among its anchors (written by seed_expand)
 	int32_t *tiecnt;                             // per anchor: equal-x neighbours before this position of the sorted read
 	int64_t biggest;                             // anchors of the longest read
-	int32_t *stack;                              // pending buckets of the tie replay: 2 * (total / 64 + 2 * n_reads + 2) ints
+	int32_t *stack;                              // pending buckets of the tie replay: 4 * (total / 64 + 2 * n_reads + 2) ints
 	uint32_t *big_id; uint8_t *big_dg;           // replay arrays for reads too long for the LDS (nullptr when there is none)
 };
 int seed_tie_lds_max();

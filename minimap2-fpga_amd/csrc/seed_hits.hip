@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 	const int na = (int)(A.d_anchor_off[read + 1] - a0);
 	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
-	int32_t *stack = A.stack + 2 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice
+	int32_t *stack = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice (room for two such lists)
 	if (CAP) {
 		replay_passes<uint16_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
 #pragma unroll 4
@@ -294,6 +294,31 @@ __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 	}
 	__syncthreads();
 	wave_sort_anchors(tmp, un, out, na, lane, s_cur);                            // stable: keeps the replayed order among equal x; `un` is free now
+}
+
+// The same for the longest reads that fit the LDS, on the four waves of a workgroup: their replay is what a batch waits for, and the
+// buckets of one level are independent (radix_replay.h, replay_levels).
+constexpr int TIE_MW_LO = TIE_CAP2, TIE_MW_HI = 16384, TIE_MW_WAVES = 4;
+
+__global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
+{
+	__shared__ uint16_t s_id[TIE_MW_HI];
+	__shared__ uint8_t s_dg[TIE_MW_HI];
+	__shared__ int s_cur[256 * TIE_MW_WAVES], s_lo[256 * TIE_MW_WAVES], s_hi[256 * TIE_MW_WAVES], s_n[2];
+	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
+	const int tid = (int)threadIdx.x;
+	const int64_t a0 = A.d_anchor_off[read];
+	const int na = (int)(A.d_anchor_off[read + 1] - a0);
+	if (na <= TIE_MW_LO || na > TIE_MW_HI) return;
+	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
+	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);
+	replay_levels<uint16_t, true, TIE_MW_WAVES>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, lists, lists + 2 * (na / 64 + 2),
+	                                             (int32_t *)tmp, tid, s_cur, s_lo, s_hi, s_n);
+	for (int i = tid; i < na; i += 64 * TIE_MW_WAVES) tmp[i] = un[s_id[i]];
+	__syncthreads();
+	if (tid >= 64) return;                                                       // the final stable sort is a one-wave routine
+	wave_sort_anchors(tmp, un, out, na, tid, s_cur);
 }
 
 } // namespace
@@ -313,30 +338,40 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (n_launches) *n_launches += 2;
 	// the grid is in order of decreasing read length: each class covers a contiguous range of blocks, the others exit at once
-	const bool use[5] = { true, A.biggest > TIE_CAP0, A.biggest > TIE_CAP1, A.biggest > TIE_CAP2, A.biggest > TIE_CAP3 };
-	if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+	const bool use[5] = { true, A.biggest > TIE_CAP0, A.biggest > TIE_CAP1, A.biggest > TIE_MW_HI, A.biggest > TIE_CAP3 };
+	if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;                 // fork
+	bool used[3] = { false, false, false };
+	if (A.biggest > TIE_MW_LO) {                                                 // the multi-wave class, on a helper stream of its own
+		hipStream_t s = aux ? aux[2] : st;
+		if (s != st) { if ((e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e; used[2] = true; }
+		hipLaunchKernelGGL(seed_ties_mw, dim3(nr), dim3(64 * TIE_MW_WAVES), 0, s, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (n_launches) ++*n_launches;
+	}
 	int helper = 0;
 	for (int c = 4; c >= 0; --c) {                                              // the longest reads first
 		if (!use[c]) continue;
 		hipStream_t s = st;
-		if (c != 0 && aux && helper < 3) {                                       // class 0 (and whatever exceeds the helpers) stays on the caller's stream
+		if (c != 0 && aux && helper < 2) {                                       // class 0 (and whatever exceeds the helpers) stays on the caller's stream
 			s = aux[helper];
-			if ((e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e;
+			if (!used[helper] && (e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e;
+			used[helper] = true;
+			++helper;
 		}
 		switch (c) {
 		case 4: hipLaunchKernelGGL((seed_ties<0, TIE_CAP3>), dim3(nr), dim3(64), 0, s, A); break;
-		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2>), dim3(nr), dim3(64), 0, s, A); break;
+		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_MW_HI>), dim3(nr), dim3(64), 0, s, A); break;
 		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1>), dim3(nr), dim3(64), 0, s, A); break;
 		case 1: hipLaunchKernelGGL((seed_ties<TIE_CAP1, TIE_CAP0>), dim3(nr), dim3(64), 0, s, A); break;
 		default: hipLaunchKernelGGL((seed_ties<TIE_CAP0, 0>), dim3(nr), dim3(64), 0, s, A); break;
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		if (n_launches) ++*n_launches;
-		if (s != st) {
-			if ((e = hipEventRecord(ev[1 + helper], s)) != hipSuccess) return e;
-			if ((e = hipStreamWaitEvent(st, ev[1 + helper], 0)) != hipSuccess) return e;
-			++helper;
-		}
+	}
+	for (int h = 0; h < 3; ++h) {                                               // join
+		if (!used[h]) continue;
+		if ((e = hipEventRecord(ev[1 + h], aux[h])) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(st, ev[1 + h], 0)) != hipSuccess) return e;
 	}
 	return hipSuccess;
 }

@@ -109,6 +109,20 @@ def test_reads_too_long_for_the_lds_replay():
     assert _check(reads, "long") > 1000
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_reads_of_the_multi_wave_replay_class(seed):
+    """12 289 .. 16 384 anchors with equal x: the replay runs level by level on the four waves of a workgroup (replay_levels)"""
+    rng = np.random.default_rng(900 + seed)
+    reads = []
+    for pos_range, rids, dup in ((40000, 2, 0.0), (1 << 22, 3, 0.3), (3000, 1, 0.1)):
+        while True:
+            r = _random_read(rng, 3400, 8, rids, pos_range, qlen=40000, dup_frac=dup)
+            if 12288 < int(r[1]["n"].sum()) <= 16384:
+                break
+        reads.append(r)
+    assert _check(reads, f"mw {seed}") > 100
+
+
 def test_anchor_offsets_that_do_not_match_the_hit_counts_are_reported():
     import mm2chain
     rng = np.random.default_rng(3)
