@@ -296,6 +296,59 @@ __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 	wave_sort_anchors(tmp, un, out, na, lane, s_cur);                            // stable: keeps the replayed order among equal x; `un` is free now
 }
 
+// ---- the key sort of wave_sort_keys on the NW waves of a workgroup (for ONE long read whose sort a batch would otherwise wait for): per step
+// of 64 * NW records every wave ranks its own 64 (peers by ballots) and publishes its per-digit counts; a record's place is the digit's
+// cursor + the counts of the waves before its own + its rank inside the wave (stable).  s_cnt: 256 ints, s_w: NW * 256 ints of LDS.
+template <int NW>
+__device__ uint64_t *block_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo, int n_bits, int tid, int *s_cnt, int *s_w)
+{
+	const int lane = tid & 63, wave = tid >> 6;
+	uint64_t *from = a, *to = b;
+	for (int shift = bit_lo; shift < bit_lo + n_bits; shift += 8) {
+		const int mask = bit_lo + n_bits - shift >= 8 ? 255 : (1 << (bit_lo + n_bits - shift)) - 1;
+		for (int d = tid; d < 256; d += 64 * NW) s_cnt[d] = 0;
+		for (int d = tid; d < 256 * NW; d += 64 * NW) s_w[d] = 0;
+		__syncthreads();
+		for (int i = tid; i < n; i += 64 * NW) atomicAdd(&s_cnt[(int)(from[i] >> shift) & mask], 1);
+		__syncthreads();
+		if (wave == 0) {
+			int h[4], sum = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { h[u] = s_cnt[4 * lane + u]; sum += h[u]; }
+			int at = wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { s_cnt[4 * lane + u] = at; at += h[u]; }
+		}
+		__syncthreads();
+		for (int i0 = 0; i0 < n; i0 += 64 * NW) {
+			const int i = i0 + tid;
+			const bool valid = i < n;
+			const uint64_t k = valid ? from[i] : 0;
+			const int d = (int)(k >> shift) & mask;
+			uint64_t peers = __ballot(valid);
+#pragma unroll
+			for (int bb = 0; bb < 8; ++bb) {
+				const uint64_t bal = __ballot((d >> bb) & 1);
+				peers &= ((d >> bb) & 1) ? bal : ~bal;
+			}
+			const int rank = lanes_before(peers);
+			if (valid && rank == 0) s_w[256 * wave + d] = __popcll(peers);
+			__syncthreads();
+			if (valid) {
+				int before = 0;
+				for (int w = 0; w < wave; ++w) before += s_w[256 * w + d];
+				to[s_cnt[d] + before + rank] = k;
+			}
+			__syncthreads();
+			if (valid && rank == 0) { atomicAdd(&s_cnt[d], __popcll(peers)); s_w[256 * wave + d] = 0; }
+			__syncthreads();
+		}
+		{ uint64_t *t = from; from = to; to = t; }
+	}
+	__syncthreads();
+	return from;
+}
+
 // The same for the longest reads that fit the LDS, on the four waves of a workgroup: their replay is what a batch waits for, and the
 // buckets of one level are independent (radix_replay.h, replay_levels).
 constexpr int TIE_MW_LO = TIE_CAP2, TIE_MW_HI = 16384, TIE_MW_WAVES = 4;
@@ -315,9 +368,28 @@ __global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
 	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);
 	replay_levels<uint16_t, true, TIE_MW_WAVES>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, lists, lists + 2 * (na / 64 + 2),
 	                                             (int32_t *)tmp, tid, s_cur, s_lo, s_hi, s_n);
+	// the final stable sort of the replayed arrangement, also on all four waves: keys = (differing bits of x, squeezed) << id bits | position
+	// in the arrangement, as in seed_sort
+	const uint64_t diff = A.xdiff[read];
+	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
+	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);
+	const int kb = b0 + b1 + bs, idb = 32 - __clz(na - 1);
+	if (kb + idb <= 64) {
+		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;
+		const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+		for (int q = tid; q < na; q += 64 * TIE_MW_WAVES) {
+			const uint64_t x = un[s_id[q]].x;
+			ka[q] = ((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0)) << idb | (uint64_t)q;
+		}
+		__syncthreads();
+		const uint64_t *ks = block_sort_keys<TIE_MW_WAVES>(ka, kbuf, na, idb, kb, tid, s_cur, s_lo);   // the tables of the replay are free now
+		const uint64_t idm = (1ull << idb) - 1;
+		for (int i = tid; i < na; i += 64 * TIE_MW_WAVES) out[i] = un[s_id[(int)(ks[i] & idm)]];
+		return;
+	}
 	for (int i = tid; i < na; i += 64 * TIE_MW_WAVES) tmp[i] = un[s_id[i]];
 	__syncthreads();
-	if (tid >= 64) return;                                                       // the final stable sort is a one-wave routine
+	if (tid >= 64) return;                                                       // the anchors themselves: a one-wave routine
 	wave_sort_anchors(tmp, un, out, na, tid, s_cur);
 }
 
