@@ -397,15 +397,47 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	const ulonglong2 *a = a_all + base;
 	int32_t *st = st_all + base;
 	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
-	for (int i = lane; i < n; i += 256) {                          // 4 waves per task: the searches are latency bound
-		const uint64_t xi = a[i].x;
-		int lo = max(i - P.max_iter, 0), hi = i;                    // answer in [lo, i]; x_i <= x_i + D always holds
-		while (lo < hi) {
-			const int mid = (lo + hi) >> 1;
-			if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;       // chain.c:192 condition for "++st"
+	// st[] is monotone: the answers of a tile of 256 anchors start at the answer of the tile before.  When that range of x values fits
+	// the LDS it is staged there with coalesced loads (every x read about twice) and searched there; probing global memory costs a
+	// cache line per lane and step.
+	constexpr int STAGE = 2048;
+	__shared__ uint64_t s_x[STAGE];
+	__shared__ int s_prev;
+	if (lane == 0) s_prev = 0;
+	__syncthreads();
+	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
+		const int i = i0 + lane, cnt = min(256, n - i0);
+		const int range_lo = max(s_prev, max(i0 - P.max_iter, 0)), len = i0 + cnt - range_lo;
+		__syncthreads();                                            // s_prev read by everyone, s_x of the tile before no longer in use
+		int lo = 0;
+		if (len <= STAGE) {
+			for (int k = lane; k < len; k += 256) s_x[k] = a[range_lo + k].x;
+			__syncthreads();
+			if (i < n) {
+				const uint64_t xi = s_x[i - range_lo];
+				int hi = i - range_lo;
+				lo = max(i - P.max_iter, range_lo) - range_lo;          // answer in [lo, hi]; x_i <= x_i + D always holds
+				while (lo < hi) {
+					const int mid = (lo + hi) >> 1;
+					if (xi > s_x[mid] + D) lo = mid + 1; else hi = mid;   // chain.c:192 condition for "++st"
+				}
+				lo += range_lo;
+			}
+		} else if (i < n) {
+			const uint64_t xi = a[i].x;
+			int hi = i;
+			lo = max(i - P.max_iter, range_lo);
+			while (lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;
+			}
 		}
-		st[i] = lo;
-		if (has_cut && lo == i && i > 0) has_cut[task] = 1;          // an empty window: the task can be cut here (chain_cut)
+		if (i < n) {
+			st[i] = lo;
+			if (has_cut && lo == i && i > 0) has_cut[task] = 1;      // an empty window: the task can be cut here (chain_cut)
+			if (lane == cnt - 1) s_prev = lo;
+		}
+		__syncthreads();
 	}
 }
 
