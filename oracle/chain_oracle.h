@@ -15,6 +15,10 @@
  *      md5 f49a6331..., cm:i:342 s1:i:3189; t-inv vs q-inv; t2 vs q2) -- tests/test_cpu_ref_host.py;
  *  (b) by hand-derived known-answer cases from the recurrence and an independent Python restatement;
  *  (c) by a literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree under V2 parameters.
+ *  (d) mm2o_collect_seed_hits (map.c:215-247, incl. the unstable radix_sort_128x) against the anchor lists the reference's own map.o
+ *      produced for 27 reads, four of them with equal-x anchors (tests/golden/ref_seed_hits.npz, tests/test_cpu_oracle.py);
+ *  (e) the same end-to-end check as (a) at scale on the GPU box: the reference host objects with the oracle's mm_chain_dp and with the
+ *      product library print identical PAF for 400 000 simulated reads (profiles/r1_e2e_synth.md).
  * (a) constrains f[]/p[] through the chains they produce on three real anchor lists (n = 346, 223, 732), not element by
  * element on arbitrary inputs: element-wise coverage rests on (b) and (c).
  */
