@@ -234,3 +234,22 @@ def test_seed_hits_oracle_equals_the_reference_anchor_lists():
         assert np.array_equal(a, ref), f"read {k} ({d[f'r{k}_src']}): anchors differ from the reference's"
         n_ties += int((ref[1:, 0] == ref[:-1, 0]).sum())
     assert n_ties > 1000
+
+
+def test_matches_from_anchors_expand_back_into_the_same_anchors():
+    """synth.matches_from_anchors (the seed-hit input of bench.py and tools/seed_probe.py): collect_seed_hits of the derived matches gives the
+    anchors of the stream again (as a multiset, sorted by x; the order among equal x is the sort's)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minimap2-fpga_amd"))
+    from mm2chain import synth
+    for profile in ("mixed", "dense", "sparse", "colinear"):
+        off, a = synth.make_stream(profile, 3, (1, 1500), seed=17)
+        off = off.numpy(); a = a.numpy().view(np.uint64)
+        for k in range(3):
+            t = a[off[k]:off[k + 1]]
+            m, h = synth.matches_from_anchors(t, 1 << 20)
+            assert int(m["n"].sum()) == t.shape[0] and h.size == t.shape[0]
+            got = ob.collect_seed_hits(m, h, 1 << 20)
+            assert np.all(got[1:, 0] >= got[:-1, 0])
+            key = lambda z: z[np.lexsort((z[:, 1], z[:, 0]))]
+            assert np.array_equal(key(got), key(t)), (profile, k)
