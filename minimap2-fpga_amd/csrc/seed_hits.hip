@@ -155,19 +155,26 @@ __device__ void wave_sort_anchors(const ulonglong2 *src, ulonglong2 *alt, ulongl
 
 // ---- stable LSD radix sort of 8-byte keys on the bits [bit_lo, bit_lo + n_bits), ping-pong between a and b; returns the buffer that holds
 // the result ----
-__device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo, int n_bits, int lane, int *s_cnt /* 256 ints of LDS */)
+// s_hist (optional): the digit histograms of all passes, 256 ints per pass, counted by the caller while it made the keys (saves reading
+// the keys once more per pass)
+__device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo, int n_bits, int lane, int *s_cnt /* 256 ints of LDS */,
+                                    const int *s_hist = nullptr)
 {
 	uint64_t *from = a, *to = b;
-	for (int shift = bit_lo; shift < bit_lo + n_bits; shift += 8) {
+	for (int shift = bit_lo, pass = 0; shift < bit_lo + n_bits; shift += 8, ++pass) {
 		const int mask = bit_lo + n_bits - shift >= 8 ? 255 : (1 << (bit_lo + n_bits - shift)) - 1;
-		for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
-		__syncthreads();
-		for (int i0 = 0; i0 < n; i0 += 256) {
-			uint64_t k[4];
+		if (s_hist) {
+			for (int d = lane; d < 256; d += 64) s_cnt[d] = s_hist[256 * pass + d];
+		} else {
+			for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
+			__syncthreads();
+			for (int i0 = 0; i0 < n; i0 += 256) {
+				uint64_t k[4];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; k[u] = i < n ? from[i] : 0; }
+				for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; k[u] = i < n ? from[i] : 0; }
 #pragma unroll
-			for (int u = 0; u < 4; ++u) if (i0 + 64 * u + lane < n) atomicAdd(&s_cnt[(int)(k[u] >> shift) & mask], 1);
+				for (int u = 0; u < 4; ++u) if (i0 + 64 * u + lane < n) atomicAdd(&s_cnt[(int)(k[u] >> shift) & mask], 1);
+			}
 		}
 		__syncthreads();
 		{
@@ -214,7 +221,7 @@ __device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo,
 // against 6 byte positions of the full x).  Falls back to sorting the anchors themselves if the squeezed bits do not fit.
 __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 {
-	__shared__ int s_cnt[256];
+	__shared__ int s_cnt[256], s_hist[4 * 256];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int lane = (int)threadIdx.x;
 	const int64_t a0 = A.d_anchor_off[read];
@@ -232,13 +239,17 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	if (kb + idb <= 64) {
 		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;                        // the two halves of the 16-byte-per-anchor scratch
 		const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+		const bool fused = kb <= 32;                                            // up to four passes: their histograms are counted right here
+		if (fused) { for (int d = lane; d < 4 * 256; d += 64) s_hist[d] = 0; __syncthreads(); }
 		for (int i = lane; i < na; i += 64) {
 			const uint64_t x = un[i].x;
 			const uint64_t sq = (x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0);   // order preserving: the dropped bits are constant
 			ka[i] = sq << idb | (uint64_t)i;
+			if (fused)
+				for (int pass = 0; 8 * pass < kb; ++pass) atomicAdd(&s_hist[256 * pass + ((int)(sq >> (8 * pass)) & 255)], 1);   // the top digit may be partial: its high bits are zero
 		}
 		__syncthreads();
-		const uint64_t *ks = wave_sort_keys(ka, kbuf, na, idb, kb, lane, s_cnt);
+		const uint64_t *ks = wave_sort_keys(ka, kbuf, na, idb, kb, lane, s_cnt, fused ? s_hist : nullptr);
 		const uint64_t idm = (1ull << idb) - 1;
 		// gather, and tiecnt[i] = number of positions j < i with x[j] == x[j+1]: tells in O(1) whether a range of positions (= a bucket
 		// of the reference's sort, before and after it) holds equal keys
