@@ -320,7 +320,14 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		// work arena: [f | p | t | st | epilogue scratch]; result arena: [u_off | b_off | u | b]
 		mm2c::EpiArgs E;
 		const size_t tmp = mm2c::epilogue_sort_temp_bytes((int64_t)tot, (int64_t)nt);
-		const size_t o_epi = align16(tot * 16), work_bytes = o_epi + layout_epilogue(E, nullptr, tot, nt, tmp);
+		// long tasks are cut into independent pieces on the device, as plans do (chain_cut)
+		int64_t extra = 0;
+		if (G.plan_cut && G.seg_min > 0)
+			for (size_t k = 0; k < nt; ++k) { const int64_t len = m_off[k + 1] - m_off[k]; if (len >= G.plan_cut_min) extra += len / G.seg_min; }
+		const size_t mp = extra > 0 ? nt + (size_t)extra : 0;
+		const size_t o_epi = align16(tot * 16), epi_bytes = layout_epilogue(E, nullptr, tot, nt, tmp);
+		const size_t o_cut = align16(o_epi + epi_bytes), o_cstat = o_cut + 256, o_chc = align16(o_cstat + mp * 4), o_cstart = align16(o_chc + nt * 4),
+		             o_cend = align16(o_cstart + mp * 8), o_cpb = align16(o_cend + mp * 8), o_cavg = align16(o_cpb + mp * 4), work_bytes = align16(o_cavg + mp * 4);
 		if ((r = grow_device(&w.d_work, &w.cap_work, work_bytes))) return r;
 		layout_epilogue(E, w.d_work + o_epi, tot, nt, tmp);
 		const size_t o_boff = align16((nt + 1) * 8);
@@ -336,6 +343,13 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
 		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
 		L.ring_class = G.ring_class;
+		if (mp > 0 && mp <= (size_t)INT32_MAX) {
+			char *b = w.d_work;
+			L.cut.max_pieces = (int64_t)mp; L.cut.seg_min = G.seg_min; L.cut.min_anchors = G.plan_cut_min;
+			L.cut.d_count = (int32_t *)(b + o_cut); L.cut.d_status = (int32_t *)(b + o_cstat); L.cut.d_has_cut = (int32_t *)(b + o_chc);
+			L.cut.d_start = (int64_t *)(b + o_cstart); L.cut.d_end = (int64_t *)(b + o_cend); L.cut.d_pbase = (int32_t *)(b + o_cpb); L.cut.d_avg = (float *)(b + o_cavg);
+			HIP_TRY(hipMemsetAsync(b + o_cut, 0, o_cstart - o_cut, w.st));          // count, status, has_cut
+		}
 		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr));
 		E.n_tasks = (int64_t)nt; E.total = (int64_t)tot; E.d_off = L.d_offsets; E.d_order = L.d_order;
 		E.d_a = (const ulonglong2 *)w.d_in; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;

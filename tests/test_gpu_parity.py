@@ -297,6 +297,9 @@ def test_plan_with_one_very_long_task_is_cut_by_default():
     f_ref, p_ref = oracle_batch(P, off, a)
     f, p = gpu_batch(P, off, a)
     assert_same(f, p, f_ref, p_ref, off, "long task")
+    # the whole-function host entry cuts on the device as well
+    res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
+    _assert_chains(res, P, 3, 40, off, a, "long task, whole function")
 
 
 def test_concurrent_callers_are_combined_into_shared_passes():
