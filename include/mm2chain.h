@@ -3,16 +3,17 @@
  *
  * Drop-in boundary for ONE hot path of kisarur/minimap2-fpga: the predecessor-scan DP that fills f[] / p[]
  * inside mm_chain_dp (chain.c:184-238), which the reference offloads through run_chaining_on_hw
- * (chain_hardware.h:68, chain_hardware.cpp:27-197, kernel device/minimap2_opencl.cl:24-182).
+ * (chain_hardware.h:68, chain_hardware.cpp:27-197, kernel device/minimap2_opencl.cl:24-182) -- and, for batched callers, the
+ * steps either side of it inside mm_map_frag: collect_seed_hits before (map.c:215-247, "seed hits -> sorted anchors") and the rest
+ * of mm_chain_dp after (chain.c:348-422, "f/p -> chains").
  *
  * Plain C: pointers and sizes only, no torch / C++ types.  All entry points return 0 on success and a
  * negative MM2C_E_* code on failure unless stated otherwise; mm2c_last_error() gives the message.  There is
  * NO CPU fallback anywhere behind this header: if no HIP device is usable every compute entry fails.
  *
- * Preconditions shared by every compute entry (they are the reference caller's guarantees):
- *   - anchors of one task are sorted ascending by x (map.c:245)
- *   - x = strand<<63 | rid<<32 | rpos with rpos < 2^31 (map.c:228-241), so anchors within max_dist_x of
- *     each other share the high 32 bits of x
+ * Preconditions shared by every chaining entry (they are the reference caller's guarantees):
+ *   - anchors of one task are sorted ascending by x (map.c:245); x = strand<<63 | rid<<32 | rpos (map.c:228-241) is compared as a
+ *     64-bit value, no layout inside it is assumed
  *   - 0 <= max_dist_x, and every task has n < 2^31 - 64 anchors (chain.c:30 "TODO" holds here too)
  */
 #ifndef MM2CHAIN_H
