@@ -102,10 +102,13 @@ def test_random_matches_against_the_oracle(seed):
 
 
 def test_reads_too_long_for_the_lds_replay():
-    """more than 12 288 anchors with equal x: the replay runs through global memory"""
+    """reads of the largest one-wave LDS class (16 385 .. 20 480 anchors) and beyond it (the replay runs through global memory), with equal x"""
     rng = np.random.default_rng(77)
-    reads = [_random_read(rng, 4000, 8, 2, 20000, qlen=60000), _random_read(rng, 3000, 10, 1, 1 << 24, qlen=60000, dup_frac=0.2)]
-    assert reads[0][1]["n"].sum() > 12288 and reads[1][1]["n"].sum() > 12288
+    reads = [_random_read(rng, 4500, 8, 2, 20000, qlen=60000), _random_read(rng, 3600, 10, 1, 1 << 24, qlen=60000, dup_frac=0.2),
+             _random_read(rng, 7000, 8, 2, 50000, qlen=90000), _random_read(rng, 9000, 6, 3, 1 << 25, qlen=90000, dup_frac=0.25)]
+    sizes = [int(r[1]["n"].sum()) for r in reads]
+    assert 16384 < sizes[0] <= 20480 or 16384 < sizes[1] <= 20480, sizes
+    assert sizes[2] > 20480 and sizes[3] > 20480, sizes
     assert _check(reads, "long") > 1000
 
 
