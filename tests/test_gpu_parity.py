@@ -455,12 +455,12 @@ def test_device_epilogue_equal_first_x_replays_the_reference_sort():
     from mm2chain import params
     P = params.map_ont()
     tasks = [_tandem_task(60, [3, 2, 1, 4], 1), _tandem_task(12, [3, 2], 2), _tandem_task(90, [1], 3), _tandem_task(150, [2, 5, 1], 4),
-             _tandem_task(300, [2, 3], 5)]      # the last one has more chains than the LDS variant of the replay holds
+             _tandem_task(300, [2, 3], 5), _tandem_task(1800, [2, 3], 6)]      # the last one has more chains than the LDS variant of the replay holds
     off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tasks])]).astype(np.int64)
     a = np.concatenate(tasks)
     res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
     _assert_chains(res, P, 3, 40, off, a, "tandem")
-    assert res[0][0].size > 64 and res[3][0].size > 64 and res[4][0].size > 512
+    assert res[0][0].size > 64 and res[3][0].size > 64 and res[4][0].size > 512 and res[5][0].size > 4096
     x_first = [int(res[0][1][i, 0]) for i in np.concatenate([[0], np.cumsum(res[0][0] & np.uint64(0xffffffff))[:-1]]).astype(np.int64)]
     assert len(set(x_first)) < len(x_first), "the test must contain chains that start at equal x"
 
