@@ -15,7 +15,9 @@
 //   * chunk 0 (the 64 nearest predecessors) lives in VGPRs and is shifted one lane per anchor with a
 //     DPP wave_shr:1, so the i -> i+1 dependency never goes through memory.
 //   * the window start of every anchor (chain.c:192-193) comes from a prepass kernel (chain_window_start, 64-bit
-//     binary searches), so the DP works on low words of x and knows each window exactly.
+//     binary searches over x values staged in LDS), so the DP works on low words of x and knows each window exactly.
+//   * plans first cut long tasks at empty windows into independent pieces (chain_cut): many waves instead of one long
+//     dependent chain for a read made of many loci.
 //   * chunks 1.. read an LDS ring of R anchors (x, q | f, p as two ds_read_b64 per lane, conflict-free); anchors
 //     arrive in coalesced 1 KiB tiles (one global_load_dwordx4 per lane per 64 anchors, next tile prefetched while
 //     the current one is processed) and a finished tile enters the ring in one shot, so the ring always holds the R
@@ -24,10 +26,11 @@
 //     fetched only for lanes that passed the filters.
 //   * chain.c's t[] (stamps "predecessor already on a visited chain") is a 16-bit stamp ring in LDS covering 2R
 //     anchors (scatter by p[j], gather by j, cleared as anchors enter), 32-bit stamps in a global scratch beyond it.
-//   * the kernel is integer-issue bound (measured: SQ_ACTIVE_INST_VALU ~84 %, SQ_ACTIVE_INST_SCA ~77 % of all SIMD cycles,
+//   * the kernel is integer-issue bound (measured: SQ_ACTIVE_INST_VALU and SQ_ACTIVE_INST_SCA each ~80 % of all SIMD cycles,
 //     both 4 cycles per wave64 instruction), so the instruction stream is kept lean: lane predicates live as
 //     64-bit masks in SGPRs (one v_cmp each, combined on the scalar unit), the window bound j >= lo is a
-//     scalar-built lane mask, a chunk with no lane passing the filters (chain.c:202-206) skips scoring.
+//     scalar-built lane mask, a chunk with no lane passing the filters (chain.c:202-206) skips scoring, an older
+//     chunk with no score above the running best skips the scan.
 //   * the max_skip rule is order dependent.  Per chunk it is evaluated with a DPP prefix max (which lanes
 //     raise the running best) and, only when a skip event interleaves with a new best, a max-plus scan of
 //     the skip counter (n -> max(n-1,0) on a new best, n -> n+1 on a "predecessor already on a visited
