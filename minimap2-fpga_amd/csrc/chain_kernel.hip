@@ -222,21 +222,25 @@ __device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t va
 // Every visited, unfiltered j stamps its predecessor p[j] (stamps for targets outside the window are never read for
 // this i and are dropped); then each lane fetches its own stamp.  LDS stamps are 16 bit, s16 = 1 + i % 16384 (0 = never
 // stamped, chain.c:46), in a ring of 2R slots that is cleared as anchors enter it, so a value identifies its anchor.
-// Lanes that do not stamp write to the sink slot [2R].  The stamp ring holds the 2R anchors before the end of the current
+// Lanes that do not stamp write to the slot of anchor i itself (see below).  The stamp ring holds the 2R anchors before the end of the current
 // tile (stamp_lo = i0 + 64 - 2R), twice the data ring; a stamp for an older target (the full i+1) goes to the global scratch t[].
 template <int R, bool FAR>
 __device__ __forceinline__ int stamp_and_fetch(mask_t valid, int pj, int lo, int stamp_lo, int stamp, int s16_v, char *t_bytes,
                                                int32_t *t_glob, int lane, int own_off2)
 {
 	const mask_t mk = valid & BALLOT(pj >= lo);
-	int tgt = sel(mk, 2 * R * 2, (pj & (2 * R - 1)) << 1);
+	// lanes that do not stamp write into the slot of anchor i itself (stamp = i + 1): it is not read during i's own scan, and what lands
+	// there (s16 of i) can never equal the s16 of a later anchor within the ring's reach -- so the ring needs no extra sink slot and the
+	// kernel's LDS is exactly 5 KB at R = 256 (32 waves per CU instead of 29)
+	const int sink = ((stamp - 1) & (2 * R - 1)) << 1;
+	int tgt = sel(mk, sink, (pj & (2 * R - 1)) << 1);
 	if (FAR) {
 		const mask_t fm = mk & BALLOT(pj < stamp_lo);
 		if (fm != 0) {
 			int pj2 = pj;
 			asm volatile("" : "+v"(pj2));                             // keep the far addressing out of the hot loop
 			if (fm >> lane & 1) __hip_atomic_store(&t_glob[pj2], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			tgt = sel(fm, tgt, 2 * R * 2);
+			tgt = sel(fm, tgt, sink);
 		}
 	}
 	*(uint16_t *)(t_bytes + tgt) = (uint16_t)s16_v;
@@ -554,7 +558,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	static_assert(R >= 128 && (R & (R - 1)) == 0, "ring must be a power of two >= 128");
 	__shared__ uint2 s_xq[R];        // x low word, query position
 	__shared__ int2 s_fp[R];         // f, p
-	__shared__ uint16_t s_t[2 * R + 2]; // 16-bit stamps (chain.c t[]), ring of 2R anchors; [2R] is the write sink of non-marking lanes
+	__shared__ uint16_t s_t[2 * R];     // 16-bit stamps (chain.c t[]), ring of 2R anchors
 	__shared__ uint8_t s_g[GEN ? R : 64];
 
 	const int lane = threadIdx.x;
@@ -569,7 +573,7 @@ chain_dp_wave(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int32_t *st = st_all + base;
 	int32_t *f = f_all + base, *p = p_all + base, *t = FAR ? t_all + base : nullptr;
 
-	for (int s = lane; s < 2 * R + 2; s += 64) s_t[s] = 0;
+	for (int s = lane; s < 2 * R; s += 64) s_t[s] = 0;
 	const int pbase = pbase_in ? pbase_in[task] : 0;
 	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative)
 
