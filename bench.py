@@ -216,6 +216,7 @@ def main():
         min_cnt, min_sc = (3, 100) if args.preset == "ava-ont" else (3, 40)     # options.c:24-25,85
         u_off, u, b_off, b = plan.chains(anchors, d_f, d_p, min_cnt, min_sc)   # warm-up (allocates the scratch)
         torch.cuda.synchronize()
+        del u_off, u, b_off, b                                                  # so that the timed call reuses these blocks instead of allocating
         tw = time.perf_counter()
         plan.run(anchors, d_f, d_p)
         u_off, u, b_off, b = plan.chains(anchors, d_f, d_p, min_cnt, min_sc)
