@@ -48,6 +48,9 @@ def load():
         lib.mm2o_mm_chain_dp.restype = C.c_int32
         lib.mm2o_mm_chain_dp.argtypes = [C.POINTER(OParams), C.c_int32, C.c_int32, C.c_int64, vp, C.POINTER(vp), C.POINTER(vp),
                                          C.POINTER(C.c_int64)]
+        lib.mm2o_backtrack.restype = C.c_int32
+        lib.mm2o_backtrack.argtypes = [C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
+                                       C.POINTER(C.c_int64)]
         lib.mm2o_bench_batch.restype = C.c_double
         lib.mm2o_bench_batch.argtypes = [C.POINTER(OParams), C.c_int64, vp, vp, vp, vp, C.c_int]
         lib.mm2o_radix_sort_64.argtypes = [vp, C.c_int64]
@@ -116,6 +119,28 @@ def mm_chain_dp(par, min_cnt, min_sc, anchors):
     op = par if isinstance(par, OParams) else oparams(par)
     u = C.c_void_p(0); b = C.c_void_p(0); nb = C.c_int64(0)
     n_u = load().mm2o_mm_chain_dp(C.byref(op), min_cnt, min_sc, a.shape[0], _ptr(a), C.byref(u), C.byref(b), C.byref(nb))
+    if n_u == 0:
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    u_np = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), shape=(n_u,)).copy()
+    b_np = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nb.value, 2)).copy()
+    libc.free(u); libc.free(b)
+    return u_np, b_np
+
+
+def backtrack(min_cnt, min_sc, anchors, f, p):
+    """the part of mm_chain_dp after the DP (chain.c:106-111 v[] fill, then :348-422) on ANY f[] / p[]: returns u, b"""
+    a = as_anchor_array(anchors)
+    n = a.shape[0]
+    f = np.ascontiguousarray(f, dtype=np.int32); p = np.ascontiguousarray(p, dtype=np.int32)
+    assert f.size == n and p.size == n and (n == 0 or (p.max() < n and p.min() >= -1 and np.all(p < np.arange(n))))
+    if n == 0:
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    v = np.zeros(n, np.int32); t = np.zeros(n, np.int32)
+    lib = load()
+    lib.mm2o_fill_v(n, _ptr(f), _ptr(p), _ptr(v))
+    u = C.c_void_p(0); b = C.c_void_p(0); nb = C.c_int64(0)
+    n_u = lib.mm2o_backtrack(n, _ptr(a), min_cnt, min_sc, _ptr(f), _ptr(p), _ptr(v), _ptr(t), C.byref(u), C.byref(b), C.byref(nb))
     if n_u == 0:
         return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
     libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]

@@ -204,6 +204,29 @@ def test_golden_fixtures():
         assert np.array_equal(f, z["f"]) and np.array_equal(p, z["p"]), name
 
 
+def test_oracle_equals_the_references_own_device_kernel():
+    """tests/golden/ref_cl_kernel_fp.npz holds f[] / p[] PRODUCED BY THE REFERENCE: device/minimap2_opencl.cl compiled for the host by
+    the image's clang and called as run_chaining_on_hw calls it (tests/golden/make_ref_cl_fixtures.py, oracle/ref_host/Makefile).
+    Both restatements of the oracle must reproduce them element by element: the literal emulation of the kernel's control flow
+    (mm2o_chain_hw_literal) and the stock CPU loop chain.c:184-238 (mm2o_chain_fpv) run with the V2 scalars max_skip = inf,
+    max_iter = 1024 -- which pins the window, the filters chain.c:202-205, the score chain.c:207-220 incl. the f32
+    truncation and ilog2, strict-max / nearest-j tie rule and the p = -1 rule of the CPU loop to reference-produced values."""
+    z = np.load(os.path.join(GOLDEN, "ref_cl_kernel_fp.npz"))
+    n_cases, n_anch, n_deep = int(z["n_cases"]), 0, 0
+    assert n_cases >= 18
+    for k in range(n_cases):
+        a, (mdx, mdy, bw, q_span), avg = z[f"c{k}_anchors"], [int(v) for v in z[f"c{k}_scalars"]], float(z[f"c{k}_avg"])
+        ns, tot, _ = ob.predict(a, mdx)
+        assert np.array_equal(ns, z[f"c{k}_num_subparts"])
+        f_lit, p_lit = ob.chain_hw_literal(mdx, mdy, bw, q_span, avg, a)
+        assert np.array_equal(f_lit, z[f"c{k}_f"]) and np.array_equal(p_lit, z[f"c{k}_p"]), f"literal emulation, case {k} {z[f'c{k}_name']}"
+        par = P(max_dist_x=mdx, max_dist_y=mdy, bw=bw, max_skip=2**31 - 1, max_iter=1024)
+        f, p, _ = ob.chain_fpv(par, a, avg)
+        assert np.array_equal(f, z[f"c{k}_f"]) and np.array_equal(p, z[f"c{k}_p"]), f"chain.c loop with V2 scalars, case {k} {z[f'c{k}_name']}"
+        n_anch += a.shape[0]; n_deep += int((ns == 8).sum())
+    assert n_anch > 30000 and n_deep > 3000     # anchors whose window fills all 8 sub-parts (look-back of 1024)
+
+
 def test_host_epilogue_of_the_library_equals_the_oracle_mm_chain_dp():
     """mm2c_chain_epilogue_host (library, host threads, no GPU) on the oracle's f[] / p[] against the oracle's mm_chain_dp"""
     import sys, os

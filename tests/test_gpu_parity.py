@@ -468,7 +468,8 @@ def test_device_epilogue_equal_first_x_replays_the_reference_sort():
 @pytest.mark.parametrize("seed", range(6))
 def test_device_epilogue_on_arbitrary_forests(seed):
     """the epilogue kernels on f[] / p[] that no DP produced (random forests: long paths, bushy trees, deep in-chunk chains,
-    equal scores) against the host epilogue (which test_cpu_oracle pins to the oracle); device-resident plan API"""
+    equal scores) against the ORACLE's backtrack (mm2o_fill_v + mm2o_backtrack = chain.c:106-111,348-422) and, beside it, the library's host
+    epilogue; device-resident plan API"""
     import mm2chain
     from mm2chain import params
     rng = np.random.default_rng(1000 + seed)
@@ -502,7 +503,10 @@ def test_device_epilogue_on_arbitrary_forests(seed):
         for i in range(n):
             ff[i] = max(15, (ff[par[i]] if par[i] >= 0 else 0) + 15 + gain[i]) if seed % 3 != 2 else int(rng.integers(0, 60))
         f[o:o + n] = ff
-    ref = mm2chain.chain_epilogue_host(2, 30, off, a, f, p, n_threads=4)
+    ref = [ob.backtrack(2, 30, a[off[k]:off[k + 1]], f[off[k]:off[k + 1]], p[off[k]:off[k + 1]]) for k in range(len(sizes))]
+    host = mm2chain.chain_epilogue_host(2, 30, off, a, f, p, n_threads=4)
+    for k in range(len(sizes)):
+        assert np.array_equal(host[k][0], ref[k][0]) and np.array_equal(host[k][1], ref[k][1]), f"host epilogue, task {k}"
     plan = mm2chain.ChainPlan(P, off)
     d_a = torch.from_numpy(a.view(np.int64)).cuda(); d_f = torch.from_numpy(f).cuda(); d_p = torch.from_numpy(p).cuda()
     u_off, u, b_off, b = plan.chains(d_a, d_f, d_p, 2, 30)
@@ -518,6 +522,44 @@ def test_device_epilogue_on_arbitrary_forests(seed):
         assert np.array_equal(bk, ref[k][1]), f"task {k} (n={sizes[k]}): b differs"
         n_chains += uk.size
     assert n_chains > 10
+
+
+def test_hip_equals_the_references_own_device_kernel():
+    """f[] / p[] the REFERENCE'S OWN device kernel produced (device/minimap2_opencl.cl compiled for the host and called like
+    run_chaining_on_hw does; tests/golden/ref_cl_kernel_fp.npz, generator beside it) against the HIP path, element by element:
+    through the reference's C++ symbol run_chaining_on_hw (chain_hardware.h:68) and through a device-resident plan with the V2 scalars"""
+    import mm2chain
+    from mm2chain import params
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cl_kernel_fp.npz"))
+    tasks, fs, ps = [], [], []
+    for k in range(int(z["n_cases"])):
+        a, (mdx, mdy, bw, q_span), avg = z[f"c{k}_anchors"], [int(v) for v in z[f"c{k}_scalars"]], float(z[f"c{k}_avg"])
+        ns = z[f"c{k}_num_subparts"]
+        ret, f, p = mm2chain.run_chaining_on_hw(a.shape[0], mdx, mdy, bw, q_span, avg, a, ns, int(ns.sum()), tid=k)
+        assert ret == 0
+        assert_same(f, p, z[f"c{k}_f"], z[f"c{k}_p"], None, f"run_chaining_on_hw, case {k} {z[f'c{k}_name']}")
+        if (mdx, mdy, bw) == (5000, 5000, 500) and q_span == 15:
+            tasks.append(a); fs.append(z[f"c{k}_f"]); ps.append(z[f"c{k}_p"])
+    off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tasks])]).astype(np.int64)
+    f, p = gpu_batch(params.fpga_v2(5000, 5000, 500, 15), off, np.concatenate(tasks))
+    assert_same(f, p, np.concatenate(fs), np.concatenate(ps), off, "plan with V2 scalars")
+    # and the stock CPU semantics (V1) restricted to what V2 can express: same vectors
+    f, p = gpu_batch(params.make_params(max_skip=INT32_MAX, max_iter=1024), off, np.concatenate(tasks))
+    assert_same(f, p, np.concatenate(fs), np.concatenate(ps), off, "plan with V1 kernel, max_skip = inf, max_iter = 1024")
+
+
+def test_hip_on_every_committed_golden_vector():
+    """the HIP path over every tests/golden/*.npz regression vector (made by make_golden.py; the CPU suite checks the oracle on them)"""
+    from mm2chain import params
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    files = sorted(x for x in os.listdir(g) if x.endswith(".npz") and not x.startswith("ref_"))
+    assert len(files) >= 6
+    for name in files:
+        z = np.load(os.path.join(g, name))
+        P = params.make_params(**{k: (float(z["par_" + k]) if k == "gap_scale" else int(z["par_" + k])) for k in
+                                  ("max_dist_x", "max_dist_y", "bw", "max_skip", "max_iter", "gap_scale", "is_cdna", "n_segs")})
+        f, p = gpu_batch(P, z["offsets"], z["anchors"])
+        assert_same(f, p, z["f"], z["p"], z["offsets"], name)
 
 
 def test_real_anchor_lists_from_the_reference_test_data():
