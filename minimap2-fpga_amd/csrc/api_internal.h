@@ -31,7 +31,7 @@ struct Global {
 	std::mutex mu;
 	bool ready = false;
 	int device = -1;
-	int ring_class = 0;
+	int ring_class = 3;
 	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
 	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
 	int64_t pipeline_chunk_anchors = 20 << 20;  // host paths: batches of at least twice this size are pipelined in chunks of this size

@@ -1,0 +1,820 @@
+// chain_dp_tile.h -- the chaining DP kernel of the library (second generation), included by chain_kernel.hip.
+//
+// Same contract as before: f[i] / p[i] of chain.c:184-238 for every anchor of every task, bit for bit, incl. the max_skip early exit
+// (chain.c:226-233); with max_skip = INT_MAX, max_iter = 1024, one q_span it is what device/minimap2_opencl.cl:24-172 computes.
+//
+// What the measurements of round 2 say about gfx950 (tools/ubench/issue_rate.hip, profiles/r2_issue_rate.md): per SIMD and ns a wave64
+// stream gets ~0.84 plain VALU instructions, but only ~0.55 of anything that touches the scalar side -- SALU ops (ONE scalar unit per CU),
+// v_cmp into an SGPR pair, v_readlane / v_writelane, v_cndmask with an SGPR mask, DPP ops -- 0.29 ds_read_b64 and 0.10 ds_bpermute.  The
+// first kernel spent 117 VALU + 113 SALU instructions per anchor and was bound by the SCALAR unit (its time is 0.62 ms per SALU
+// instruction per anchor on the headline batch, whatever else changes).  Hence this layout:
+//   * one 64-lane wave = one workgroup = one task, as before (the recurrence is sequential in i).
+//   * the look-back window of anchor i is scanned nearest-first in TILE-ALIGNED chunks: tile T = anchors [64T, 64T+64), lane L holds
+//     anchor 64T + 63 - L, so ascending lane = descending j = the reference's scan order inside every chunk, and the chunks of one
+//     anchor are: the part of its own tile before it (from registers: x, q, and f / p that v_writelane puts into the anchor's lane),
+//     then tiles T-1, T-2, ... from an LDS ring that is written once per 64 anchors: x / q of NX tiles (all the filters need), f / p of
+//     the NF nearest; deeper f / p and anything beyond NX tiles come from L2 (the task's own earlier stores), for nonempty chunks only.
+//     No per-lane ring arithmetic, no window shifting, no cross-lane data movement per anchor.
+//   * the filters chain.c:202-205 of a chunk cost 6 plain VALU + one v_cmp: dr-1, dq-1, |dr-dq| (v_sad_u32), two saturating
+//     subtractions against max_dq-1 and bw, v_or, compare with zero; dr == 0 (equal x, chain.c:202) never reaches the vector unit:
+//     equal x are neighbours in the sorted array, so the lanes to drop are a run that one ballot per TILE locates.
+//   * chain.c's t[] stamps: 16-bit stamp ring in LDS covering every anchor the ring reaches, exec-masked ds_write_b16 by p, ds_read_u16 by j.
+//   * the whole scan of an anchor -- chunk loop, f / p fetch, stamps, score, the order-dependent fold (strict running max, max_skip
+//     counter as a max-plus prefix scan) -- is ONE hand-written instruction sequence (scan_anchor_asm below) for the variant that
+//     matters (max_skip on, one segment, gap_scale 1, window inside the ring): the compiler's code for wave-uniform control flow
+//     (64-bit boolean masks, s_mov phi chains) needs 2.5x the scalar instructions.  Everything else (segments / cDNA, gap_scale != 1,
+//     windows beyond the ring, equal-x runs longer than a tile) goes through the C++ restatement of the same scan (scan_anchor).
+#ifndef MM2C_CHAIN_DP_TILE_H
+#define MM2C_CHAIN_DP_TILE_H
+#include "chain_wave.h"
+
+namespace mm2c {
+
+// a - b, saturating at 0 (unsigned); both operands in VGPRs so that the instruction issues at the full VALU rate
+__device__ __forceinline__ int usat_sub(int a, int b)
+{
+	int r;
+	asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ int min3i(int a, int b, int c)
+{
+	int r;
+	asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ int add3i(int a, int b, int c)
+{
+	int r;
+	asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+// 16-bit LDS store for the lanes of mask m only (exec is all ones everywhere in this kernel: control flow is wave-uniform)
+__device__ __forceinline__ void lds_store_b16_masked(mask_t m, int byte_addr, int value)
+{
+	asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, -1" : : "s"(m), "v"(byte_addr), "v"(value) : "memory");
+}
+// put two wave-uniform values into lane `l` (wave-uniform) of two registers; the lane select goes through M0 because a VALU
+// instruction of gfx9 reads at most one SGPR
+__device__ __forceinline__ void write_lane2(int &v0, int &v1, int a0, int a1, int l)
+{
+	asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+	    : "+v"(v0), "+v"(v1) : "s"(l), "s"(a0), "s"(a1));   // M0 is scratch for the compiler too: it loads it right before each of its own uses
+}
+
+// ---------------------------------------------------------------- LDS layout of one wave (byte offsets into the kernel's only LDS object)
+// rings are structure-of-arrays indexed by the anchor itself: anchor j of the task lives at dword (j mod 64 NX) of the x / q rings (NX tiles, a
+// power of two, the tile in progress included: 64 (NX - 1) anchors before it are reachable), at dword (j mod 64 NF) of the f / p rings
+// (the NF tiles before the one in progress: its own f / p are in registers until it is finished) and at halfword (j mod SN) of the stamp ring
+template <int NX, int NF, bool GEN, bool TAB>
+struct Lds {
+	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q rings
+	static constexpr int X = 0, Q = NX * 256, F = 2 * NX * 256, Pp = F + NF * 256, ST = Pp + NF * 256, GAP = ST + 2 * SN,
+	                     G = GAP + (TAB ? 1024 : 0), BYTES = G + (GEN ? NX * 64 : 0);
+	static constexpr int RB = NX * 256;          // bytes of one x / q ring array
+	static constexpr int FMASK = NF * 256 - 1;   // slot of a tile in the f / p rings = its x / q slot mod NF (NF a power of two dividing NX)
+};
+
+// what the chunks of one anchor share (wave-uniform unless noted)
+struct AnchorCtx {
+	int xi1, qi1;            // x_i - 1, q_i - 1 (so that dr - 1 and dq - 1 come out of one subtraction each)
+	int span_i, seg_i;
+	int lo;                  // start of the window (chain.c:192-193)
+	int stamp, s16;          // i + 1 (global scratch t[]), 1 + i % 16384 (LDS stamp ring)
+	int stamp_lo;            // oldest anchor whose stamp slot is in the LDS ring
+	int far_mode;            // the window reaches beyond the LDS ring (FAR variants)
+	float avg;
+	// per-lane values
+	int mdq1_v, bw_v, span1_v, s16_v, rl;   // max_dq - 1, bw, span_i - 1, s16, 63 - lane
+};
+
+struct TileMem {
+	char *lds;               // the wave's LDS (layout: Lds<>)
+	const uint4 *a; const int32_t *f, *p; int32_t *t;   // global arrays of the task
+	int pbase;
+};
+
+// ---------------------------------------------------------------- the filters chain.c:202-205 of one chunk as a lane mask
+template <bool GEN, bool FULL, bool DR0>
+__device__ __forceinline__ mask_t chunk_filter(const KParams &P, const AnchorCtx &X, mask_t in_w, int dr1, int dq1, int dd, int gj, mask_t &same)
+{
+	mask_t valid;
+	if (!GEN) {
+		// same segment, genomic: dr != 0 (the caller's masks), 0 < dq <= min(max_dist_y, max_dist_x), dd <= bw
+		const int viol = usat_sub(dq1, X.mdq1_v) | usat_sub(dd, X.bw_v);
+		valid = BALLOT(viol == 0);
+		if (!FULL) valid &= in_w;
+		if (DR0) valid &= BALLOT(dr1 != -1);            // an equal-x run that reaches beyond the own tile (rare)
+	} else {
+		same = BALLOT(gj == X.seg_i);
+		valid = pair_filter<true>(P, FULL ? ~0ull : in_w, dr1 + 1, dq1 + 1, dd, same);
+	}
+	return valid;
+}
+
+// ---------------------------------------------------------------- what follows the filters for a chunk with at least one surviving lane
+// stamps (chain.c:229,233), score (chain.c:207-220), then the order-dependent fold.  base = first anchor of the tile the chunk belongs to.
+// FAR: stamp targets may lie beyond the LDS stamp ring (X.far_mode, wave-uniform).
+template <class LY, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+__device__ __forceinline__ bool chunk_finish(const KParams &P, const AnchorCtx &X, const TileMem &M, mask_t valid, mask_t same,
+                                             int dr1, int dq1, int dd, int fj, int pj, int base, int lane, Carry &c)
+{
+	constexpr int SN = LY::SN;
+	mask_t marked = 0;
+	if (SKIP) {
+		// every visited, unfiltered j stamps its predecessor; stamps whose target lies before the window are never read for this i and are
+		// dropped (their slots may belong to other anchors by now)
+		mask_t mk = valid & BALLOT(pj >= X.lo);
+		if (FAR && X.far_mode) {
+			const mask_t fm = mk & BALLOT(pj < X.stamp_lo);
+			if (fm != 0) {
+				int pj2 = pj;
+				asm volatile("" : "+v"(pj2));                 // keep the far addressing out of the hot path
+				if (fm >> lane & 1) __hip_atomic_store(&M.t[pj2], X.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				mk &= ~fm;
+			}
+		}
+		lds_store_b16_masked(mk, LY::ST + ((pj & (SN - 1)) << 1), X.s16_v);
+		const int tj = *(const uint16_t *)(M.lds + LY::ST + ((X.rl + (base & (SN - 1))) << 1));   // same wave, LDS is in order: the stores above (asm volatile, "memory") have landed
+		marked = valid & BALLOT(tj == X.s16);
+	}
+	int sc;
+	if (!GEN && TAB) {
+		const int g = *(const int16_t *)(M.lds + LY::GAP + (min((unsigned)dd, 511u) << 1));   // 1 - gap cost (lanes that failed the filters hold any dd)
+		sc = add3i(min3i(dq1, dr1, X.span1_v), fj, g);          // min(dq, dr, span) - cost + f[j], chain.c:207-208,219-220
+	} else sc = pair_score<GEN, GS1>(P, X.avg, dr1 + 1, dq1 + 1, dd, same, X.span_i) + fj;
+	const int scv = sel(valid, SENT, sc);
+	return fold_lean<SKIP>(P, base + 63, marked, scv, c);
+}
+
+// f / p of the tile `depth` tiles before the own one (first anchor `base`, x / q ring address `addr`): from the LDS rings of the NF nearest
+// tiles, else from L2 / HBM (the task's own earlier stores; relative to the caller's task there, piece-relative here)
+template <class LY, int NF>
+__device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, int base, int rl, int &fj, int &pj)
+{
+	if (depth <= NF) {
+		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 4
+		fj = *(const int *)(M.lds + LY::F + o);
+		pj = max(*(const int *)(M.lds + LY::Pp + o) - M.pbase, -1);   // the ring holds p as memory does: relative to the caller's task
+	} else {
+		const int j = max(base + rl, 0);                          // lanes before the window of a partly covered tile may point before the task
+		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		pj = __hip_atomic_load(&M.p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		pj = max(pj - M.pbase, -1);
+	}
+}
+
+// ---------------------------------------------------------------- one chunk beyond the LDS ring: anchors, f, p and stamps from L2 / HBM
+template <class LY, bool SKIP, bool GEN, bool GS1, bool TAB, bool DR0>
+__device__ __forceinline__ bool far_chunk(const KParams &P, const AnchorCtx &X, const TileMem &M, mask_t in_w, int base, int lane, Carry &c)
+{
+	const int j = base + X.rl;
+	int xj = 0, qj = 0, gj = 0;
+	if (in_w >> lane & 1) {
+		const uint4 aj = M.a[j];
+		xj = (int)aj.x; qj = (int)aj.z;
+		if (GEN) gj = (aj.w >> 16) & 0xff;
+	}
+	const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
+	const int dd = absdiff(dr1, dq1);
+	mask_t same = ~0ull;
+	const mask_t valid = chunk_filter<GEN, false, DR0>(P, X, in_w, dr1, dq1, dd, gj, same);
+	if (valid == 0) return false;
+	int fj = 0, pj = -1;
+	const bool vl = valid >> lane & 1;
+	if (vl) {
+		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		pj = __hip_atomic_load(&M.p[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (pj >= 0) pj -= M.pbase;               // p[] in memory is relative to the caller's task, the scan works piece-relative
+	}
+	mask_t marked = 0;
+	if (SKIP) {
+		if (vl && pj >= X.lo) __hip_atomic_store(&M.t[pj], X.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // pj < j < stamp_lo: always the global scratch
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // far stamps of this and earlier chunks have landed
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		int tj = 0;
+		if (vl) tj = __hip_atomic_load(&M.t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		marked = valid & BALLOT(tj == X.stamp);
+	}
+	int sc;
+	if (!GEN && TAB) {
+		const int g = *(const int16_t *)(M.lds + LY::GAP + (min((unsigned)dd, 511u) << 1));
+		sc = add3i(min3i(dq1, dr1, X.span1_v), fj, g);
+	} else sc = pair_score<GEN, GS1>(P, X.avg, dr1 + 1, dq1 + 1, dd, same, X.span_i) + fj;
+	const int scv = sel(valid, SENT, sc);
+	return fold_lean<SKIP>(P, base + 63, marked, scv, c);
+}
+
+// ---------------------------------------------------------------- the look-back scan of one anchor, chain.c:197-235 (C++ path: every variant)
+// k = position of the anchor inside its tile (first anchor i0); own_* = the tile itself in registers (lane L = anchor i0 + 63 - L; f / p of its
+// finished anchors); addr0 = per-lane byte offset of this lane's anchor of the tile before in the x / q rings.  DR0: test dr != 0 per lane.
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool DR0>
+__device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X, const TileMem &M, int lane, int i0, int k, mask_t eq_run,
+                                            int own_x, int own_q, int own_g, int own_f, int own_p, int addr0, Carry &c)
+{
+	typedef Lds<NX, NF, GEN, TAB> LY;
+	// ---- the own tile: anchors i-1 .. i0 sit in lanes 64-k .. 63
+	if (k > 0) {
+		mask_t m = ~0ull << (64 - k);
+		const int nin = i0 + 64 - X.lo;                       // lanes below nin hold j >= lo
+		if (nin < 64) m &= first_lanes(nin);
+		if (!DR0) m &= ~eq_run;
+		const int dr1 = X.xi1 - own_x, dq1 = X.qi1 - own_q;
+		const int dd = absdiff(dr1, dq1);
+		mask_t same = ~0ull;
+		const mask_t valid = chunk_filter<GEN, false, DR0>(P, X, m, dr1, dq1, dd, own_g, same);
+		if (valid != 0 && chunk_finish<LY, SKIP, GEN, GS1, FAR, TAB>(P, X, M, valid, same, dr1, dq1, dd, own_f, own_p, i0, lane, c)) return;
+	}
+	const int before = i0 - X.lo;                             // anchors of older tiles inside the window
+	if (before <= 0) return;
+	const int n_full = before >> 6, part = before & 63;      // whole tiles, and the lanes of the last one that are inside
+	int base = i0 - 64, depth = 1;
+	int addr = addr0;                                         // this lane's anchor of the tile the scan has reached, in the x / q rings
+	// ---- whole tiles from the LDS ring
+#pragma nounroll
+	for (int cfull = FAR ? min(n_full, NX - 1) : n_full; cfull > 0; --cfull) {
+		const int xj = *(const int *)(M.lds + LY::X + addr), qj = *(const int *)(M.lds + LY::Q + addr);
+		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
+		const int dd = absdiff(dr1, dq1);
+		mask_t same = ~0ull;
+		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 2)) : 0;
+		const mask_t valid = chunk_filter<GEN, true, DR0>(P, X, ~0ull, dr1, dq1, dd, gj, same);
+		if (valid != 0) {
+			int fj, pj;
+			ring_fp<LY, NF>(M, addr, depth, base, X.rl, fj, pj);
+			if (chunk_finish<LY, SKIP, GEN, GS1, FAR, TAB>(P, X, M, valid, same, dr1, dq1, dd, fj, pj, base, lane, c)) return;
+		}
+		addr = (addr - 256) & (LY::RB - 1);                   // one tile back
+		base -= 64; ++depth;
+	}
+	if (!FAR || n_full < NX - 1) {
+		// ---- the last, partly covered tile, from the ring
+		if (part == 0) return;
+		const int xj = *(const int *)(M.lds + LY::X + addr), qj = *(const int *)(M.lds + LY::Q + addr);
+		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
+		const int dd = absdiff(dr1, dq1);
+		mask_t same = ~0ull;
+		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 2)) : 0;
+		const mask_t valid = chunk_filter<GEN, false, DR0>(P, X, first_lanes(part), dr1, dq1, dd, gj, same);
+		if (valid != 0) {
+			int fj, pj;
+			ring_fp<LY, NF>(M, addr, depth, base, X.rl, fj, pj);
+			chunk_finish<LY, SKIP, GEN, GS1, FAR, TAB>(P, X, M, valid, same, dr1, dq1, dd, fj, pj, base, lane, c);
+		}
+		return;
+	}
+	// ---- beyond the ring (FAR): whole tiles, then the partly covered one
+#pragma nounroll
+	for (int cfar = n_full - (NX - 1); cfar >= 0; --cfar, base -= 64) {
+		const mask_t m = cfar > 0 ? ~0ull : (part ? first_lanes(part) : 0);
+		if (m != 0 && far_chunk<LY, SKIP, GEN, GS1, TAB, DR0>(P, X, M, m, base, lane, c)) return;
+	}
+}
+
+// ---------------------------------------------------------------- the same scan, hand-written, for the variant that carries the throughput
+// max_skip on, one segment, gap_scale 1 (chain.c:218 without :219's double path), window inside the LDS ring, no equal-x run beyond the
+// own tile.  One instruction sequence per anchor; registers: see the operand list.  Chunk loop: tile `d` tiles back (d = 0: the own tile)
+// is filtered with 7 VALU + 1 v_cmp + 1 s_and; only a chunk with a surviving lane enters Lne (f / p fetch, stamps, score, fold).
+// The fold has three paths (as fold_lean): A no lane beats the running best, B1 some does and neither marks nor skips exist,
+// B2 the general case (prefix max by DPP, skip counter as a max-plus scan n <- max(n + d, 0) over the lanes).
+// Wait states of gfx940 that the assembler does not insert for inline asm: VALU write -> DPP read of the same VGPR: 2 (s_nop 1);
+// VALU write -> v_readlane of it: s_nop 0 kept for safety; LDS results: s_waitcnt lgkmcnt(0); global results: s_waitcnt vmcnt(0).
+// ---------------------------------------------------------------- the same scan, hand-written, for the variant that carries the throughput
+// max_skip on, one segment, max_dq - 1 >= bw; gap cost computed (gap_scale 1) or read from the per-task table.  One instruction sequence
+// per TILE: anchors k_start .. of the tile with first anchor i0, one after the other; lane L = 63 - k holds anchor i0 + k in the per-tile
+// registers: tx / tq = x, q; tx1 / tq1 = x - 1, q - 1; tspan = span; tlo = window start, tbef = anchors of older tiles inside the window
+// (both clamped to what the ring holds); ts16 = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
+// all, bit 30: window clamped, bit 31: anchor not handled here.  Results go into the anchor's lane of own_f / own_p.  Returns the position
+// of the first anchor it did not process (cnt when the tile is done, else a bit-31 anchor).  A clamped window that the ring part of the scan
+// does not end (no `break` of chain.c:231) goes on tile by tile from L2 / HBM: x, q from the anchor array, f / p from the task's own
+// earlier stores, stamps in the 32-bit global scratch t[] (value i + 1) -- also for the far predecessors of ring lanes.
+// Per anchor: the own tile (lanes L+1 .. L+w), then `nfull` whole older tiles in a count-down loop that branches on VCC (7 VALU + 2 LDS
+// + 1 SALU + 2 branches per tile; x / q of the next tile are requested while this one is filtered), then the partly covered tile.
+// A chunk with a surviving lane goes through Lhf: f / p of its tile (registers, LDS, or L2 beyond NF tiles), stamps, score, fold.
+// The fold: A no lane beats the running best; B1 some does and neither marks nor skips exist (one candidate: no reduction at all);
+// B2 general: prefix max by DPP -> lanes that raise the best (nm), skip events (se); closed form when every nm precedes every se,
+// else the max-plus scan n <- max(n + d, 0) over the lanes.
+// Wait states the assembler does not insert for inline asm (gfx940): VALU write -> DPP read of that VGPR: 2 (s_nop 1); VALU write ->
+// v_readlane of it: s_nop 0 kept for safety; LDS results: s_waitcnt lgkmcnt(0); global results: s_waitcnt vmcnt(0).
+#define MM2C_DPP_STEP(R, CTRL) "s_nop 1\n\t" "v_max_i32_dpp " R ", " R ", " R " " CTRL "\n\t"
+#define MM2C_DPP_PREFIX_MAX(R) MM2C_DPP_STEP(R, "row_shr:1 row_mask:0xf bank_mask:0xf") MM2C_DPP_STEP(R, "row_shr:2 row_mask:0xf bank_mask:0xf") \
+	MM2C_DPP_STEP(R, "row_shr:4 row_mask:0xf bank_mask:0xf") MM2C_DPP_STEP(R, "row_shr:8 row_mask:0xf bank_mask:0xf") \
+	MM2C_DPP_STEP(R, "row_bcast:15 row_mask:0xa bank_mask:0xf") MM2C_DPP_STEP(R, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define MM2C_FILTER(X, Q) "v_sub_u32 %[dr], %[xi1], " X "\n\t" "v_sub_u32 %[dq], %[qi1], " Q "\n\t"
+#define MM2C_FILTER2 "v_sad_u32 %[dd], %[dr], %[dq], 0\n\t" "v_sub_u32_e64 %[u1], %[dq], %[mdqbw] clamp\n\t" "v_max_u32 %[u1], %[u1], %[dd]\n\t" \
+	"v_cmp_ge_u32 vcc, %[bw], %[u1]\n\t"
+#define MM2C_NEXT_XQ "ds_read_b32 %[nx], %[addr] offset:%[XOFF]\n\t" "ds_read_b32 %[nq], %[addr] offset:%[QOFF]\n\t" \
+	"v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
+// x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
+#define MM2C_FAR_REQ "v_add_u32 %[u2], %[fb], %[rl]\n\t" "v_max_i32 %[u2], 0, %[u2]\n\t" "v_lshlrev_b32 %[u2], 4, %[u2]\n\t" \
+	"global_load_dword %[nx], %[u2], %[aptr]\n\t" "global_load_dword %[nq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
+#define MM2C_SCORE_CMP "v_or_b32 %[va], 1, %[dd]\n\t" "v_ffbh_u32 %[va], %[va]\n\t" "v_lshrrev_b32 %[va], 1, %[va]\n\t" "v_cvt_f32_u32 %[vc], %[dd]\n\t" \
+	"v_mul_f32 %[vc], %[avg], %[vc]\n\t" "v_cvt_i32_f32 %[vc], %[vc]\n\t" "v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t" "v_sub_u32 %[sc], %[sc], %[vc]\n\t" \
+	"v_add3_u32 %[sc], %[sc], %[va], -14\n\t"
+#define MM2C_ADDF_CMP "v_add_u32 %[sc], %[sc], %[vf]\n\t"
+#define MM2C_SCORE_TAB "v_min_u32 %[va], 0x1ff, %[dd]\n\t" "v_lshlrev_b32 %[va], 1, %[va]\n\t" "ds_read_i16 %[va], %[va] offset:%[GAPOFF]\n\t" \
+	"v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t"
+#define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t"
+
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF) \
+template <int NX, int NF> \
+__device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
+                                    int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tbef, int tw, int ts16, int &own_f, int &own_p, \
+                                    int addr1, int ownst, int own2s, int rl4, int rl, int mdqbw_v, int bw_v, int sent_v) \
+{ \
+	typedef Lds<NX, NF, false, TABV> LY; \
+	typedef Lds<NX, NF, false, true> LYT; \
+	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
+	mask_t mask, valid, mk, marked, nm, se; \
+	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v; \
+	asm volatile( \
+		"s_sub_i32 %[L], 63, %[kstart]\n" \
+		"Lk_%=:\n\t" \
+		"v_readlane_b32 %[pk], %[tw], %[L]\n\t" \
+		"v_readlane_b32 %[best], %[tspan], %[L]\n\t" \
+		"s_mov_b32 %[bestj], -1\n\t" \
+		"s_cmp_lt_i32 %[pk], 0\n\t" \
+		"s_cbranch_scc1 Lexit_%=\n\t" \
+		"s_bitcmp1_b32 %[pk], 29\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n\t" \
+		"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
+		"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
+		"v_readlane_b32 %[nfull], %[tbef], %[L]\n\t" \
+		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
+		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
+		"v_readlane_b32 %[s16], %[ts16], %[L]\n\t" \
+		"v_mov_b32 %[addr], %[addr1]\n\t" \
+		MM2C_NEXT_XQ \
+		"s_add_i32 %[span1], %[best], -1\n\t" \
+		"s_mov_b32 %[nskip], 0\n\t" \
+		"s_and_b32 %[part], %[nfull], 63\n\t" \
+		"s_lshr_b32 %[nfull], %[nfull], 6\n\t" \
+		"s_mov_b32 %[n], %[nfull]\n\t" \
+		"v_mov_b32 %[s16v], %[s16]\n\t" \
+		"s_and_b32 %[t0], %[pk], 63\n\t" \
+		"s_cbranch_scc0 Lloop_%=\n\t" \
+		"s_add_i32 %[t1], %[L], 1\n\t" \
+		"s_bfm_b64 %[mask], %[t0], %[t1]\n\t" \
+		MM2C_FILTER("%[tx]", "%[tq]") MM2C_FILTER2 \
+		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
+		"s_cbranch_scc0 Lloop_%=\n\t" \
+		"s_mov_b32 %[base], %[i0]\n\t" \
+		"v_mov_b32 %[vf], %[own_f]\n\t" \
+		"v_mov_b32 %[vp], %[own_p]\n\t" \
+		"v_mov_b32 %[vb], %[ownst]\n\t" \
+		SCORE \
+		"s_branch Lhf_%=\n" \
+		"Lloop_%=:\n\t" \
+		"s_sub_u32 %[n], %[n], 1\n\t" \
+		"s_cbranch_scc1 Lpart_%=\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		MM2C_FILTER("%[nx]", "%[nq]") MM2C_NEXT_XQ MM2C_FILTER2 \
+		"s_cbranch_vccz Lloop_%=\n\t" \
+		"s_mov_b64 %[valid], vcc\n\t" \
+		"s_sub_i32 %[d], %[nfull], %[n]\n" \
+		"Lold_%=:\n\t" \
+		"s_lshl_b32 %[t0], %[d], 6\n\t" \
+		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+		"s_and_b32 %[t0], %[base], %[RMASK]\n\t" \
+		"v_lshl_add_u32 %[vb], %[t0], 1, %[own2s]\n\t" \
+		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
+		"s_cbranch_scc1 Lfg_%=\n\t" \
+		"v_lshl_add_u32 %[u2], %[t0], 2, %[rl4]\n\t" \
+		"v_and_b32 %[u2], %[FMASK], %[u2]\n\t" \
+		"ds_read_b32 %[vp], %[u2] offset:%[POFF]\n\t" \
+		"ds_read_b32 %[vf], %[u2] offset:%[FOFF]\n\t" \
+		SCORE \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		"s_branch Lfx_%=\n" \
+		"Lfg_%=:\n\t" \
+		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+		"v_max_i32 %[u2], 0, %[u2]\n\t" \
+		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
+		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+		SCORE \
+		"s_waitcnt vmcnt(0)\n" \
+		"Lfx_%=:\n\t" \
+		"s_cmp_eq_u32 %[pbase], 0\n\t" \
+		"s_cbranch_scc1 Lhf_%=\n\t" \
+		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
+		"v_max_i32 %[vp], -1, %[vp]\n" \
+		"Lhf_%=:\n\t" \
+		"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+		"s_and_b64 %[mk], vcc, %[valid]\n\t" \
+		"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
+		"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
+		"s_mov_b64 exec, %[mk]\n\t" \
+		"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
+		"s_mov_b64 exec, -1\n\t" \
+		"ds_read_u16 %[vb], %[vb]\n\t" \
+		"s_bitcmp1_b32 %[pk], 30\n\t" \
+		"s_cbranch_scc0 Lmk_%=\n\t" \
+		"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
+		"s_and_b64 %[mask], vcc, %[valid]\n\t" \
+		"s_andn2_b64 %[mask], %[mask], %[mk]\n\t" \
+		"s_cbranch_scc0 Lmk_%=\n\t" \
+		"s_sub_i32 %[t0], %[i0], %[L]\n\t" \
+		"s_add_i32 %[t0], %[t0], 64\n\t" \
+		"v_mov_b32 %[u1], %[t0]\n\t" \
+		"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
+		"s_mov_b64 exec, %[mask]\n\t" \
+		"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
+		"s_mov_b64 exec, -1\n" \
+		"Lmk_%=:\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		ADDF \
+		"v_cndmask_b32_e64 %[sc], %[sent], %[sc], %[valid]\n\t" \
+		"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
+		"s_and_b64 %[marked], vcc, %[valid]\n\t" \
+		"v_cmp_lt_i32 vcc, %[best], %[sc]\n\t" \
+		"s_cbranch_vccnz Limp_%=\n\t" \
+		"s_cbranch_scc0 Lret_%=\n\t" \
+		"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
+		"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
+		"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n" \
+		"Lret_%=:\n\t" \
+		"s_bitcmp1_b32 %[pk], 28\n\t" \
+		"s_cbranch_scc0 Lloop_%=\n\t" \
+		"s_branch Lfloop_%=\n" \
+		"Lpart_%=:\n\t" \
+		"s_mov_b32 %[n], 0\n\t" \
+		"s_cmp_eq_u32 %[part], 0\n\t" \
+		"s_cbranch_scc1 Lend_%=\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+		"s_sub_i32 %[t0], 64, %[part]\n\t" \
+		"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
+		"s_mov_b32 %[part], 0\n\t" \
+		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
+		"s_cbranch_scc0 Lend_%=\n\t" \
+		"s_add_i32 %[d], %[nfull], 1\n\t" \
+		"s_branch Lold_%=\n" \
+		"Limp_%=:\n\t" \
+		"s_cmp_lg_u64 %[marked], 0\n\t" \
+		"s_cbranch_scc1 Lb2_%=\n\t" \
+		"s_cmp_lg_u32 %[nskip], 0\n\t" \
+		"s_cbranch_scc1 Lb2_%=\n\t" \
+		"s_bcnt1_i32_b64 %[t0], vcc\n\t" \
+		"s_cmp_eq_u32 %[t0], 1\n\t" \
+		"s_cbranch_scc0 Lb1m_%=\n\t" \
+		"s_ff1_i32_b64 %[t0], vcc\n\t" \
+		"v_readlane_b32 %[best], %[sc], %[t0]\n\t" \
+		"s_add_i32 %[t1], %[base], 63\n\t" \
+		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
+		"s_branch Lret_%=\n" \
+		"Lb1m_%=:\n\t" \
+		"v_mov_b32 %[va], %[sc]\n\t" \
+		MM2C_DPP_PREFIX_MAX("%[va]") \
+		"s_nop 0\n\t" \
+		"v_readlane_b32 %[best], %[va], 63\n\t" \
+		"s_nop 0\n\t" \
+		"v_cmp_eq_u32 vcc, %[best], %[sc]\n\t" \
+		"s_ff1_i32_b64 %[t0], vcc\n\t" \
+		"s_add_i32 %[t1], %[base], 63\n\t" \
+		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
+		"s_branch Lret_%=\n" \
+		"Lb2_%=:\n\t" \
+		"v_mov_b32 %[va], %[sc]\n\t" \
+		MM2C_DPP_PREFIX_MAX("%[va]") \
+		"v_bfrev_b32 %[vb], 1\n\t" \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[vb], %[va] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_max_i32 %[vb], %[best], %[vb]\n\t" \
+		"v_cmp_gt_i32_e64 %[nm], %[sc], %[vb]\n\t" \
+		"s_andn2_b64 %[se], %[marked], %[nm]\n\t" \
+		"s_cbranch_scc1 Lli_%=\n\t" \
+		"s_bcnt1_i32_b64 %[t0], %[nm]\n\t" \
+		"s_sub_i32 %[nskip], %[nskip], %[t0]\n\t" \
+		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
+		"s_mov_b32 %[last], 63\n\t" \
+		"s_branch Ltk_%=\n" \
+		"Lli_%=:\n\t" \
+		"s_flbit_i32_b64 %[t0], %[nm]\n\t" \
+		"s_sub_i32 %[t0], 63, %[t0]\n\t" \
+		"s_ff1_i32_b64 %[t1], %[se]\n\t" \
+		"s_cmp_lt_i32 %[t0], %[t1]\n\t" \
+		"s_cbranch_scc0 Lgen_%=\n\t" \
+		"s_bcnt1_i32_b64 %[t0], %[nm]\n\t" \
+		"s_sub_i32 %[nskip], %[nskip], %[t0]\n\t" \
+		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
+		"s_bcnt1_i32_b64 %[t0], %[se]\n\t" \
+		"s_add_i32 %[t1], %[nskip], %[t0]\n\t" \
+		"s_cmp_le_i32 %[t1], %[maxskip]\n\t" \
+		"s_cbranch_scc0 Lcfb_%=\n\t" \
+		"s_mov_b32 %[nskip], %[t1]\n\t" \
+		"s_mov_b32 %[last], 63\n\t" \
+		"s_branch Ltk_%=\n" \
+		"Lcfb_%=:\n\t" \
+		"s_sub_i32 %[t0], %[maxskip], %[nskip]\n\t" \
+		"s_max_i32 %[t0], %[t0], 0\n\t" \
+		"s_mov_b64 vcc, %[se]\n\t" \
+		"v_mbcnt_lo_u32_b32 %[vc], vcc_lo, 0\n\t" \
+		"v_mbcnt_hi_u32_b32 %[vc], vcc_hi, %[vc]\n\t" \
+		"v_cmp_eq_u32 vcc, %[t0], %[vc]\n\t" \
+		"s_and_b64 %[nm], vcc, %[se]\n\t" \
+		"s_ff1_i32_b64 %[last], %[nm]\n\t" \
+		"s_sub_i32 %[last], %[last], 1\n\t" \
+		"s_branch Ltk_%=\n" \
+		"Lgen_%=:\n\t" \
+		"s_mov_b64 vcc, %[se]\n\t" \
+		"v_mbcnt_lo_u32_b32 %[vc], vcc_lo, 0\n\t" \
+		"v_mbcnt_hi_u32_b32 %[vc], vcc_hi, %[vc]\n\t" \
+		"s_mov_b64 vcc, %[nm]\n\t" \
+		"v_mbcnt_lo_u32_b32 %[u1], vcc_lo, 0\n\t" \
+		"v_mbcnt_hi_u32_b32 %[u1], vcc_hi, %[u1]\n\t" \
+		"v_sub_u32 %[vc], %[vc], %[u1]\n\t" \
+		"v_cndmask_b32_e64 %[u1], 0, 1, %[se]\n\t" \
+		"v_add_u32 %[vc], %[vc], %[u1]\n\t" \
+		"v_cndmask_b32_e64 %[u1], 0, 1, %[nm]\n\t" \
+		"v_sub_u32 %[vc], %[vc], %[u1]\n\t" \
+		"v_sub_u32 %[vb], 0, %[vc]\n\t" \
+		MM2C_DPP_PREFIX_MAX("%[vb]") \
+		"v_max_i32 %[vb], %[nskip], %[vb]\n\t" \
+		"v_add_u32 %[vb], %[vc], %[vb]\n\t" \
+		"v_cmp_lt_i32 vcc, %[maxskip], %[vb]\n\t" \
+		"s_and_b64 %[nm], vcc, %[se]\n\t" \
+		"s_cbranch_scc1 Lbk_%=\n\t" \
+		"s_nop 0\n\t" \
+		"v_readlane_b32 %[nskip], %[vb], 63\n\t" \
+		"s_mov_b32 %[last], 63\n\t" \
+		"s_branch Ltk_%=\n" \
+		"Lbk_%=:\n\t" \
+		"s_ff1_i32_b64 %[last], %[nm]\n\t" \
+		"s_sub_i32 %[last], %[last], 1\n" \
+		"Ltk_%=:\n\t" \
+		"s_cmp_lt_i32 %[last], 0\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n\t" \
+		"v_readlane_b32 %[t0], %[va], %[last]\n\t" \
+		"s_cmp_le_i32 %[t0], %[best]\n\t" \
+		"s_cbranch_scc1 Laf_%=\n\t" \
+		"s_mov_b32 %[best], %[t0]\n\t" \
+		"v_cmp_eq_u32 vcc, %[t0], %[sc]\n\t" \
+		"s_ff1_i32_b64 %[t1], vcc\n\t" \
+		"s_add_i32 %[t0], %[base], 63\n\t" \
+		"s_sub_i32 %[bestj], %[t0], %[t1]\n" \
+		"Laf_%=:\n\t" \
+		"s_cmp_eq_u32 %[last], 63\n\t" \
+		"s_cbranch_scc1 Lret_%=\n\t" \
+		"s_branch Ldone_%=\n" \
+		"Lend_%=:\n\t" \
+		"s_bitcmp1_b32 %[pk], 30\n\t" \
+		"s_cbranch_scc0 Ldone_%=\n\t" \
+		"s_bitset1_b32 %[pk], 28\n\t" \
+		"s_sub_i32 %[t0], %[i0], %[lo0]\n\t" \
+		"s_and_b32 %[part], %[t0], 63\n\t" \
+		"s_lshr_b32 %[nfull], %[t0], 6\n\t" \
+		"s_sub_i32 %[n], %[nfull], %[NXM1]\n\t" \
+		"s_mov_b32 %[d], %[NXM1]\n\t" \
+		"s_mov_b32 %[lo], %[lo0]\n\t" \
+		"s_sub_i32 %[s16], %[i0], %[L]\n\t" \
+		"s_add_i32 %[s16], %[s16], 64\n\t" \
+		"v_mov_b32 %[s16v], %[s16]\n\t" \
+		"s_sub_i32 %[fb], %[i0], %[REACH]\n" \
+		"Lfloop_%=:\n\t" \
+		"s_add_u32 %[d], %[d], 1\n\t" \
+		"s_sub_u32 %[n], %[n], 1\n\t" \
+		"s_cbranch_scc1 Lfpart_%=\n\t" \
+		MM2C_FAR_REQ \
+		"s_waitcnt vmcnt(0)\n\t" \
+		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+		"s_cbranch_vccz Lfloop_%=\n\t" \
+		"s_mov_b64 %[valid], vcc\n\t" \
+		"s_branch Lfold_%=\n" \
+		"Lfpart_%=:\n\t" \
+		"s_mov_b32 %[n], 0\n\t" \
+		"s_cmp_eq_u32 %[part], 0\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n\t" \
+		MM2C_FAR_REQ \
+		"s_waitcnt vmcnt(0)\n\t" \
+		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+		"s_sub_i32 %[t0], 64, %[part]\n\t" \
+		"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
+		"s_mov_b32 %[part], 0\n\t" \
+		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
+		"s_cbranch_scc0 Ldone_%=\n" \
+		"Lfold_%=:\n\t" \
+		"s_lshl_b32 %[t0], %[d], 6\n\t" \
+		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+		"v_max_i32 %[u2], 0, %[u2]\n\t" \
+		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
+		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+		SCORE \
+		"s_waitcnt vmcnt(0)\n\t" \
+		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
+		"v_max_i32 %[vp], -1, %[vp]\n\t" \
+		"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+		"s_and_b64 %[mk], vcc, %[valid]\n\t" \
+		"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
+		"s_mov_b64 exec, %[mk]\n\t" \
+		"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
+		"s_mov_b64 exec, -1\n\t" \
+		"s_waitcnt vmcnt(0)\n\t" \
+		"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
+		"s_waitcnt vmcnt(0)\n\t" \
+		"s_branch Lmk_%=\n" \
+		"Ldone_%=:\n\t" \
+		"s_mov_b32 m0, %[L]\n\t" \
+		"s_nop 0\n\t" \
+		"v_writelane_b32 %[own_f], %[best], m0\n\t" \
+		"v_writelane_b32 %[own_p], %[bestj], m0\n\t" \
+		"s_sub_i32 %[L], %[L], 1\n\t" \
+		"s_cmp_ge_i32 %[L], %[Lend]\n\t" \
+		"s_cbranch_scc1 Lk_%=\n" \
+		"Lexit_%=:\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
+		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [L] "=&s"(L), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
+		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
+		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), \
+		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
+		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), \
+		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
+		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
+		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tbef] "v"(tbef), [tw] "v"(tw), [ts16] "v"(ts16), \
+		  [addr1] "v"(addr1), [ownst] "v"(ownst), [own2s] "v"(own2s), [rl4] "v"(rl4), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
+		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
+		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		: "memory", "vcc", "scc"); \
+	return 63 - L; \
+}
+
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB)
+
+// ---------------------------------------------------------------- the kernel: one wave per task
+// LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+__global__ void __launch_bounds__(64)
+chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+              const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
+              const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
+{
+	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
+	typedef Lds<NX, NF, GEN, TAB> LY;
+	constexpr int SN = LY::SN;
+	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...
+	const bool ASM = ASMV && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // ... when its three-instruction filter applies (max_dq - 1 >= bw: every preset)
+	__shared__ __attribute__((aligned(16))) char lds[LY::BYTES];   // the kernel's only LDS object: the assembly addresses it from 0
+
+	const int lane = threadIdx.x;
+	const int64_t task = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int64_t)blockIdx.x;
+	if (task >= n_tasks) return;
+	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut): the grid is sized for the worst case
+	if (only_flagged && status[task] == 0) return;
+	const int64_t base0 = offsets[task];
+	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base0));
+	if (n <= 0) return;
+	const uint4 *a = a_all + base0;        // {x lo, x hi, y lo (= query pos), y hi (span | flags | seg)}
+	const int32_t *st = st_all + base0;
+	int32_t *f = f_all + base0, *p = p_all + base0, *t = FAR ? t_all + base0 : nullptr;
+	if (ASMV && (uint32_t)(uintptr_t)(void *)lds != 0) { if (lane == 0) status[task] = 3; return; }   // cannot happen: one LDS object per kernel
+
+	uint16_t *const s_t = (uint16_t *)(lds + LY::ST);
+	for (int s = lane; s < SN; s += 64) s_t[s] = 0;
+	const int pbase = pbase_in ? pbase_in[task] : 0;
+	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative)
+
+	// avg_qspan_scaled, chain.c:48-49: from the prepass (or the caller); computed here only when neither supplied it
+	float avg = avg_in ? avg_in[task] : -1.0f;
+	if (avg < 0.f) {
+		uint64_t sum = 0;
+		for (int k = lane; k < n; k += 64) sum += (a[k].w & 0xffu);
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
+	}
+	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
+	if (TAB) {
+		// gap cost of chain.c:209,218-219 for every dd the filter lets through (dd <= bw <= 511), stored as 1 - cost
+		int16_t *const s_gap = (int16_t *)(lds + LY::GAP);
+		for (int dd = lane; dd <= P.bw && dd < 512; dd += 64) {
+			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
+			int g = (int)((float)dd * avg) + (lg >> 1);
+			if (P.gap_scale != 1.0f) g = (int)__dadd_rn(__dmul_rn((double)g, (double)P.gap_scale), .499);   // chain.c:219
+			s_gap[dd] = (int16_t)(1 - g);
+		}
+	}
+
+	const int rl = 63 - lane;
+	AnchorCtx X;
+	X.avg = avg; X.rl = rl; X.seg_i = 0; X.far_mode = 0;
+	X.mdq1_v = P.max_dq - 1; X.bw_v = P.bw;
+	int own2s = LY::ST + 2 * rl, rl4 = rl << 2, sent_v = SENT, mdqbw_v = P.max_dq - 1 - P.bw;   // stamp slot / ring dword of this lane's anchor of a tile at 0 mod SN                // stamp slot of this lane's anchor of a tile whose base is 0 mod SN; the score of a dead lane
+	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(own2s), "+v"(rl4), "+v"(sent_v), "+v"(mdqbw_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
+	TileMem M;
+	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
+
+	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;   // the own tile: lane L = anchor i0 + 63 - L
+	int seg0 = 0;
+	bool t_ready = false;                                     // t[0 .. i0) has been zeroed (wave-uniform)
+	const bool no_pairs = !GEN && P.max_dq <= 0;              // chain.c:203 lets nothing through
+
+	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
+	int cur_st = (rl < n) ? st[rl] - st_sub : 0;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int idx = i0 + rl;
+		const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - i0));
+		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
+		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64] - st_sub; }   // prefetch the next tile
+		// x of anchor i0 - 1 (lane 0 of the tile before) for the equal-x test, before own_x is replaced
+		int prev_last = rdlane(own_x, 0);
+		own_x = (int)cur.x; own_q = (int)cur.z;
+		own_g = (cur.w >> 16) & 0xff;                                         // MM_SEED_SEG_MASK mmpriv.h:22-23
+		if (!GEN && !(P.flags & KF_IGNORE_SEG)) {
+			// the simple variant assumes one segment id per task; anything else is redone by the general one
+			if (i0 == 0) seg0 = rdlane(own_g, 63);
+			if (BALLOT(rl < cnt && own_g != seg0)) { if (lane == 0) status[task] = 1; return; }
+		}
+		s_t[idx & (SN - 1)] = 0;             // stamp slots of the entering anchors (recycled from idx - SN)
+		const int stamp_lo = i0 - 64 * (NX - 1);   // oldest anchor reachable without global memory while this tile is processed
+		{
+			const int o = (idx & (SN - 1)) << 2;   // the tile enters the x / q rings (its slot held the tile NX tiles back)
+			*(int *)(lds + LY::X + o) = own_x;
+			*(int *)(lds + LY::Q + o) = own_q;
+			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 2)) = (uint8_t)own_g;
+		}
+		if (FAR) {
+			// global stamp scratch t[]: zeroed lazily, only once this task's windows can reach beyond the LDS ring
+			const int reach = rdlane(cur_st, 63);                 // window start of the first anchor of the tile (st[] is monotone)
+			if (!t_ready && reach < stamp_lo) {
+				for (int z = lane; z < i0; z += 64) t[z] = 0;
+				t_ready = true;
+			}
+			if (t_ready && idx < n) t[idx] = 0;
+		}
+		const int span_l = P.span_override >= 0 ? P.span_override : (int)(cur.w & 0xff);   // chain.c:189
+		// anchors with the x of their predecessor (chain.c:202 `dr == 0`): bit L set <=> the anchor of lane L has the x of the anchor of lane L+1
+		mask_t eq_prev = 0;
+		if (!GEN) {
+			asm volatile("" : "+v"(prev_last));
+			const int px = __builtin_amdgcn_update_dpp(prev_last, own_x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+			eq_prev = BALLOT(px == own_x);
+			if (i0 == 0) eq_prev &= ~(1ull << 63);
+		}
+		X.stamp_lo = stamp_lo;
+		const int addr0 = ((idx - 64) & (SN - 1)) << 2;       // per lane: byte offset of its anchor of the tile before in the x / q rings
+
+		// per-anchor scalars of the tile, kept per lane (the hand-written loop fetches them with v_readlane): window start, LDS stamp, number
+		// of own-tile predecessors inside the window; bit 31 of the latter marks the anchors that take the C++ path (x equal to the
+		// predecessor's).  An anchor whose window reaches beyond the ring is scanned as far as the ring goes; only if that scan runs out without
+		// the `break` of chain.c:231 does the hand-written loop hand the anchor back to the C++ path
+		const int lo_l = no_pairs ? idx : min(cur_st, idx);
+		int tw_l = min(rl, idx - lo_l);
+		if (lo_l >= idx) tw_l |= 1 << 29;
+		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
+		if (eq_prev >> lane & 1) tw_l |= (int)0x80000000;
+		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);
+		const int s16_l = 1 + (idx & 0x3fff), ownst = LY::ST + ((idx & (SN - 1)) << 1);
+		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
+
+		for (int k = 0; k < cnt; ++k) {
+			if (ASM) {
+				if (TAB) k = scan_tile_asm_tab<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c,
+				                                       lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v);
+				else k = scan_tile_asm_cmp<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c,
+				                                   lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v);
+				k = __builtin_amdgcn_readfirstlane(k);
+				if (k >= cnt) break;
+			}
+			const int L = 63 - k;
+			const int i = i0 + k;
+			const int xi = rdlane(own_x, L), qi = rdlane(own_q, L);
+			const int span_i = rdlane(span_l, L);
+			const int lo = rdlane(lo_l, L);                                                      // chain.c:192-193
+			Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
+			if (i - lo > 0) {
+				mask_t eq_run = 0; bool dr0 = false;
+				if (!GEN && eq_prev != 0) {
+					const mask_t r = eq_prev >> L;                    // bit 0: i has the x of i-1, bit 1: i-1 has the x of i-2, ... (k+1 bits)
+					const int e = (int)__builtin_ctzll(~r);            // length of the run of equal x that ends at i
+					if (e > k) dr0 = true;                              // it reaches beyond the tile: per-lane test in every chunk
+					else if (e > 0) eq_run = ((1ull << e) - 1) << (L + 1);
+				}
+				X.xi1 = xi - 1; X.qi1 = qi - 1; X.span_i = span_i; X.span1_v = span_i - 1;
+				if (GEN) X.seg_i = rdlane(own_g, L);                                                 // chain.c:191
+				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + (i & 0x3fff); X.s16_v = X.s16;
+				X.far_mode = FAR && lo < stamp_lo;
+				if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
+				else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);
+			}
+			// ---- commit anchor i (chain.c:236) into its lane of the own tile
+			write_lane2(own_f, own_p, __builtin_amdgcn_readfirstlane(c.best), __builtin_amdgcn_readfirstlane(c.best_j), L);
+		}
+		// ---- the finished tile: results leave in coalesced stores ...
+		if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
+		{
+			const int o = (idx << 2) & LY::FMASK;    // ... and enters the f / p rings
+			*(int *)(lds + LY::F + o) = own_f;
+			*(int *)(lds + LY::Pp + o) = own_p < 0 ? own_p : own_p + pbase;
+		}
+		cur = nxt; cur_st = nxt_st;
+	}
+}
+
+} // namespace mm2c
+#endif

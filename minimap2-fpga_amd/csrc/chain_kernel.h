@@ -37,13 +37,14 @@ struct LaunchArgs {
 	const int64_t *d_offsets;   // n_tasks+1, CSR
 	const int32_t *d_order;     // launch order (longest task first) or nullptr
 	const void *d_anchors;      // 16 B per anchor
-	const float *d_avg;         // per task or nullptr (computed in kernel, chain.c:48-49)
+	const float *d_avg;         // per task or nullptr (computed on the device, chain.c:48-49)
+	float *d_avg_ws = nullptr;  // n_tasks floats of workspace: when d_avg is nullptr the prepass computes avg_qspan_scaled into it
 	const int32_t *d_pbase;     // per task or nullptr: added to every p >= 0 on output (tasks that are pieces of a caller's task)
 	int32_t *d_f, *d_p;
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
-	int ring_class;             // 0: 256, 1: 512, 2: 1024 anchors of LDS ring per task
+	int ring_class;             // 3: tile kernel (4 register tiles + 3 LDS tiles); 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
 	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
 };
 

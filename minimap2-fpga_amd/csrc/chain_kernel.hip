@@ -45,178 +45,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <stdlib.h>
 #include "chain_kernel.h"
+#include "chain_wave.h"
+#ifndef MM2C_NX
+#define MM2C_NX 8        // tiles of x / q in the LDS ring of the tile kernel: 384 anchors before the own tile pass the filters without global memory
+#define MM2C_NF 2        // tiles of f / p beside them (deeper ones are fetched from L2 for the lanes that passed)
+#endif
+#include "chain_dp_tile.h"
 
 namespace mm2c {
-
-typedef unsigned long long mask_t;       // one bit per lane, lives in an SGPR pair
-#define SENT INT_MIN                     // score of a lane that is not a candidate
-
-// ---------------------------------------------------------------- wave64 primitives (DPP, gfx9 encodings)
-// dpp_ctrl: row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-__device__ __forceinline__ int wave_shr1(int lane0_value, int v)
-{
-	return __builtin_amdgcn_update_dpp(lane0_value, v, 0x138, 0xf, 0xf, false);
-}
-
-// shift the chunk-0 window one lane up and put a wave-uniform value into lane 0 (2 VALU)
-__device__ __forceinline__ int window_push(int w, int lane0_value)
-{
-	w = __builtin_amdgcn_update_dpp(w, w, 0x138, 0xf, 0xf, false);
-	asm("v_writelane_b32 %0, %1, 0" : "+v"(w) : "s"(lane0_value));
-	return w;
-}
-// inclusive prefix max over ascending lanes (6 v_max_i32_dpp)
-__device__ __forceinline__ int prefix_max_incl(int v)
-{
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x111, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x112, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x114, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x118, 0xf, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x142, 0xa, 0xf, false));
-	v = max(v, __builtin_amdgcn_update_dpp(SENT, v, 0x143, 0xc, 0xf, false));
-	return v;
-}
-
-#define BALLOT(c) ((mask_t)__builtin_amdgcn_ballot_w64(c))
-__device__ __forceinline__ int lanes_below(mask_t m)   // number of set bits of m in lanes below this one
-{
-	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-}
-__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// per-lane select by a scalar lane mask: bit set -> b, clear -> a
-__device__ __forceinline__ int sel(mask_t m, int a, int b)
-{
-	int r;
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
-	return r;
-}
-// |a - b| for unsigned operands (one VALU)
-__device__ __forceinline__ int absdiff(int a, int b)
-{
-	int r;
-	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
-	return r;
-}
-// lanes 0..n-1 (the lanes whose predecessor index is still >= the window start)
-__device__ __forceinline__ mask_t first_lanes(int n)   // n >= 1
-{
-	int sh = 64 - n;
-	sh = sh < 0 ? 0 : sh;
-	return ~0ull >> sh;
-}
-
-struct Carry { int best, best_j, n_skip; };
-
-// ---------------------------------------------------------------- filters of chain.c:202-206 as a lane mask
-// dr = x_i - x_j (low words; exact inside the window), dq = q_i - q_j.  `ok` = lanes inside the window.
-// For a lane inside the window 0 <= dr <= max_dist_x.
-template <bool GEN>
-__device__ __forceinline__ mask_t pair_filter(const KParams &P, mask_t ok, int dr, int dq, int dd, mask_t same)
-{
-	if (!GEN) {
-		// same segment, genomic: dr != 0, 0 < dq <= min(max_dist_y, max_dist_x), dd <= bw
-		ok &= BALLOT(dr != 0);
-		ok &= BALLOT((unsigned)(dq - 1) < (unsigned)P.max_dq);
-		ok &= BALLOT(dd <= P.bw);
-		return ok;
-	}
-	const mask_t dr0 = BALLOT(dr == 0);
-	ok &= ~(same & dr0) & BALLOT(dq > 0);                                       // chain.c:202
-	ok &= ~(same & BALLOT(dq > P.max_dist_y)) & BALLOT(dq <= P.max_dist_x);     // chain.c:203
-	ok &= ~(same & BALLOT(dd > P.bw));                                          // chain.c:205
-	if (P.n_segs > 1 && !P.is_cdna) ok &= ~(same & BALLOT(dr > P.max_dist_y));  // chain.c:206
-	return ok;
-}
-
-// ---------------------------------------------------------------- score of a pair, chain.c:207-219, WITHOUT f[j]
-template <bool GEN, bool GS1>
-__device__ __forceinline__ int pair_score(const KParams &P, float avg, int dr, int dq, int dd, mask_t same, int span_i)
-{
-	int s = min(min(dq, dr), span_i);                                 // chain.c:207-208
-	const int c = __builtin_clz((unsigned)dd | 1u);                   // chain.c:209: log_dd = dd ? ilog2_32(dd) : 0 = 31 - c
-	const int lin = (int)((float)dd * avg);                           // f32 multiply, truncate
-	int gap;
-	if (GEN) {
-		const int lg = 31 - c;
-		const int g_same = lin + (lg >> 1);                           // chain.c:216,218
-		if (P.is_cdna) {                                              // chain.c:211-217 with is_cdna
-			const int g_cdna = dr > dq ? min(lin, lg) : g_same;
-			const int g_diff = dr == 0 ? 0 : min(lin, lg);
-			gap = sel(same, g_diff, g_cdna);
-		} else {
-			const int g_diff = dr == 0 ? 0 : min(lin, lg);            // sidi != sidj
-			gap = sel(same, g_diff, g_same);
-		}
-		s += sel(same, dr == 0 ? 1 : 0, 0);                           // chain.c:214 `++sc`
-	} else gap = lin + 15 - (c >> 1);                                 // (31 - c) >> 1 == 15 - (c >> 1) for c in 0..31
-	if (GS1) s -= gap;                                                // (int)((double)g*1.0+.499) == g for g >= 0
-	else s -= (int)__dadd_rn(__dmul_rn((double)gap, (double)P.gap_scale), .499); // chain.c:219
-	return s;
-}
-
-// ---------------------------------------------------------------- the order-dependent part of one chunk
-// scv: score per lane (SENT where the lane is not a candidate), marked: lanes with t[j] == i.
-// Updates the carry exactly as chain.c:226-232 would after walking the lanes in ascending order.
-// Returns true when the reference loop executes `break` inside this chunk.
-// a chunk in which no lane raises the best (chain.c:226 never taken): every marked lane is a skip event (chain.c:229-231)
-template <bool SKIP>
-__device__ __forceinline__ bool skips_only(const KParams &P, mask_t se, Carry &c)
-{
-	if (SKIP && se != 0) {
-		const int64_t need = (int64_t)P.max_skip - c.n_skip;               // the event of this 0-based rank breaks
-		if (need < (int64_t)__builtin_popcountll(se)) return true;
-		c.n_skip += (int)__builtin_popcountll(se);
-	}
-	return false;
-}
-
-template <bool SKIP, bool PRETEST>
-__device__ __forceinline__ bool fold_chunk(const KParams &P, int jtop, mask_t valid, mask_t marked, int scv, Carry &c)
-{
-	// Most older chunks hold no score above the running best (the scan is nearest-first and chains grow from near predecessors): then
-	// no lane takes chain.c:226, every marked lane is a skip event, and the counter needs no scan at all.  (Not worth a test in
-	// chunk 0, which usually does raise the best.)
-	if (PRETEST && BALLOT(scv > c.best) == 0) return skips_only<SKIP>(P, marked & valid, c);
-	const int incl = prefix_max_incl(scv);
-	int last = 63;                                                    // last lane the reference visits in this chunk
-	bool broke = false;
-	if (SKIP) {
-		const mask_t cand = marked & valid;
-		if (cand != 0 || c.n_skip > 0) {
-			const int run = max(c.best, wave_shr1(SENT, incl));       // best before this lane, in scan order
-			const mask_t nm = BALLOT(scv > run);                      // chain.c:226 takes the branch
-			const mask_t se = cand & ~nm;                             // chain.c:229-230 `++n_skip`
-			if (se == 0) {
-				c.n_skip = max(c.n_skip - (int)__builtin_popcountll(nm), 0);
-			} else if (nm == 0 || (63 - (int)__builtin_clzll(nm)) < (int)__builtin_ctzll(se)) {
-				// every new best precedes every skip event: counter = max(n - #nm, 0) + rank of the event
-				const int n1 = max(c.n_skip - (int)__builtin_popcountll(nm), 0);
-				const int64_t need = (int64_t)P.max_skip - n1;         // the event of this 0-based rank breaks
-				if (need < (int64_t)__builtin_popcountll(se)) {
-					const int r = need < 0 ? 0 : (int)need;
-					const mask_t hit = se & BALLOT(lanes_below(se) == r);
-					last = (int)__builtin_ctzll(hit) - 1; broke = true;
-				} else c.n_skip = n1 + (int)__builtin_popcountll(se);
-			} else {
-				// general interleaving: Lindley recursion n <- max(n + d, 0), d = +1 (se) / -1 (nm)
-				const int S = lanes_below(se) - lanes_below(nm) + sel(se, 0, 1) - sel(nm, 0, 1);
-				const int nl = S + max(c.n_skip, prefix_max_incl(-S));
-				const mask_t brk = se & BALLOT(nl > P.max_skip);      // chain.c:230-231
-				if (brk != 0) { last = (int)__builtin_ctzll(brk) - 1; broke = true; }
-				else c.n_skip = rdlane(nl, 63);
-			}
-		}
-	}
-	if (last >= 0) {
-		const int mc = rdlane(incl, last);                            // best over the visited lanes of this chunk
-		if (mc > c.best) {                                            // strict: nearest j wins ties (chain.c:226)
-			c.best = mc;
-			c.best_j = jtop - (int)__builtin_ctzll(BALLOT(scv == mc));
-		}
-	}
-	return broke;
-}
 
 // ---------------------------------------------------------------- chain.c:233 + :229 for a chunk whose lanes are all ring-resident
 // Every visited, unfiltered j stamps its predecessor p[j] (stamps for targets outside the window are never read for
@@ -394,7 +232,8 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 // each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
 __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-                   const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */)
+                   const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
+                   float *__restrict__ avg_out /* per task, or nullptr */)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -410,8 +249,18 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	constexpr int STAGE = 2048;
 	__shared__ uint64_t s_x[STAGE];
 	__shared__ int s_prev;
-	if (lane == 0) s_prev = 0;
+	__shared__ unsigned long long s_sum;
+	if (lane == 0) { s_prev = 0; s_sum = 0; }
 	__syncthreads();
+	if (avg_out && n > 0) {
+		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
+		uint64_t sum = 0;
+		for (int k = lane; k < n; k += 256) sum += (a[k].y >> 32) & 0xff;
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+		if ((lane & 63) == 0) atomicAdd(&s_sum, (unsigned long long)sum);
+		__syncthreads();
+		if (lane == 0) avg_out[task] = (float)(__dmul_rn(.01, (double)(float)s_sum) / (double)n);
+	}
 	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
 		const int i = i0 + lane, cnt = min(256, n - i0);
 		const int range_lo = max(s_prev, max(i0 - P.max_iter, 0)), len = i0 + cnt - range_lo;
@@ -687,6 +536,37 @@ static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagg
 	return hipGetLastError();
 }
 
+// ---- second-generation kernel (chain_dp_tile.h): x / q rings of NX tiles, f / p rings of NF tiles
+template <bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged)
+{
+	constexpr int NX = MM2C_NX, NF = MM2C_NF;
+	if (L.cut.max_pieces > 0) {
+		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
+		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,
+		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count);
+		return hipGetLastError();
+	}
+	hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
+	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t,
+	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr);
+	return hipGetLastError();
+}
+
+template <bool SKIP, bool FAR>
+static hipError_t launch_tile_sf(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool gen, bool gs1, bool tab, int only_flagged)
+{
+	if (tab && !gen) return launch_tile_one<SKIP, false, true, FAR, true>(L, d_avg, st, only_flagged);   // the table absorbs gap_scale
+	if (gen) return gs1 ? launch_tile_one<SKIP, true, true, FAR, false>(L, d_avg, st, only_flagged) : launch_tile_one<SKIP, true, false, FAR, false>(L, d_avg, st, only_flagged);
+	return gs1 ? launch_tile_one<SKIP, false, true, FAR, false>(L, d_avg, st, only_flagged) : launch_tile_one<SKIP, false, false, FAR, false>(L, d_avg, st, only_flagged);
+}
+
+static hipError_t launch_tile(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool skip, bool gen, bool gs1, bool far_, bool tab, int only_flagged)
+{
+	if (skip) return far_ ? launch_tile_sf<true, true>(L, d_avg, st, gen, gs1, tab, only_flagged) : launch_tile_sf<true, false>(L, d_avg, st, gen, gs1, tab, only_flagged);
+	return far_ ? launch_tile_sf<false, true>(L, d_avg, st, gen, gs1, tab, only_flagged) : launch_tile_sf<false, false>(L, d_avg, st, gen, gs1, tab, only_flagged);
+}
+
 template <int R, bool GEN, bool FAR>
 static hipError_t launch_sg(const LaunchArgs &L, hipStream_t st, bool skip, bool gs1, int only_flagged)
 {
@@ -710,7 +590,7 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 	return hipGetLastError();
 }
 
-int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : 1024; }
+int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }
 
 hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin)
 {
@@ -721,28 +601,38 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const bool gs1 = P.gap_scale == 1.0f;
 	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
+	const bool tile = L.ring_class >= 3;                   // second-generation kernel: 448 anchors before the current tile without global memory
 	const bool far_ = (int64_t)P.max_iter > (int64_t)R;   // the ring always holds the R anchors before the current tile
+	// the gap-cost table of the tile kernel: dd <= bw <= 511 entries of int16 (cost <= 2.55 * 511 + 4, times gap_scale)
+	// used when gap_scale != 1 (it takes the f64 path of chain.c:219 out of the loop); with gap_scale 1 computing the cost is as fast and the
+	// kernel's LDS stays at 6 KB (measured: 62.8 vs 66.3 ms on the headline batch)
+	const bool tab = tile && !gs1 && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
+	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
+	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
+	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
-	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr);
+	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
 	if (e == hipSuccess && L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL(chain_cut, dim3((unsigned)L.n_tasks), dim3(64), 0, st, L.cut.seg_min, L.n_tasks, L.d_offsets, L.d_order,
-		                   (const uint4 *)L.d_anchors, L.d_avg, L.d_st, L.cut);
+		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut);
 		e = hipGetLastError();
 		if (n_launches) ++*n_launches;
 	}
 	if (e == hipSuccess && ev_dp_begin) e = hipEventRecord(ev_dp_begin, st);
+	LaunchArgs L1 = L; L1.d_avg = d_avg;
 	for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
 		// pass 0: the variant the parameters ask for; pass 1 (simple variant only, segments not ignored): redo the
 		// tasks that turned out to carry more than one segment id with the general variant.
 		const bool gen = want_gen || pass == 1;
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
+		if (tile) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {
-		case 256: e = launch_r<256>(L, st, skip, gen, gs1, far_, flagged); break;
-		case 512: e = launch_r<512>(L, st, skip, gen, gs1, far_, flagged); break;
-		default:  e = launch_r<1024>(L, st, skip, gen, gs1, far_, flagged); break;
+		case 256: e = launch_r<256>(L1, st, skip, gen, gs1, far_, flagged); break;
+		case 512: e = launch_r<512>(L1, st, skip, gen, gs1, far_, flagged); break;
+		default:  e = launch_r<1024>(L1, st, skip, gen, gs1, far_, flagged); break;
 		}
 		if (n_launches) ++*n_launches;
 	}

@@ -208,7 +208,7 @@ using namespace mm2c_api;
 struct mm2c_plan {
 	mm2c_params_t par;
 	int64_t n_tasks = 0, total = 0;
-	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr;
+	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
 	bool ran = false, epi_ran = false;
 	std::vector<int32_t> sizes_desc;        // task sizes, longest first (host copy: bounds the number of pieces of the device-side cut)
@@ -237,7 +237,7 @@ int mm2c_init(int device_ordinal)
 	HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
 	G.device = dev;
 	const char *rc = getenv("MM2C_RING_CLASS");
-	G.ring_class = rc ? std::max(0, std::min(2, atoi(rc))) : 0;
+	G.ring_class = rc ? std::max(0, std::min(3, atoi(rc))) : 3;
 	G.ready = true;
 	return 0;
 }
@@ -273,7 +273,7 @@ int mm2c_tune(const char *key, int value)
 {
 	if (!key) return fail(MM2C_E_ARG, "key is NULL");
 	if (strcmp(key, "ring_class") == 0) {
-		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "ring_class must be 0, 1 or 2");
+		if (value < 0 || value > 3) return fail(MM2C_E_ARG, "ring_class must be 0, 1, 2 or 3");
 		G.ring_class = value;
 		return 0;
 	}
@@ -342,6 +342,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_status, nt * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -364,7 +365,7 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 {
 	if (!pl) return;
 	if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // as hipFree would: the blocks go back to the cache and may be reused at once
-	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st);
+	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st); dev_free(pl->d_avg_ws);
 	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
@@ -386,6 +387,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.P = to_kparams(&pl->par);
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
+	L.d_avg_ws = pl->d_avg_ws;
 	L.ring_class = G.ring_class;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
