@@ -83,9 +83,12 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 void mm2c_plan_destroy(mm2c_plan_t *plan);
 int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
 
+/* stream arguments: a hipStream_t passed as void*.  NULL is the HIP null stream (what a default-stream caller such as PyTorch works on,
+ * so the call is ordered with the caller's own work); MM2C_STREAM_LIBRARY asks for the library's private non-blocking stream. */
+#define MM2C_STREAM_LIBRARY ((void *)(intptr_t)-1)
+
 /*
- * Enqueue the DP for every task of the plan on `stream` (a hipStream_t passed as void*, NULL = the library's
- * own stream).  All pointers are DEVICE pointers: d_anchors[total] (16 B each), d_f[total], d_p[total].
+ * Enqueue the DP for every task of the plan on `stream`.  All pointers are DEVICE pointers: d_anchors[total] (16 B each), d_f[total], d_p[total].
  * d_avg_qspan is either NULL (the kernel computes avg_qspan_scaled per task exactly as chain.c:48-49) or
  * n_tasks floats.  p[] is task-relative, -1 = no predecessor, exactly as chain.c:236.  Asynchronous.
  * A plan owns one workspace: do not run the same plan concurrently with itself (different plans and different streams are fine).

@@ -73,7 +73,14 @@ int mm2c_stream_read(const char *path, mm2c_stream_t *out)
 	if (fread(buf, 1, HDR_BYTES, fp) != HDR_BYTES) { fclose(fp); return MM2C_E_ARG; }
 	memcpy(&h, buf, sizeof(h));
 	if (memcmp(h.magic, MAGIC, 8) != 0 || h.version != 1 || h.header_bytes < HDR_BYTES || h.n_tasks < 0 || h.total < 0) { fclose(fp); return MM2C_E_ARG; }
-	if (h.header_bytes > HDR_BYTES) fseek(fp, (long)h.header_bytes, SEEK_SET);
+	{
+		/* the counts come from the file: they must fit the file (and size_t) before anything is allocated */
+		long file_bytes;
+		if (fseek(fp, 0, SEEK_END) != 0 || (file_bytes = ftell(fp)) < 0) { fclose(fp); return MM2C_E_ARG; }
+		if (h.header_bytes > file_bytes || h.n_tasks > ((int64_t)file_bytes - h.header_bytes) / 8 - 1 ||
+		    h.total > ((int64_t)file_bytes - h.header_bytes - (h.n_tasks + 1) * 8) / 16) { fclose(fp); return MM2C_E_ARG; }
+		if (fseek(fp, (long)h.header_bytes, SEEK_SET) != 0) { fclose(fp); return MM2C_E_ARG; }
+	}
 	out->n_tasks = h.n_tasks; out->total = h.total; out->min_cnt = h.min_cnt; out->min_sc = h.min_sc;
 	out->par.max_dist_x = h.max_dist_x; out->par.max_dist_y = h.max_dist_y; out->par.bw = h.bw; out->par.max_skip = h.max_skip;
 	out->par.max_iter = h.max_iter; out->par.gap_scale = h.gap_scale; out->par.is_cdna = h.is_cdna; out->par.n_segs = h.n_segs;
@@ -89,12 +96,20 @@ int mm2c_stream_read(const char *path, mm2c_stream_t *out)
 	return 0;
 }
 
+typedef struct { mm2c_anchor_t a; int64_t i; } sort_rec_t;
+static int cmp_sort_rec(const void *pa, const void *pb)
+{
+	const sort_rec_t *a = (const sort_rec_t *)pa, *b = (const sort_rec_t *)pb;
+	if (a->a.x != b->a.x) return a->a.x < b->a.x ? -1 : 1;
+	return a->i < b->i ? -1 : a->i > b->i;
+}
+
 int mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par, int min_cnt, int min_sc, mm2c_stream_t *out)
 {
 	FILE *fp;
 	char line[1024], name[512], strand;
 	char **names = 0;
-	int n_names = 0, m_names = 0, rpos, qpos, span, gap, started = 0;
+	int n_names = 0, m_names = 0, rpos, qpos, span, gap, started = 0, oom = 0;
 	int64_t m_a = 1 << 16, m_t = 1 << 10;
 	if (!text_path || !par || !out) return MM2C_E_ARG;
 	memset(out, 0, sizeof(*out));
@@ -102,11 +117,16 @@ int mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par, 
 	out->par = *par; out->min_cnt = min_cnt; out->min_sc = min_sc;
 	out->anchors = (mm2c_anchor_t *)malloc((size_t)m_a * 16);
 	out->offsets = (int64_t *)malloc((size_t)(m_t + 1) * 8);
+	if (!out->anchors || !out->offsets) { fclose(fp); mm2c_stream_free(out); return MM2C_E_ARG; }
 	out->offsets[0] = 0;
 	while (fgets(line, sizeof(line), fp)) {
 		if (line[0] == 'R' && line[1] == 'S' && line[2] == '\t') {              /* map.c:299: a new read starts */
 			if (started) {
-				if (out->n_tasks + 1 >= m_t) { m_t <<= 1; out->offsets = (int64_t *)realloc(out->offsets, (size_t)(m_t + 1) * 8); }
+				if (out->n_tasks + 1 >= m_t) {
+					void *q = realloc(out->offsets, (size_t)(2 * m_t + 1) * 8);
+					if (!q) { oom = 1; break; }
+					m_t <<= 1; out->offsets = (int64_t *)q;
+				}
 				out->offsets[++out->n_tasks] = out->total;
 			}
 			started = 1;
@@ -115,10 +135,19 @@ int mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par, 
 			if (sscanf(line + 3, "%511s\t%d\t%c\t%d\t%d\t%d", name, &rpos, &strand, &qpos, &span, &gap) != 6) continue;
 			for (rid = 0; rid < n_names; ++rid) if (strcmp(names[rid], name) == 0) break;
 			if (rid == n_names) {
-				if (n_names == m_names) { m_names = m_names ? m_names << 1 : 16; names = (char **)realloc(names, (size_t)m_names * sizeof(char *)); }
-				names[n_names++] = strdup(name);
+				if (n_names == m_names) {
+					void *q = realloc(names, (size_t)(m_names ? m_names << 1 : 16) * sizeof(char *));
+					if (!q) { oom = 1; break; }
+					m_names = m_names ? m_names << 1 : 16; names = (char **)q;
+				}
+				if ((names[n_names] = strdup(name)) == 0) { oom = 1; break; }
+				++n_names;
 			}
-			if (out->total == m_a) { m_a <<= 1; out->anchors = (mm2c_anchor_t *)realloc(out->anchors, (size_t)m_a * 16); }
+			if (out->total == m_a) {
+				void *q = realloc(out->anchors, (size_t)m_a * 32);
+				if (!q) { oom = 1; break; }
+				m_a <<= 1; out->anchors = (mm2c_anchor_t *)q;
+			}
 			out->anchors[out->total].x = (uint64_t)(strand == '-') << 63 | (uint64_t)rid << 32 | (uint32_t)rpos;   /* map.c:232-241 */
 			out->anchors[out->total].y = (uint64_t)(span & 0xff) << 32 | (uint32_t)qpos;
 			++out->total;
@@ -126,8 +155,31 @@ int mm2c_stream_from_seed_dump(const char *text_path, const mm2c_params_t *par, 
 		}
 	}
 	fclose(fp);
-	if (started) out->offsets[++out->n_tasks] = out->total;
+	if (started && !oom) out->offsets[++out->n_tasks] = out->total;
 	while (n_names) free(names[--n_names]);
 	free(names);
+	if (oom) { mm2c_stream_free(out); return MM2C_E_ARG; }
+	/* reference ids are numbered here by first appearance in the dump, not by the index's order: a read that hits several references
+	 * may come out with descending ids.  Every chaining entry needs x ascending inside a task (map.c:245), so each task is sorted by x
+	 * (stable: the dump's order among equal x is kept).  Segment ids and flag bits are not part of the SD lines and are 0 here. */
+	{
+		int64_t k;
+		for (k = 0; k < out->n_tasks; ++k) {
+			mm2c_anchor_t *a = out->anchors + out->offsets[k];
+			const int64_t n = out->offsets[k + 1] - out->offsets[k];
+			int64_t i, j;
+			int sorted = 1;
+			for (i = 1; i < n && sorted; ++i) sorted = a[i - 1].x <= a[i].x;
+			if (sorted) continue;
+			{
+				sort_rec_t *r = (sort_rec_t *)malloc((size_t)n * sizeof(sort_rec_t));
+				if (!r) { mm2c_stream_free(out); return MM2C_E_ARG; }
+				for (i = 0; i < n; ++i) { r[i].a = a[i]; r[i].i = i; }
+				qsort(r, (size_t)n, sizeof(sort_rec_t), cmp_sort_rec);
+				for (j = 0; j < n; ++j) a[j] = r[j].a;
+				free(r);
+			}
+		}
+	}
 	return 0;
 }

@@ -31,14 +31,15 @@ struct Global {
 	std::mutex mu;
 	bool ready = false;
 	int device = -1;
-	int ring_class = 3;
-	size_t combine_max_anchors = 1u << 17;   // host paths: calls up to this many anchors are combined with concurrent callers' calls
-	size_t stage_max_anchors = 1u << 21;     // host paths: calls up to this many anchors go through pinned staging buffers
-	int64_t pipeline_chunk_anchors = 20 << 20;  // host paths: batches of at least twice this size are pipelined in chunks of this size
-	int64_t cut_below_tasks = 4096;         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
-	int seg_min = 256;                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
-	int plan_cut = 1;                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
-	int plan_cut_min = 8192;                // ... tasks of at least this many anchors (the ones that make the tail of a batch)
+	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
+	std::atomic<int> ring_class{3};
+	std::atomic<size_t> combine_max_anchors{1u << 17};   // host paths: calls up to this many anchors are combined with concurrent callers' calls
+	std::atomic<size_t> stage_max_anchors{1u << 21};     // host paths: calls up to this many anchors go through pinned staging buffers
+	std::atomic<int64_t> pipeline_chunk_anchors{20 << 20};  // host paths: batches of at least twice this size are pipelined in chunks of this size
+	std::atomic<int64_t> cut_below_tasks{4096};         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
+	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
+	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
+	std::atomic<int> plan_cut_min{8192};                // ... tasks of at least this many anchors (the ones that make the tail of a batch)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
 	std::vector<ThreadCtx *> thread_ctxs;   // owned; released in mm2c_shutdown
 	std::atomic<uint64_t> tasks{0}, anchors{0}, launches{0}, segments{0}, host_call_ns{0}, passes{0};

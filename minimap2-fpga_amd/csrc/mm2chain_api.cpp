@@ -32,7 +32,7 @@ struct DevCache {
 	std::vector<Block> free_blocks;                 // cached, not in use
 	std::vector<Block> live;                        // handed out (to know their size on free)
 	size_t cached_bytes = 0;
-	static constexpr size_t MAX_CACHED = (size_t)64 << 30;
+	static constexpr size_t MAX_CACHED = (size_t)16 << 30;   // HBM the cache may keep out of sight of other allocators (mm2c_tune("trim", 0) returns it)
 } DC;
 
 hipError_t dev_alloc(void **out, size_t bytes)
@@ -73,6 +73,8 @@ hipError_t dev_alloc(void **out, size_t bytes)
 void dev_free(void *p)
 {
 	if (!p) return;
+	// like hipFree, this waits for the device: a parked block is handed to the next caller at once, so nothing may still be in flight on it
+	(void)hipDeviceSynchronize();
 	DevCache::Block b{p, 0};
 	bool park = false;
 	{
@@ -89,7 +91,7 @@ void dev_free(void *p)
 void dev_cache_release()
 {
 	std::vector<DevCache::Block> drop;
-	{ std::lock_guard<std::mutex> lk(DC.mu); drop.swap(DC.free_blocks); DC.cached_bytes = 0; DC.live.clear(); }
+	{ std::lock_guard<std::mutex> lk(DC.mu); drop.swap(DC.free_blocks); DC.cached_bytes = 0; }   // blocks still handed out stay known (their size is needed when they come back)
 	for (auto &b : drop) (void)hipFree(b.p);
 }
 
@@ -271,6 +273,8 @@ int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_byt
 
 int mm2c_tune(const char *key, int value)
 {
+	std::lock_guard<std::mutex> lk(G.mu);
+	if (key && strcmp(key, "trim") == 0) { dev_cache_release(); return 0; }   // give the cached device memory back to the runtime
 	if (!key) return fail(MM2C_E_ARG, "key is NULL");
 	if (strcmp(key, "ring_class") == 0) {
 		if (value < 0 || value > 3) return fail(MM2C_E_ARG, "ring_class must be 0, 1, 2 or 3");
@@ -382,7 +386,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (pl->n_tasks == 0 || pl->total == 0) return 0;
 	if (!d_anchors || !d_f || !d_p) return fail(MM2C_E_ARG, "device pointer is NULL");
-	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
@@ -432,7 +436,7 @@ int mm2c_plan_predict_device(mm2c_plan_t *pl, const void *d_anchors, uint8_t *d_
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (pl->n_tasks == 0) return 0;
 	if (!d_anchors && pl->total > 0) return fail(MM2C_E_ARG, "device pointer is NULL");
-	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	HIP_TRY(mm2c::launch_predict(pl->par.max_dist_x, pl->n_tasks, pl->d_off, pl->d_order, d_anchors, d_num_subparts,
 	                             d_total_subparts, d_total_trip_count, st));
 	G.launches += 1;
@@ -464,7 +468,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (!d_u_off || !d_b_off) return fail(MM2C_E_ARG, "device pointer is NULL");
-	hipStream_t st = stream ? (hipStream_t)stream : G.stream;
+	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	if (pl->n_tasks == 0 || pl->total == 0) {
 		HIP_TRY(hipMemsetAsync(d_u_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));
 		HIP_TRY(hipMemsetAsync(d_b_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));

@@ -32,7 +32,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	for (int r = 0; r < n_req; ++r) { total += reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]; n_tasks_all += reqs[r]->n_tasks; }
 	if (total == 0) return 0;
 	// cutting costs a host pass over the anchors: only worth it when the pass has too few tasks to fill the GPU on its own
-	const int64_t seg_min = n_tasks_all < G.cut_below_tasks ? G.seg_min : 0;
+	const int64_t seg_min = n_tasks_all < G.cut_below_tasks ? (int)G.seg_min.load() : 0;
 	// uncut tasks without a caller-supplied avg_qspan_scaled: the kernel sums the spans itself (chain.c:48-49), no host pass
 	bool kernel_avg = seg_min == 0;
 	for (int r = 0; r < n_req; ++r) if (reqs[r]->avg) kernel_avg = false;
@@ -203,30 +203,47 @@ int submit_combined(HostReq *me)
 		if (!CB.leader_active) break;
 		CB.cv.wait(lk);
 	}
-	// leader: collect the pending requests that share my scalars, up to the staging size
+	// leader: collect the pending requests that share my scalars, up to the staging size.  Nothing in here may leave the followers waiting
+	// or `leader_active` set: allocation failures (std::bad_alloc from the vectors here and inside run_requests) become an error code for
+	// every request of the batch, and no exception crosses the extern "C" boundary.
 	CB.leader_active = true;
 	std::vector<HostReq *> batch, rest;
-	size_t tot = 0;
-	for (HostReq *q : CB.pending) {
-		const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
-		if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; }
-		else rest.push_back(q);
-	}
-	CB.pending.swap(rest);
-	lk.unlock();
 	int rc = 0;
-	{
-		std::lock_guard<std::mutex> gl(G.mu);
-		if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
-		else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
-			CB.ctx = ThreadCtx();
-			hipError_t e = hipSetDevice(G.device);
-			if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
-			if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
-			else CB.epoch = G.epoch;
+	try {
+		size_t tot = 0;
+		for (HostReq *q : CB.pending) {
+			const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
+			if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; }
+			else rest.push_back(q);
 		}
+		CB.pending.swap(rest);
+	} catch (...) {
+		// could not even form the batch: serve only myself (the others stay pending for the next leader)
+		batch.clear();
+		for (size_t k = 0; k < CB.pending.size(); ++k) if (CB.pending[k] == me) { CB.pending.erase(CB.pending.begin() + (long)k); break; }
+		me->rc = fail(MM2C_E_ARG, "out of host memory in the call combiner"); me->done = true;
+		strncpy(me->err, g_err, sizeof(me->err) - 1); me->err[sizeof(me->err) - 1] = 0;
+		CB.leader_active = false;
+		CB.cv.notify_all();
+		return me->rc;
 	}
-	if (rc == 0) rc = run_requests(&CB.ctx, batch.data(), (int)batch.size());
+	lk.unlock();
+	try {
+		{
+			std::lock_guard<std::mutex> gl(G.mu);
+			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+			else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
+				CB.ctx = ThreadCtx();
+				hipError_t e = hipSetDevice(G.device);
+				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
+				if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
+				else CB.epoch = G.epoch;
+			}
+		}
+		if (rc == 0) rc = run_requests(&CB.ctx, batch.data(), (int)batch.size());
+	} catch (...) {
+		rc = fail(MM2C_E_ARG, "out of host memory in a combined chaining pass");
+	}
 	lk.lock();
 	for (HostReq *q : batch) {
 		q->rc = rc; q->done = true;
@@ -295,7 +312,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 	ThreadCtx *c;
 	if ((rc = get_thread_ctx(&c))) return rc;
 	HIP_TRY(hipSetDevice(G.device));
-	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors : total;
+	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors.load() : total;
 	const mm2c_anchor_t *a0 = h_anchors + h_offsets[0];
 	int64_t base_u = 0, base_b = 0;
 	int nl = 0;

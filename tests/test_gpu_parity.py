@@ -562,6 +562,31 @@ def test_hip_on_every_committed_golden_vector():
         assert_same(f, p, z["f"], z["p"], z["offsets"], name)
 
 
+def test_runs_are_ordered_on_torchs_stream_without_device_sync():
+    """producer (upload, fill) and consumer (download) on torch's current stream -- the default one (the HIP null stream, handle 0) and a side
+    stream -- with no torch.cuda.synchronize() anywhere: the library enqueues on the stream it is handed, NULL meaning the null stream"""
+    import contextlib
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 96, (500, 4000), seed=77)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    total = a.shape[0]
+    h_a = torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1, 2)).pin_memory()
+    for side in (None, torch.cuda.Stream()):
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            d_a = h_a.cuda(non_blocking=True)
+            d_f = torch.empty(total, dtype=torch.int32, device="cuda").fill_(-5)
+            d_p = torch.empty(total, dtype=torch.int32, device="cuda").fill_(-5)
+            plan = mm2chain.ChainPlan(P, off)
+            plan.run(d_a, d_f, d_p)
+            u_off, u, b_off, b = plan.chains(d_a, d_f, d_p, 3, 40)
+            f, p, n_chains = d_f.cpu().numpy(), d_p.cpu().numpy(), int(u_off[-1].item())     # stream-ordered copies
+            plan.close()
+        assert_same(f, p, f_ref, p_ref, off, "side stream" if side is not None else "default stream")
+        assert n_chains > 0
+
+
 def test_real_anchor_lists_from_the_reference_test_data():
     """anchors that reach mm_chain_dp for test/MT-human.fa vs MT-orang.fa and t-inv.fa vs q-inv.fa (dumped through the
     reference's own host objects, tests/golden/make_ref_anchor_fixtures.py): f/p through the kernel, chains through mm_chain_dp"""
