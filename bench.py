@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--ring-class", type=int, default=None)
     ap.add_argument("--general", action="store_true", help="run the general kernel variant (segment ids / cDNA branches, chain.c:206,211-217) on the same stream")
     ap.add_argument("--gap-scale", type=float, default=None, help="chain_gap_scale other than 1 (the f64 path of chain.c:219)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE fixed batch of --reads reads (the same on every rank), its tasks dealt to the ranks by "
+                         "sharding.shard_tasks (longest first, on anchors per task) and gathered into a rank-local CSR batch; "
+                         "value = anchors of the whole batch / max-over-ranks time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     args = ap.parse_args()
 
@@ -139,8 +143,43 @@ def main():
     distinct = min(args.distinct, args.reads)
     times = max(1, args.reads // distinct)
     n_per = (int(0.2 * args.anchors_per_read), int(1.8 * args.anchors_per_read)) if args.ragged else args.anchors_per_read
-    off1, a1 = synth.make_stream(args.profile, distinct, n_per, seed=args.seed + rank, q_span=q_span, device="cuda", locus=locus)
-    off, anchors = synth.replicate(off1, a1, times)
+    off1, a1 = synth.make_stream(args.profile, distinct, n_per, seed=args.seed + (0 if args.strong else rank), q_span=q_span, device="cuda", locus=locus)
+    distinct_chk = distinct
+    if not args.strong:
+        off, anchors = synth.replicate(off1, a1, times)
+        global_total = int(off[-1])
+    else:
+        # ONE batch for all ranks: the `distinct` synthetic reads tiled `times` times (task t = distinct read t mod distinct, as
+        # synth.replicate lays them out); this rank keeps the tasks shard_tasks deals it and builds its own CSR batch from them.
+        sizes1 = (off1[1:] - off1[:-1]).numpy()
+        sizes = np.tile(sizes1, times)
+        global_total = int(sizes.sum())
+        ids = sharding.shard_tasks(sizes, world, rank)
+        d_ids = ids % distinct
+        lens = sizes1[d_ids]
+        new_off = np.zeros(ids.size + 1, dtype=np.int64); new_off[1:] = np.cumsum(lens)
+        starts = off1.numpy()[:-1][d_ids]
+        n_loc_rows = int(new_off[-1])
+        anchors = torch.empty((n_loc_rows, 2), dtype=torch.int64, device="cuda")
+        rel = torch.from_numpy(starts - new_off[:-1]).cuda()              # source row = destination row + rel[task]
+        lens_t = torch.from_numpy(lens).cuda()
+        CH = 1 << 24                                                      # rows per gather: torch's indexing kernels go wrong beyond 2^31 bytes
+        t_lo = 0
+        while t_lo < ids.size:                                            # whole tasks per chunk
+            t_hi = int(np.searchsorted(new_off, new_off[t_lo] + CH, side="right")) - 1
+            t_hi = max(t_hi, t_lo + 1)
+            r0, r1 = int(new_off[t_lo]), int(new_off[t_hi])
+            src = torch.repeat_interleave(rel[t_lo:t_hi], lens_t[t_lo:t_hi]) + torch.arange(r0, r1, device="cuda")
+            anchors[r0:r1] = a1.index_select(0, src)
+            t_lo = t_hi
+        for t in (0, ids.size - 1):                                       # the gather is part of the harness: check it
+            assert torch.equal(anchors[int(new_off[t]):int(new_off[t + 1])], a1[int(starts[t]):int(starts[t]) + int(lens[t])])
+        off = torch.from_numpy(new_off)
+        # the reads the oracle check below looks at: the first ones of THIS rank's batch
+        n_loc = min(64, ids.size)
+        off1 = off[: n_loc + 1].clone(); a1 = anchors[: int(off1[-1])].clone()
+        distinct_chk = n_loc
+        del src, lens_t, rel
     n_tasks = off.numel() - 1
     total = int(off[-1])
     d_f = torch.empty(total, dtype=torch.int32, device="cuda")
@@ -174,12 +213,17 @@ def main():
 
     # ---- correctness of what was just timed: a sample of tasks against the oracle (outside the timed region)
     import oracle_binding as ob
-    n_check = min(64, distinct)
+    n_check = min(64, distinct_chk)
     end = int(off1[n_check])
     f_ref, p_ref, _ = ob.chain_batch(P, off1[: n_check + 1].numpy(), a1[:end].cpu().numpy().view(np.uint64), min(8, os.cpu_count() or 1))
     verified = bool(np.array_equal(d_f[:end].cpu().numpy(), f_ref) and np.array_equal(d_p[:end].cpu().numpy(), p_ref))
-    last = total - int(off1[-1])                                # the last replica must equal the first one
-    verified = verified and bool(torch.equal(d_f[last:], d_f[: int(off1[-1])]))
+    if not args.strong:
+        last = total - int(off1[-1])                            # the last replica must equal the first one
+        verified = verified and bool(torch.equal(d_f[last:], d_f[: int(off1[-1])]))
+    if world > 1:                                               # every rank's check counts
+        vt = torch.tensor([1 if verified else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+        verified = bool(int(vt[0]))
 
     if rank != 0:
         if world > 1:
@@ -191,12 +235,13 @@ def main():
     out = {
         "metric": "anchors/sec chained", "value": tot_anchors / wall, "unit": "anchors/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"synthetic ONT anchor stream ({args.profile}), {args.anchors_per_read} anchors/read, "
                                f"{args.preset} chaining params (max_dist={P.max_dist_x}, bw={P.bw}, max_iter={P.max_iter}, max_skip={P.max_skip}), "
                                f"HBM-resident",
-                   "reads_per_gpu_per_step": n_tasks, "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
-                   "profile": args.profile, "preset": args.preset, "ragged": bool(args.ragged), "parallelism": f"read-sharded x{world}"},
+                   "reads_per_gpu_per_step": n_tasks, "reads_whole_batch": (global_total and (args.reads if args.strong else n_tasks * world)), "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
+                   "profile": args.profile, "preset": args.preset, "ragged": bool(args.ragged),
+                   "parallelism": f"read-sharded x{world}" + (" (one batch, tasks dealt longest-first)" if args.strong else "")},
         "verified_vs_oracle": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_wave", "kernel_ms_avg": k_avg_ms,
@@ -206,7 +251,7 @@ def main():
 
     # ---- secondary figures (outside the timed region, rank 0)
     try:
-        if args.no_secondary or world > 1:                                # N = 1 only: keep multi-GPU runs lean
+        if args.no_secondary or world > 1 or args.strong:                                # N = 1 only: keep multi-GPU runs lean
             raise StopIteration
         _, _, tt = plan_predict_totals(mm2chain, P, off1, a1)
         out["secondary"] = {"nominal_cells_per_s": float(tt) * times / (k_avg_ms * 1e-3),

@@ -57,6 +57,15 @@ typedef struct {
 
 /* ---- lifecycle: replaces hardware_init(BUFFER_N, XCLBIN_FILE) / cleanup() (chain_hardware.h:70-71, main.c:367,430) ---- */
 int  mm2c_init(int device_ordinal);           /* -1: current device.  Idempotent. */
+/* Several devices in one process (the reference scaffolds NUM_HW_KERNELS command queues / buffer sets / locks, chain_hardware.cpp:9-23,
+ * chain_hardware.h:57): mm2c_init_devices instead of mm2c_init.  ordinals[0] is the primary device (plans, the per-read entries and
+ * the call combiner run there); the host-batch entries (mm2c_chain_batch_host, mm2c_mm_chain_dp_batch_host, mm2c_seed_chain_batch_host)
+ * split a batch of at least "multi_min_anchors" anchors (mm2c_tune, default 2^20) into one contiguous range of tasks per device with
+ * about equal anchor counts (mm2c_split_tasks) and run the ranges side by side, each on its own stream set and arenas.  Chaining tasks
+ * are independent (chain.c:42-45), so there is no exchange between devices.  An ordinal may be listed more than once. */
+int  mm2c_init_devices(int n, const int *ordinals);
+int  mm2c_device_count(void);
+int  mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64_t *bounds /* n_parts + 1 */);
 void mm2c_shutdown(void);                     /* not while another thread is inside a compute entry */
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
@@ -95,6 +104,11 @@ int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
  */
 int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *d_avg_qspan,
                          int32_t *d_f, int32_t *d_p, void *stream);
+
+/* The same with the extent of every buffer stated (elements, not bytes): MM2C_E_TOOBIG when one is shorter than the plan needs, the way
+ * the reference refuses n > BUFFER_N (chain_hardware.cpp:34-37).  The entries without _n trust the caller. */
+int mm2c_plan_run_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_anchors, const float *d_avg_qspan, int64_t n_avg,
+                           int32_t *d_f, int64_t n_f, int32_t *d_p, int64_t n_p, void *stream);
 
 /* milliseconds between HIP events recorded (on the run's stream) around the DP kernel (chain_dp_wave) of the most
  * recent mm2c_plan_run_device; synchronises on the end event.  _prepass_ms: the same for the window-start kernel
@@ -152,6 +166,9 @@ mm2c_anchor_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip,
  * mm2c_plan_total_anchors < 2^31 */
 int mm2c_plan_chains_device(mm2c_plan_t *plan, const void *d_anchors, const int32_t *d_f, const int32_t *d_p, int min_cnt, int min_sc,
                             int64_t *d_u_off, uint64_t *d_u, int64_t *d_b_off, void *d_b, void *stream);
+int mm2c_plan_chains_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_anchors, const int32_t *d_f, int64_t n_f, const int32_t *d_p, int64_t n_p,
+                              int min_cnt, int min_sc, int64_t *d_u_off, int64_t n_u_off, uint64_t *d_u, int64_t n_u, int64_t *d_b_off, int64_t n_b_off,
+                              void *d_b, int64_t n_b, void *stream);
 int mm2c_plan_last_epilogue_ms(mm2c_plan_t *plan, float *ms);
 
 /* the epilogue on n_threads host threads from f[] / p[] in host memory (what the reference does on the calling thread) */
@@ -185,6 +202,10 @@ void mm2c_seedplan_destroy(mm2c_seedplan_t *plan);
 /* asynchronous on `stream`; all pointers are device memory; d_anchors needs room for h_anchor_off[n_reads] anchors */
 int mm2c_seedplan_run_device(mm2c_seedplan_t *plan, const mm2c_match_t *d_matches, const uint64_t *d_hits, const int32_t *d_qlen,
                              void *d_anchors, void *stream);
+/* the same with the extents of the buffers stated; a match that points outside hits[0 .. n_hits) is detected on the device and reported by
+ * mm2c_seedplan_check (its read is not expanded) */
+int mm2c_seedplan_run_device_n(mm2c_seedplan_t *plan, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
+                               const int32_t *d_qlen, int64_t n_qlen, void *d_anchors, int64_t n_anchors, void *stream);
 int mm2c_seedplan_check(mm2c_seedplan_t *plan, int64_t *n_reads_with_ties);   /* waits; MM2C_E_ARG if a read's counts disagreed */
 int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
 /* host buffers in, anchors out (computes the anchor offsets itself): anchor_off[n_reads+1], anchors with room for the sum of all n */

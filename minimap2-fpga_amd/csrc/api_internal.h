@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <mutex>
 #include <numeric>
 #include <vector>
@@ -30,7 +32,9 @@ struct ThreadCtx;
 struct Global {
 	std::mutex mu;
 	bool ready = false;
-	int device = -1;
+	int device = -1;                        // primary device (= devices[0])
+	std::vector<int> devices;               // every device the library drives (mm2c_init_devices); entries may repeat
+	std::atomic<int64_t> multi_min_anchors{1 << 20};   // host batches of at least this many anchors are split across the devices
 	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
 	std::atomic<int> ring_class{3};
 	std::atomic<size_t> combine_max_anchors{1u << 17};   // host paths: calls up to this many anchors are combined with concurrent callers' calls
@@ -85,6 +89,13 @@ struct ThreadCtx {
 };
 
 int get_thread_ctx(ThreadCtx **out);
+int cur_device();                                    // device of the calling thread: a worker of a split batch drives its own, everyone else the primary
+int n_devices();
+bool in_split_worker();
+// runs fn(part, k0, k1) for the contiguous task ranges mm2c_split_tasks gives, each on its own host thread bound to its own device context;
+// returns the first non-zero code.  Only used when more than one device is configured and the caller is not itself such a worker.
+bool should_split(int64_t total_anchors);
+int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int(int, int64_t, int64_t)> &fn);
 hipError_t create_partner_stream(hipStream_t *st);
 int grow_device(char **p, size_t *cap, size_t need);
 int grow_pinned(char **p, size_t *cap, size_t need);

@@ -89,6 +89,7 @@ struct SeedArgs {
 	const int32_t *d_order;                      // reads by anchor count, biggest first, or nullptr
 	const Match *d_matches;
 	const uint64_t *d_hits;                      // the hit pool the matches point into
+	int64_t n_hits = 0;                          // its length when the caller declared it (0: matches are trusted)
 	const int32_t *d_qlen;
 	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
 	ulonglong2 *d_anchors;                       // out

@@ -7,6 +7,7 @@
 // -- every accepted call is computed on the GPU; many tasks are in flight at once (one wave each) instead of one
 // task per kernel; callers on different host threads get their own stream and staging buffers instead of a mutex.
 #include "api_internal.h"
+#include <string>
 
 namespace mm2c_api {
 
@@ -33,7 +34,15 @@ struct DevCache {
 	std::vector<Block> live;                        // handed out (to know their size on free)
 	size_t cached_bytes = 0;
 	static constexpr size_t MAX_CACHED = (size_t)16 << 30;   // HBM the cache may keep out of sight of other allocators (mm2c_tune("trim", 0) returns it)
-} DC;
+};
+static DevCache g_caches[64];                      // one per device ordinal: a block is only ever handed back to the device it came from
+static DevCache &dev_cache()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+	return g_caches[d];
+}
+#define DC dev_cache()
 
 hipError_t dev_alloc(void **out, size_t bytes)
 {
@@ -90,20 +99,70 @@ void dev_free(void *p)
 
 void dev_cache_release()
 {
-	std::vector<DevCache::Block> drop;
-	{ std::lock_guard<std::mutex> lk(DC.mu); drop.swap(DC.free_blocks); DC.cached_bytes = 0; }   // blocks still handed out stay known (their size is needed when they come back)
-	for (auto &b : drop) (void)hipFree(b.p);
+	for (DevCache &c : g_caches) {
+		std::vector<DevCache::Block> drop;
+		{ std::lock_guard<std::mutex> lk(c.mu); drop.swap(c.free_blocks); c.cached_bytes = 0; }   // blocks still handed out stay known (their size is needed when they come back)
+		for (auto &b : drop) (void)hipFree(b.p);
+	}
 }
 
 thread_local ThreadCtx *tl_ctx = nullptr;
 thread_local uint64_t tl_epoch = 0;
+thread_local int tl_slot = -1;                     // >= 0: this thread is the worker of a split batch and drives G.devices[tl_slot]
+
+// per device slot: the context the worker of a split batch uses (persistent, so that its arenas are allocated once), and the lock that
+// makes concurrent split batches take turns on it
+static ThreadCtx g_slot_ctx[64];
+static std::mutex g_slot_mu[64];
+static uint64_t g_slot_epoch[64];
+
+int n_devices() { return (int)G.devices.size(); }
+bool in_split_worker() { return tl_slot >= 0; }
+int cur_device() { return tl_slot >= 0 && tl_slot < (int)G.devices.size() ? G.devices[(size_t)tl_slot] : G.device; }
+bool should_split(int64_t total_anchors) { return tl_slot < 0 && G.devices.size() > 1 && total_anchors >= G.multi_min_anchors; }
+
+int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int(int, int64_t, int64_t)> &fn)
+{
+	const int nd = (int)std::min<size_t>(G.devices.size(), 64);
+	std::vector<int64_t> bounds((size_t)nd + 1);
+	if (mm2c_split_tasks(n_tasks, h_offsets, nd, bounds.data()) != 0) return MM2C_E_ARG;
+	std::vector<int> rcs((size_t)nd, 0);
+	std::vector<std::string> errs((size_t)nd);
+	std::vector<std::thread> th;
+	for (int s = 0; s < nd; ++s) {
+		if (bounds[(size_t)s] == bounds[(size_t)s + 1]) continue;
+		th.emplace_back([&, s]() {
+			std::lock_guard<std::mutex> hold(g_slot_mu[s]);            // one split batch at a time per device context
+			tl_slot = s;
+			rcs[(size_t)s] = fn(s, bounds[(size_t)s], bounds[(size_t)s + 1]);
+			if (rcs[(size_t)s] != 0) errs[(size_t)s] = g_err;
+			tl_slot = -1;
+		});
+	}
+	for (auto &t : th) t.join();
+	for (int s = 0; s < nd; ++s) if (rcs[(size_t)s] != 0) return fail(rcs[(size_t)s], "device %d: %s", G.devices[(size_t)s], errs[(size_t)s].c_str());
+	return 0;
+}
 
 int get_thread_ctx(ThreadCtx **out)
 {
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (tl_slot >= 0) {
+		// the worker of a split batch: the persistent context of its device slot (the caller holds the slot's lock)
+		ThreadCtx *c = &g_slot_ctx[tl_slot];
+		HIP_TRY(hipSetDevice(cur_device()));
+		if (!c->st || g_slot_epoch[tl_slot] != G.epoch) {
+			*c = ThreadCtx();
+			hipError_t e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+			if (e != hipSuccess) return fail(MM2C_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+			g_slot_epoch[tl_slot] = G.epoch;
+		}
+		*out = c;
+		return 0;
+	}
 	if (tl_ctx && tl_epoch == G.epoch) { *out = tl_ctx; return 0; }
-	HIP_TRY(hipSetDevice(G.device));
+	HIP_TRY(hipSetDevice(cur_device()));
 	ThreadCtx *c = new ThreadCtx();
 	hipError_t e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete c; return fail(MM2C_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -209,6 +268,7 @@ using namespace mm2c_api;
 
 struct mm2c_plan {
 	mm2c_params_t par;
+	int device = 0;                         // the device the plan's workspace lives on
 	int64_t n_tasks = 0, total = 0;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
@@ -238,9 +298,48 @@ int mm2c_init(int device_ordinal)
 	HIP_TRY(hipSetDevice(dev));
 	HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
 	G.device = dev;
+	if (G.devices.empty()) G.devices.assign(1, dev);
 	const char *rc = getenv("MM2C_RING_CLASS");
 	G.ring_class = rc ? std::max(0, std::min(3, atoi(rc))) : 3;
 	G.ready = true;
+	return 0;
+}
+
+int mm2c_init_devices(int n, const int *ordinals)
+{
+	if (n < 1 || n > 64 || !ordinals) return fail(MM2C_E_ARG, "1 to 64 device ordinals expected");
+	{
+		std::lock_guard<std::mutex> lk(G.mu);
+		if (G.ready) return fail(MM2C_E_ARG, "mm2c_init_devices after initialisation: call mm2c_shutdown first");
+		int n_dev = 0;
+		hipError_t e = hipGetDeviceCount(&n_dev);
+		if (e != hipSuccess || n_dev <= 0)
+			return fail(MM2C_E_NODEVICE, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+		for (int k = 0; k < n; ++k)
+			if (ordinals[k] < 0 || ordinals[k] >= n_dev) return fail(MM2C_E_NODEVICE, "device ordinal %d out of range (%d devices)", ordinals[k], n_dev);
+		G.devices.assign(ordinals, ordinals + n);
+	}
+	const int rc = mm2c_init(ordinals[0]);
+	if (rc != 0) { std::lock_guard<std::mutex> lk(G.mu); G.devices.clear(); }
+	return rc;
+}
+
+int mm2c_device_count(void) { return G.ready ? (int)G.devices.size() : 0; }
+
+/* Contiguous ranges of tasks with about equal anchor counts: range s = tasks [bounds[s], bounds[s+1]).  A range ends at the first task
+ * boundary at or beyond s+1 parts of the total (so no range exceeds its share by more than one task); ranges may be empty. */
+int mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64_t *bounds)
+{
+	if (n_tasks < 0 || n_parts < 1 || !bounds || (n_tasks > 0 && !offsets)) return fail(MM2C_E_ARG, "bad argument");
+	bounds[0] = 0;
+	const int64_t total = n_tasks > 0 ? offsets[n_tasks] - offsets[0] : 0;
+	int64_t k = 0;
+	for (int s = 1; s <= n_parts; ++s) {
+		if (s == n_parts) { bounds[s] = n_tasks; break; }
+		const int64_t goal = offsets ? offsets[0] + (int64_t)((__int128)total * s / n_parts) : 0;
+		while (k < n_tasks && offsets[k] < goal) ++k;
+		bounds[s] = k;
+	}
 	return 0;
 }
 
@@ -248,14 +347,17 @@ void mm2c_shutdown(void)
 {
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!G.ready) return;
-	(void)hipSetDevice(G.device);
+	(void)hipSetDevice(cur_device());
 	(void)hipDeviceSynchronize();
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
+	for (size_t k = 0; k < G.devices.size() && k < 64; ++k) if (g_slot_ctx[k].st) { (void)hipSetDevice(G.devices[k]); (void)hipDeviceSynchronize(); g_slot_ctx[k].release(); }
+	(void)hipSetDevice(G.device);
 	release_combiner();
 	dev_cache_release();
 	G.thread_ctxs.clear();
 	if (G.stream) (void)hipStreamDestroy(G.stream);
 	G.stream = nullptr;
+	G.devices.clear();
 	G.ready = false;
 	++G.epoch;
 }
@@ -264,7 +366,7 @@ int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_byt
 {
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	hipDeviceProp_t prop;
-	HIP_TRY(hipGetDeviceProperties(&prop, G.device));
+	HIP_TRY(hipGetDeviceProperties(&prop, cur_device()));
 	if (name && name_len) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
 	if (cu_count) *cu_count = prop.multiProcessorCount;
 	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
@@ -294,6 +396,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "plan_cut_min") == 0) {
 		if (value < 1) return fail(MM2C_E_ARG, "plan_cut_min must be >= 1");
 		G.plan_cut_min = value;
+		return 0;
+	}
+	if (strcmp(key, "multi_min_anchors") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "multi_min_anchors must be >= 0");
+		G.multi_min_anchors = value;
 		return 0;
 	}
 	if (strcmp(key, "seg_min") == 0) {
@@ -339,7 +446,8 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	pl->total = n_tasks > 0 ? h_offsets[n_tasks] - h_offsets[0] : 0;
 	pl->sizes_desc.resize((size_t)n_tasks);
 	for (int64_t k = 0; k < n_tasks; ++k) pl->sizes_desc[(size_t)k] = (int32_t)(h_offsets[order[(size_t)k] + 1] - h_offsets[order[(size_t)k]]);
-	hipError_t e = hipSetDevice(G.device);
+	pl->device = cur_device();
+	hipError_t e = hipSetDevice(pl->device);
 	const size_t nt = (size_t)std::max<int64_t>(n_tasks, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_off, (nt + 1) * 8);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_order, nt * 4);
@@ -368,6 +476,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 void mm2c_plan_destroy(mm2c_plan_t *pl)
 {
 	if (!pl) return;
+	(void)hipSetDevice(pl->device);
 	if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // as hipFree would: the blocks go back to the cache and may be reused at once
 	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st); dev_free(pl->d_avg_ws);
 	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
@@ -386,6 +495,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (pl->n_tasks == 0 || pl->total == 0) return 0;
 	if (!d_anchors || !d_f || !d_p) return fail(MM2C_E_ARG, "device pointer is NULL");
+	HIP_TRY(hipSetDevice(pl->device));
 	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
@@ -452,6 +562,17 @@ int mm2c_plan_last_prepass_ms(mm2c_plan_t *pl, float *ms)
 	return 0;
 }
 
+int mm2c_plan_run_device_n(mm2c_plan_t *pl, const void *d_anchors, int64_t n_anchors, const float *d_avg_qspan, int64_t n_avg,
+                           int32_t *d_f, int64_t n_f, int32_t *d_p, int64_t n_p, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	// the reference refuses a call that does not fit its device buffers (chain_hardware.cpp:34-37); here the caller states what its buffers hold
+	if (n_anchors < pl->total || n_f < pl->total || n_p < pl->total || (d_avg_qspan && n_avg < pl->n_tasks))
+		return fail(MM2C_E_TOOBIG, "a buffer is shorter than the plan's %lld anchors / %lld tasks (anchors %lld, f %lld, p %lld, avg %lld)",
+		            (long long)pl->total, (long long)pl->n_tasks, (long long)n_anchors, (long long)n_f, (long long)n_p, (long long)n_avg);
+	return mm2c_plan_run_device(pl, d_anchors, d_avg_qspan, d_f, d_p, stream);
+}
+
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 {
 	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
@@ -478,7 +599,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	if (pl->total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "the device epilogue takes batches of fewer than 2^31 anchors (got %lld)", (long long)pl->total);
 	mm2c::EpiArgs &E = pl->E;
 	if (!pl->d_epi) {
-		HIP_TRY(hipSetDevice(G.device));
+		HIP_TRY(hipSetDevice(pl->device));
 		const size_t tmp = mm2c::epilogue_sort_temp_bytes(pl->total, pl->n_tasks);
 		const size_t bytes = layout_epilogue(E, nullptr, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
 		HIP_TRY(dev_alloc((void **)&pl->d_epi, bytes));
@@ -499,6 +620,16 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	return 0;
 }
 
+int mm2c_plan_chains_device_n(mm2c_plan_t *pl, const void *d_anchors, int64_t n_anchors, const int32_t *d_f, int64_t n_f, const int32_t *d_p, int64_t n_p,
+                              int min_cnt, int min_sc, int64_t *d_u_off, int64_t n_u_off, uint64_t *d_u, int64_t n_u, int64_t *d_b_off, int64_t n_b_off,
+                              void *d_b, int64_t n_b, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (n_anchors < pl->total || n_f < pl->total || n_p < pl->total || n_u < pl->total || n_b < pl->total || n_u_off < pl->n_tasks + 1 || n_b_off < pl->n_tasks + 1)
+		return fail(MM2C_E_TOOBIG, "a buffer is shorter than the plan's %lld anchors / %lld tasks", (long long)pl->total, (long long)pl->n_tasks);
+	return mm2c_plan_chains_device(pl, d_anchors, d_f, d_p, min_cnt, min_sc, d_u_off, d_u, d_b_off, d_b, stream);
+}
+
 int mm2c_plan_last_epilogue_ms(mm2c_plan_t *pl, float *ms)
 {
 	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
@@ -512,7 +643,7 @@ void *mm2c_pinned_alloc(size_t bytes)
 {
 	void *p = nullptr;
 	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
-	if (hipSetDevice(G.device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+	if (hipSetDevice(cur_device()) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
 		fail(MM2C_E_HIP, "hipHostMalloc(%zu) failed", bytes);
 		return nullptr;
 	}

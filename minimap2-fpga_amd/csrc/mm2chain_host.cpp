@@ -67,7 +67,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	seg_off.push_back(total);
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
-	HIP_TRY(hipSetDevice(G.device));
+	HIP_TRY(hipSetDevice(cur_device()));
 	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
 	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
@@ -234,7 +234,7 @@ int submit_combined(HostReq *me)
 			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 			else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
 				CB.ctx = ThreadCtx();
-				hipError_t e = hipSetDevice(G.device);
+				hipError_t e = hipSetDevice(cur_device());
 				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
 				if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
 				else CB.epoch = G.epoch;
@@ -270,6 +270,10 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
 	if (total == 0) return 0;
 	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (should_split(total))      // several devices: one contiguous range of tasks per device, side by side (f / p are indexed by the caller's offsets)
+		return run_split(n_tasks, h_offsets, [&](int, int64_t k0, int64_t k1) {
+			return mm2c_chain_batch_host(par, k1 - k0, h_offsets + k0, h_anchors, h_avg_qspan ? h_avg_qspan + k0 : nullptr, h_f, h_p);
+		});
 	HostReq req;
 	req.par = par; req.n_tasks = n_tasks; req.off = h_offsets; req.a = h_anchors; req.avg = h_avg_qspan; req.f = h_f; req.p = h_p;
 	req.err[0] = 0;
@@ -306,12 +310,38 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		return rc ? fail(rc, "mm2c_chain_epilogue_host failed") : 0;
 	}
 	if (total == 0) { for (int64_t k = 1; k <= n_tasks; ++k) u_off[k] = b_off[k] = 0; return 0; }
+	if (should_split(total)) {
+		// several devices: each takes a contiguous range of tasks and leaves its chains compact at the place in u / b where its anchors
+		// would start (there is room: a range has no more chains or chained anchors than anchors); then the ranges are closed up
+		const int nd = n_devices();
+		std::vector<std::vector<int64_t>> uo((size_t)nd), bo((size_t)nd);
+		std::vector<int64_t> r0((size_t)nd, 0), r1((size_t)nd, 0);
+		rc = run_split(n_tasks, h_offsets, [&](int part, int64_t k0, int64_t k1) {
+			uo[(size_t)part].assign((size_t)(k1 - k0) + 1, 0); bo[(size_t)part].assign((size_t)(k1 - k0) + 1, 0);
+			r0[(size_t)part] = k0; r1[(size_t)part] = k1;
+			const int64_t at = h_offsets[k0] - h_offsets[0];
+			return mm2c_mm_chain_dp_batch_host(par, min_cnt, min_sc, k1 - k0, h_offsets + k0, h_anchors, 0, uo[(size_t)part].data(), u + at,
+			                                   bo[(size_t)part].data(), b + at);
+		});
+		if (rc != 0) return rc;
+		int64_t U = 0, B = 0;
+		for (int part = 0; part < nd; ++part) {
+			const int64_t k0 = r0[(size_t)part], k1 = r1[(size_t)part];
+			if (k1 == k0) continue;
+			const int64_t at = h_offsets[k0] - h_offsets[0], nu = uo[(size_t)part].back(), nb = bo[(size_t)part].back();
+			if (U != at) memmove(u + U, u + at, (size_t)nu * 8);
+			if (B != at) memmove(b + B, b + at, (size_t)nb * 16);
+			for (int64_t k = k0; k < k1; ++k) { u_off[k + 1] = U + uo[(size_t)part][(size_t)(k - k0) + 1]; b_off[k + 1] = B + bo[(size_t)part][(size_t)(k - k0) + 1]; }
+			U += nu; B += nb;
+		}
+		return 0;
+	}
 	// everything on the GPU: anchors up, DP, epilogue, chains down; big batches in chunks of whole tasks on two streams, so that the
 	// upload of chunk k+1, the kernels of chunk k and the download of chunk k-1 overlap
 	if (total >= (int64_t)INT32_MAX && G.pipeline_chunk_anchors >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch too big for one chunk");
 	ThreadCtx *c;
 	if ((rc = get_thread_ctx(&c))) return rc;
-	HIP_TRY(hipSetDevice(G.device));
+	HIP_TRY(hipSetDevice(cur_device()));
 	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors.load() : total;
 	const mm2c_anchor_t *a0 = h_anchors + h_offsets[0];
 	int64_t base_u = 0, base_b = 0;

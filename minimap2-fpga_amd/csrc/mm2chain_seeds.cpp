@@ -6,6 +6,8 @@ using namespace mm2c_api;
 
 struct mm2c_seedplan {
 	int64_t n_reads = 0, total = 0, n_matches = 0;
+	int device = 0;
+	int64_t n_hits_declared = 0;           // set by mm2c_seedplan_run_device_n for the run it starts
 	char *d_mem = nullptr;                 // [match_off | anchor_off | order | status | has_ties | stack | unsorted | scratch | big_id | big_dg]
 	mm2c::SeedArgs S;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -38,7 +40,8 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
 	             o_stack = take(4 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
 	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1);
-	hipError_t e = hipSetDevice(G.device);
+	pl->device = cur_device();
+	hipError_t e = hipSetDevice(pl->device);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_mem, at);
 	if (e == hipSuccess && n_reads > 0) {
 		std::vector<int64_t> off((size_t)n_reads + 1);
@@ -72,6 +75,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
 {
 	if (!pl) return;
+	(void)hipSetDevice(pl->device);
 	if (pl->ran) (void)hipDeviceSynchronize();
 	dev_free(pl->d_mem);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
@@ -91,6 +95,7 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	mm2c::SeedArgs &S = pl->S;
 	S.d_matches = (const mm2c::Match *)d_matches; S.d_hits = d_hits; S.d_qlen = d_qlen; S.d_anchors = (ulonglong2 *)d_anchors;
+	S.n_hits = pl->n_hits_declared; pl->n_hits_declared = 0;
 	HIP_TRY(hipMemsetAsync(S.status, 0, (size_t)pl->n_reads * 4, st));
 	HIP_TRY(hipMemsetAsync(S.has_ties, 0, (size_t)pl->n_reads * 4, st));
 	HIP_TRY(hipEventRecord(pl->ev0, st));
@@ -100,6 +105,18 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	pl->ran = true;
 	G.launches += (uint64_t)nl;
 	return 0;
+}
+
+int mm2c_seedplan_run_device_n(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
+                               const int32_t *d_qlen, int64_t n_qlen, void *d_anchors, int64_t n_anchors, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (n_matches < pl->n_matches || n_qlen < pl->n_reads || n_anchors < pl->total || n_hits < 0)
+		return fail(MM2C_E_TOOBIG, "a buffer is shorter than the plan needs (matches %lld of %lld, qlen %lld of %lld, anchors %lld of %lld)",
+		            (long long)n_matches, (long long)pl->n_matches, (long long)n_qlen, (long long)pl->n_reads, (long long)n_anchors, (long long)pl->total);
+	if (pl->total > 0 && n_hits == 0) return fail(MM2C_E_TOOBIG, "the hit pool is empty but the plan expands %lld hits", (long long)pl->total);
+	pl->n_hits_declared = n_hits;                  // checked per match on the device (mm2c_seedplan_check reports it)
+	return mm2c_seedplan_run_device(pl, d_matches, d_hits, d_qlen, d_anchors, stream);
 }
 
 int mm2c_seedplan_check(mm2c_seedplan_t *pl, int64_t *n_reads_with_ties)
@@ -113,6 +130,7 @@ int mm2c_seedplan_check(mm2c_seedplan_t *pl, int64_t *n_reads_with_ties)
 	HIP_TRY(hipMemcpy(ti.data(), pl->S.has_ties, ti.size() * 4, hipMemcpyDeviceToHost));
 	int64_t nt = 0;
 	for (size_t r = 0; r < st.size(); ++r) {
+		if (st[r] == 2) return fail(MM2C_E_ARG, "read %zu: a match points outside the declared hit pool", r);
 		if (st[r] != 0) return fail(MM2C_E_ARG, "read %zu: the hit counts of its matches do not add up to its anchor range", r);
 		nt += ti[r] != 0;
 	}
@@ -200,6 +218,32 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 	const int64_t total = anchor_off[n_reads];
 	if (total == 0) { for (int64_t r = 1; r <= n_reads; ++r) u_off[r] = b_off[r] = 0; return 0; }
 	if (!h_hits || !u || !b) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (should_split(total)) {
+		// several devices: a contiguous range of reads each (about equal anchor counts), results closed up afterwards as in mm2c_mm_chain_dp_batch_host
+		const int nd = n_devices();
+		std::vector<std::vector<int64_t>> ao((size_t)nd), uo((size_t)nd), bo((size_t)nd);
+		std::vector<int64_t> r0((size_t)nd, 0), r1((size_t)nd, 0);
+		rc = run_split(n_reads, anchor_off, [&](int part, int64_t k0, int64_t k1) {
+			const size_t m = (size_t)(k1 - k0) + 1;
+			ao[(size_t)part].assign(m, 0); uo[(size_t)part].assign(m, 0); bo[(size_t)part].assign(m, 0);
+			r0[(size_t)part] = k0; r1[(size_t)part] = k1;
+			const int64_t at = anchor_off[k0];
+			return mm2c_seed_chain_batch_host(par, min_cnt, min_sc, k1 - k0, h_match_off + k0, h_matches, h_hits, n_hits, h_qlen + k0,
+			                                  ao[(size_t)part].data(), uo[(size_t)part].data(), u + at, bo[(size_t)part].data(), b + at);
+		});
+		if (rc != 0) return rc;
+		int64_t U = 0, B = 0;
+		for (int part = 0; part < nd; ++part) {
+			const int64_t k0 = r0[(size_t)part], k1 = r1[(size_t)part];
+			if (k1 == k0) continue;
+			const int64_t at = anchor_off[k0], nu = uo[(size_t)part].back(), nb = bo[(size_t)part].back();
+			if (U != at) memmove(u + U, u + at, (size_t)nu * 8);
+			if (B != at) memmove(b + B, b + at, (size_t)nb * 16);
+			for (int64_t k = k0; k < k1; ++k) { u_off[k + 1] = U + uo[(size_t)part][(size_t)(k - k0) + 1]; b_off[k + 1] = B + bo[(size_t)part][(size_t)(k - k0) + 1]; }
+			U += nu; B += nb;
+		}
+		return 0;
+	}
 	if (total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch of %lld anchors; the limit of one call is 2^31-1", (long long)total);
 	mm2c_seedplan_t *sp = mm2c_seedplan_create(n_reads, h_match_off, anchor_off);
 	if (!sp) return MM2C_E_HIP;
@@ -212,6 +256,11 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 	const size_t o_m = take((size_t)n_m * sizeof(mm2c_match_t)), o_h = take((size_t)n_hits * 8), o_q = take(nr * 4), o_a = take(tot * 16),
 	             o_f = take(tot * 4), o_p = take(tot * 4), o_uo = take((nr + 1) * 8), o_bo = take((nr + 1) * 8), o_u = take(tot * 8), o_b = take(tot * 16);
 	hipStream_t st = G.stream;
+	if (in_split_worker()) {                       // the worker of a split batch: the stream of its own device
+		ThreadCtx *c;
+		if ((rc = get_thread_ctx(&c))) { mm2c_plan_destroy(pl); mm2c_seedplan_destroy(sp); return rc; }
+		st = c->st;
+	}
 	auto body = [&]() -> int {
 		int r;
 		HIP_TRY(dev_alloc((void **)&d, at));

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 		const int i = c0 + lane;
 		Match q = {};
 		if (i < nm) q = m[i];
+		if (A.n_hits > 0 && __ballot(i < nm && (q.cr_off < 0 || q.cr_off + (int64_t)q.n > A.n_hits))) {
+			if (lane == 0) A.status[read] = 2;                                   // a match reaches beyond the hit pool the caller declared
+			return;
+		}
 		const int incl = wave_incl_scan((int)q.n, lane);
 		const int total = __shfl(incl, 63);
 		__syncthreads();

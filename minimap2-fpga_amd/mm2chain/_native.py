@@ -30,6 +30,9 @@ class Stats(C.Structure):
 # every symbol include/mm2chain.h declares with C linkage: name -> (restype, argtypes)
 C_SYMBOLS = {
     "mm2c_init": (C.c_int, [C.c_int]),
+    "mm2c_init_devices": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "mm2c_device_count": (C.c_int, []),
+    "mm2c_split_tasks": (C.c_int, [C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "mm2c_shutdown": (None, []),
     "mm2c_last_error": (C.c_char_p, []),
     "mm2c_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
@@ -40,6 +43,7 @@ C_SYMBOLS = {
     "mm2c_plan_destroy": (None, [C.c_void_p]),
     "mm2c_plan_total_anchors": (C.c_int64, [C.c_void_p]),
     "mm2c_plan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_plan_run_device_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "mm2c_plan_predict_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_plan_last_prepass_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -51,6 +55,8 @@ C_SYMBOLS = {
                                  C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
     "mm2c_plan_chains_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_plan_chains_device_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "mm2c_plan_last_epilogue_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_chain_epilogue_host": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -59,6 +65,8 @@ C_SYMBOLS = {
     "mm2c_seedplan_create": (C.c_void_p, [C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_seedplan_destroy": (None, [C.c_void_p]),
     "mm2c_seedplan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_seedplan_run_device_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.c_void_p]),
     "mm2c_seedplan_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mm2c_seedplan_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

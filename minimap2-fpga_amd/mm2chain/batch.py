@@ -26,6 +26,27 @@ def init(device=None):
     _inited = True
 
 
+def init_devices(ordinals):
+    """several devices in one process (the reference's NUM_HW_KERNELS scaffolding, chain_hardware.cpp:9-23): ordinals[0] is the primary
+    device; the host-batch entries split big batches across all of them.  An ordinal may repeat."""
+    global _inited
+    arr = (C.c_int * len(ordinals))(*[int(d) for d in ordinals])
+    N.check(N.load().mm2c_init_devices(len(ordinals), arr), "mm2c_init_devices")
+    _inited = True
+
+
+def device_count():
+    return N.load().mm2c_device_count()
+
+
+def split_tasks(offsets, n_parts):
+    """mm2c_split_tasks: bounds of n_parts contiguous task ranges with about equal anchor counts (no GPU involved)"""
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    bounds = np.zeros(n_parts + 1, dtype=np.int64)
+    N.check(N.load().mm2c_split_tasks(off.size - 1, off.ctypes.data, int(n_parts), bounds.ctypes.data), "mm2c_split_tasks")
+    return bounds
+
+
 def shutdown():
     """cleanup() equivalent (main.c:430)"""
     global _inited
@@ -67,13 +88,15 @@ class ChainPlan:
         """anchors: int64 [total, 2] on the GPU; f, p: int32 [total] on the GPU.  Asynchronous on `stream`
         (default: torch's current stream, so torch.cuda.Event timing and torch.cuda.synchronize see it)."""
         assert anchors.is_cuda and f.is_cuda and p.is_cuda, "HBM-resident path needs device tensors"
-        assert anchors.dtype == torch.int64 and anchors.is_contiguous() and anchors.numel() == 2 * self.total
-        assert f.dtype == torch.int32 and p.dtype == torch.int32 and f.numel() == self.total and p.numel() == self.total
+        assert anchors.dtype == torch.int64 and anchors.is_contiguous() and f.dtype == torch.int32 and p.dtype == torch.int32
+        assert f.is_contiguous() and p.is_contiguous()
         if avg is not None:
-            assert avg.is_cuda and avg.dtype == torch.float32 and avg.numel() == self.n_tasks
+            assert avg.is_cuda and avg.dtype == torch.float32 and avg.is_contiguous()
         st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        N.check(self.lib.mm2c_plan_run_device(self.handle, anchors.data_ptr(), avg.data_ptr() if avg is not None else None,
-                                              f.data_ptr(), p.data_ptr(), st), "mm2c_plan_run_device")
+        # the extents of the tensors go with the pointers: the library refuses buffers shorter than the plan (cf. chain_hardware.cpp:34-37)
+        N.check(self.lib.mm2c_plan_run_device_n(self.handle, anchors.data_ptr(), anchors.numel() // 2, avg.data_ptr() if avg is not None else None,
+                                                avg.numel() if avg is not None else 0, f.data_ptr(), f.numel(), p.data_ptr(), p.numel(), st),
+                "mm2c_plan_run_device_n")
 
     def predict(self, anchors: torch.Tensor, stream=None):
         """chain.c:53-78 on the GPU: returns (num_subparts uint8 [total], total_subparts int64 [n_tasks],
@@ -91,17 +114,16 @@ class ChainPlan:
         """the epilogue of mm_chain_dp (chain.c:106-111,348-422) on the GPU, after run() on the same stream.  Returns device
         tensors (u_off int64 [n_tasks+1], u int64 [total], b_off int64 [n_tasks+1], b int64 [total, 2]); only the first
         u_off[-1] / b_off[-1] entries of u / b are defined."""
-        assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.numel() == 2 * self.total
-        assert f.dtype == torch.int32 and p.dtype == torch.int32 and f.numel() == self.total and p.numel() == self.total
+        assert anchors.is_cuda and anchors.dtype == torch.int64 and f.dtype == torch.int32 and p.dtype == torch.int32
         dev = anchors.device
         u_off = torch.empty(self.n_tasks + 1, dtype=torch.int64, device=dev)
         b_off = torch.empty(self.n_tasks + 1, dtype=torch.int64, device=dev)
         u = torch.empty(max(self.total, 1), dtype=torch.int64, device=dev)
         b = torch.empty((max(self.total, 1), 2), dtype=torch.int64, device=dev)
         st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        N.check(self.lib.mm2c_plan_chains_device(self.handle, anchors.data_ptr(), f.data_ptr(), p.data_ptr(), min_cnt, min_sc,
-                                                 u_off.data_ptr(), u.data_ptr(), b_off.data_ptr(), b.data_ptr(), st),
-                "mm2c_plan_chains_device")
+        N.check(self.lib.mm2c_plan_chains_device_n(self.handle, anchors.data_ptr(), anchors.numel() // 2, f.data_ptr(), f.numel(), p.data_ptr(), p.numel(),
+                                                   min_cnt, min_sc, u_off.data_ptr(), u_off.numel(), u.data_ptr(), u.numel(), b_off.data_ptr(),
+                                                   b_off.numel(), b.data_ptr(), b.numel() // 2, st), "mm2c_plan_chains_device_n")
         return u_off, u, b_off, b
 
     def last_epilogue_ms(self):
@@ -259,8 +281,9 @@ class SeedPlan:
             anchors = torch.empty((max(self.total, 1), 2), dtype=torch.int64, device=hits.device)
         assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.numel() >= 2 * self.total
         st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        N.check(self.lib.mm2c_seedplan_run_device(self.handle, matches.data_ptr(), hits.data_ptr(), qlen.data_ptr(), anchors.data_ptr(), st),
-                "mm2c_seedplan_run_device")
+        N.check(self.lib.mm2c_seedplan_run_device_n(self.handle, matches.data_ptr(), matches.numel() * matches.element_size() // 24, hits.data_ptr(),
+                                                    hits.numel(), qlen.data_ptr(), qlen.numel(), anchors.data_ptr(), anchors.numel() // 2, st),
+                "mm2c_seedplan_run_device_n")
         return anchors
 
     def check(self):

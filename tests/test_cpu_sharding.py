@@ -70,3 +70,26 @@ def test_two_rank_gloo_shards_cover_the_batch():
     assert res[0][3] == res[1][3] == int(off[-1])                      # all-reduced anchor count = whole batch
     assert res[0][2] + res[1][2] == int(f.astype(np.int64).sum())      # the two shards together reproduce the whole
     assert res[0][4] == res[1][4] > 0
+
+
+def test_in_process_device_split_covers_and_balances():
+    """mm2c_split_tasks (the split the host-batch entries use when mm2c_init_devices configured several devices; cf. the reference's
+    per-kernel queue scaffolding chain_hardware.cpp:9-23): with a fake device count, every task lands in exactly one contiguous range, in
+    order, and no range exceeds its share of the anchors by more than its last task.  Pure host logic: no GPU is touched."""
+    import mm2chain
+    rng = np.random.default_rng(3)
+    for n_tasks, n_parts in [(1000, 8), (7, 8), (1, 3), (0, 4), (5000, 2), (64, 64)]:
+        sizes = rng.integers(0, 9000, n_tasks)
+        if n_tasks > 10:
+            sizes[rng.integers(0, n_tasks, 3)] = 300000          # a few very long reads
+        off = np.concatenate([[17], 17 + np.cumsum(sizes)]).astype(np.int64)      # offsets need not start at 0
+        b = mm2chain.split_tasks(off, n_parts)
+        assert b[0] == 0 and b[-1] == n_tasks and np.all(np.diff(b) >= 0)
+        total = int(off[-1] - off[0])
+        for s in range(n_parts):
+            part = int(off[b[s + 1]] - off[b[s]])
+            last = int(sizes[b[s + 1] - 1]) if b[s + 1] > b[s] else 0
+            assert part <= total / n_parts + last + 1, (n_tasks, n_parts, s, part)
+        # ranges end at the first task boundary at or beyond their share
+        for s in range(1, n_parts):
+            assert int(off[b[s]] - off[0]) >= total * s // n_parts or b[s] == n_tasks

@@ -1,0 +1,68 @@
+"""In-process multi-device path of the library (mm2c_init_devices; the reference scaffolds per-kernel queues / buffers / locks,
+chain_hardware.cpp:9-23).  A GPU box of the test pool has one MI355X, so the same ordinal is listed twice (and three times): two device
+contexts with their own streams and arenas, host batches split into contiguous task ranges that run side by side on worker threads and
+are closed up afterwards -- everything the 8-GPU form does except that the contexts share a device.  Results must equal the
+single-context results (which the other GPU tests pin to the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_binding as ob
+from helpers import oracle_batch, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(profile, n_reads, n_per, seed):
+    from mm2chain import synth
+    off, a = synth.make_stream(profile, n_reads, n_per, seed=seed)
+    return off.numpy(), a.numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_host_batches_split_across_device_contexts(n_ctx):
+    import mm2chain
+    from mm2chain import params, synth
+    assert torch.cuda.is_available()
+    P = params.map_ont()
+    off, a = _stream("mixed", 300, (200, 6000), seed=31 + n_ctx)
+    off = off + 5                                              # offsets need not start at 0
+    a_all = np.concatenate([np.zeros((5, 2), np.uint64), a])
+    f_ref, p_ref = oracle_batch(P, off - 5, a)
+    mm2chain.shutdown()
+    mm2chain.init_devices([0] * n_ctx)
+    try:
+        assert mm2chain.device_count() == n_ctx
+        mm2chain.tune("multi_min_anchors", 1000)
+        # f / p through the host-buffer path
+        f, p = mm2chain.chain_batch_host(P, off, a_all)
+        assert_same(f[5:], p[5:], f_ref, p_ref, off - 5, "split chain_batch_host")
+        # whole mm_chain_dp: DP + epilogue on the GPU, chains closed up across the ranges
+        res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a_all, epilogue_threads=0)
+        for k in (0, 1, 57, 150, 299):
+            u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, a_all[off[k]:off[k + 1]])
+            assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), k
+        n_chains = sum(r[0].size for r in res)
+        # matches in, chains out
+        ms, hs, mo, ho, ql = [], [], [0], [0], []
+        for k in range(40):
+            m, h = synth.matches_from_anchors(a_all[off[k]:off[k + 1]], 1 << 20)
+            m = m.copy(); m["cr_off"] += ho[-1]
+            ms.append(m); hs.append(h); mo.append(mo[-1] + m.size); ho.append(ho[-1] + h.size); ql.append(1 << 20)
+        out = mm2chain.seed_chain_batch(P, 3, 40, np.array(mo, np.int64), np.concatenate(ms), np.concatenate(hs), np.array(ql, np.int32))
+    finally:
+        mm2chain.shutdown()
+    # the same three calls with one context
+    mm2chain.init(0)
+    try:
+        res1 = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a_all, epilogue_threads=0)
+        out1 = mm2chain.seed_chain_batch(P, 3, 40, np.array(mo, np.int64), np.concatenate(ms), np.concatenate(hs), np.array(ql, np.int32))
+    finally:
+        mm2chain.shutdown()
+    assert n_chains == sum(r[0].size for r in res1)
+    for k in range(len(res)):
+        assert np.array_equal(res[k][0], res1[k][0]) and np.array_equal(res[k][1], res1[k][1]), k
+    assert len(out) == len(out1) == 40
+    for k in range(40):
+        assert np.array_equal(out[k][0], out1[k][0]) and np.array_equal(out[k][1], out1[k][1]), k
+        assert np.array_equal(out[k][0], res1[k][0]), k          # seeds -> chains == anchors -> chains (scores and counts; the order among equal x is the sort's)

@@ -587,6 +587,43 @@ def test_runs_are_ordered_on_torchs_stream_without_device_sync():
         assert n_chains > 0
 
 
+def test_short_device_buffers_are_refused():
+    """the device-pointer entries take the extent of every buffer; one that is shorter than the plan needs is refused with MM2C_E_TOOBIG
+    before anything is launched (cf. the reference's n > BUFFER_N check, chain_hardware.cpp:34-37)"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 8, 1000, seed=3)
+    total = a.shape[0]
+    d_a = torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1, 2)).cuda()
+    d_f = torch.empty(total, dtype=torch.int32, device="cuda"); d_p = torch.empty_like(d_f)
+    plan = mm2chain.ChainPlan(P, off)
+    for bad in ("anchors", "f", "p", "avg"):
+        args = dict(anchors=d_a, f=d_f, p=d_p, avg=None)
+        if bad == "anchors": args["anchors"] = d_a[:-1].contiguous()
+        elif bad == "avg": args["avg"] = torch.zeros(7, dtype=torch.float32, device="cuda")
+        else: args[bad] = torch.empty(total - 1, dtype=torch.int32, device="cuda")
+        with pytest.raises(RuntimeError, match="shorter than the plan"):
+            plan.run(args["anchors"], args["f"], args["p"], args["avg"])
+    plan.run(d_a, d_f, d_p)
+    with pytest.raises(RuntimeError, match="shorter than the plan"):
+        plan.chains(d_a, d_f[:-1].contiguous(), d_p, 3, 40)
+    torch.cuda.synchronize()
+    plan.close()
+    # seed plan: a match that points outside the declared hit pool is caught on the device
+    from mm2chain import synth
+    m, h = synth.matches_from_anchors(a[off[0]:off[1]], 1 << 20)
+    sp = mm2chain.SeedPlan(np.array([0, m.size], np.int64), np.array([0, int(m["n"].sum())], np.int64))
+    d_m = torch.from_numpy(m.view(np.uint8).copy()).cuda()
+    d_h = torch.from_numpy(h.view(np.int64)).cuda()
+    d_q = torch.tensor([1 << 20], dtype=torch.int32, device="cuda")
+    sp.run(d_m, d_h, d_q); sp.check()
+    sp.run(d_m, d_h[:-1].contiguous(), d_q)
+    with pytest.raises(RuntimeError, match="outside the declared hit pool"):
+        sp.check()
+    sp.close()
+
+
 def test_real_anchor_lists_from_the_reference_test_data():
     """anchors that reach mm_chain_dp for test/MT-human.fa vs MT-orang.fa and t-inv.fa vs q-inv.fa (dumped through the
     reference's own host objects, tests/golden/make_ref_anchor_fixtures.py): f/p through the kernel, chains through mm_chain_dp"""
