@@ -76,6 +76,12 @@ int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_by
  * twice that size (default 20 Mi anchors).  Results never depend on a knob. */
 int  mm2c_tune(const char *key, int value);
 
+/* HW/SW split model of the reference for this hardware (chain.c:80-81,101; constants in the form of chain_hardware.h:19-30 live in
+ * include/mm2chain_split.h): hw_ms = k1_hw * n + k2_hw * total_subparts + c_hw for one synchronous per-read call into this library,
+ * sw_ms = k_sw * total_trip_count + c_sw for chain.c's loop on one host core.  preset: "map-ont" or "asm20".  The library itself never
+ * declines a task; a host that keeps the reference's predictor loads K1_HW .. C_SW (options.c:6,95-99) from here. */
+int  mm2c_split_model(const char *preset, float *k1_hw, float *k2_hw, float *c_hw, float *k_sw, float *c_sw);
+
 /* defaults of `minimap2 -x map-ont` (options.c:24-31,93-99; map.c:305-316) */
 void mm2c_params_map_ont(mm2c_params_t *p);
 /* V2 = what the FPGA kernel computes for a run_chaining_on_hw call */

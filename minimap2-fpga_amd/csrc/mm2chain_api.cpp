@@ -7,6 +7,7 @@
 // -- every accepted call is computed on the GPU; many tasks are in flight at once (one wave each) instead of one
 // task per kernel; callers on different host threads get their own stream and staging buffers instead of a mutex.
 #include "api_internal.h"
+#include "mm2chain_split.h"
 #include <string>
 
 namespace mm2c_api {
@@ -409,6 +410,22 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	return fail(MM2C_E_ARG, "unknown tuning key '%s'", key);
+}
+
+int mm2c_split_model(const char *preset, float *k1_hw, float *k2_hw, float *c_hw, float *k_sw, float *c_sw)
+{
+	// the constants of include/mm2chain_split.h (fitted on the MI355X box by tools/fit_split_model.py) for a host that keeps the reference's
+	// predictor chain.c:80-81,101; presets as options.c:93-99 ("map-ont" and the other ONT / default presets) and :113-122 ("asm20", PacBio CCS)
+	if (!preset || !k1_hw || !k2_hw || !c_hw || !k_sw || !c_sw) return fail(MM2C_E_ARG, "NULL argument");
+	if (strcmp(preset, "map-ont") == 0 || strcmp(preset, "ont") == 0 || strcmp(preset, "ava-ont") == 0) {
+		*k1_hw = (float)MI355X_ONT_K1_HW; *k2_hw = (float)MI355X_ONT_K2_HW; *c_hw = (float)MI355X_ONT_C_HW; *k_sw = (float)MI355X_ONT_K_SW; *c_sw = (float)MI355X_ONT_C_SW;
+		return 0;
+	}
+	if (strcmp(preset, "asm20") == 0 || strcmp(preset, "pbccs") == 0 || strcmp(preset, "map-hifi") == 0) {
+		*k1_hw = (float)MI355X_PBCCS_K1_HW; *k2_hw = (float)MI355X_PBCCS_K2_HW; *c_hw = (float)MI355X_PBCCS_C_HW; *k_sw = (float)MI355X_PBCCS_K_SW; *c_sw = (float)MI355X_PBCCS_C_SW;
+		return 0;
+	}
+	return fail(MM2C_E_ARG, "unknown preset '%s' (map-ont, asm20)", preset);
 }
 
 void mm2c_params_map_ont(mm2c_params_t *p)

@@ -37,6 +37,7 @@ C_SYMBOLS = {
     "mm2c_last_error": (C.c_char_p, []),
     "mm2c_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "mm2c_tune": (C.c_int, [C.c_char_p, C.c_int]),
+    "mm2c_split_model": (C.c_int, [C.c_char_p] + [C.POINTER(C.c_float)] * 5),
     "mm2c_params_map_ont": (None, [C.POINTER(Params)]),
     "mm2c_params_fpga_v2": (None, [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mm2c_plan_create": (C.c_void_p, [C.POINTER(Params), C.c_int64, C.c_void_p]),

@@ -47,6 +47,13 @@ def split_tasks(offsets, n_parts):
     return bounds
 
 
+def split_model(preset="map-ont"):
+    """the HW/SW split constants for this hardware (chain.c:80-81; include/mm2chain_split.h) as a dict K1_HW, K2_HW, C_HW, K_SW, C_SW"""
+    v = [C.c_float(0) for _ in range(5)]
+    N.check(N.load().mm2c_split_model(preset.encode(), *[C.byref(x) for x in v]), "mm2c_split_model")
+    return dict(zip(("K1_HW", "K2_HW", "C_HW", "K_SW", "C_SW"), [x.value for x in v]))
+
+
 def shutdown():
     """cleanup() equivalent (main.c:430)"""
     global _inited

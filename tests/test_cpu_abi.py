@@ -100,3 +100,20 @@ def test_header_is_self_contained_c99_and_cxx11(tmp_path):
     inc = os.path.join(root, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "cxx.o")])
+
+
+def test_split_model_getter_returns_the_header_constants():
+    """f4: mm2c_split_model hands out the constants of include/mm2chain_split.h (the form of chain_hardware.h:19-30) -- non-negative slopes,
+    a positive per-call cost; no GPU needed"""
+    import re
+    import mm2chain
+    txt = open(os.path.join(ROOT, "include", "mm2chain_split.h")).read()
+    hdr = {m.group(1): float(m.group(2)) for m in re.finditer(r"#define MI355X_(\w+) ([-+0-9.eE]+)", txt)}
+    assert len(hdr) == 10
+    for preset, pre in (("map-ont", "ONT"), ("asm20", "PBCCS")):
+        c = mm2chain.split_model(preset)
+        for k, v in c.items():
+            assert abs(v - hdr[f"{pre}_{k}"]) <= 1e-6 * max(1.0, abs(v)), (preset, k)
+        assert c["K1_HW"] >= 0 and c["K2_HW"] >= 0 and c["K_SW"] > 0 and c["C_HW"] > 0
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.split_model("no-such-preset")

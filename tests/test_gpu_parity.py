@@ -768,3 +768,34 @@ def test_full_size_properties():
     sel = slice(0, int(off_np[16]))
     f_ref, p_ref = oracle_batch(P, off_np[:17], a_np[sel])
     assert_same(f0[sel], p0[sel], f_ref, p_ref, off_np[:17], "full-size sample")
+
+
+def test_split_model_decides_like_the_measured_faster_side():
+    """f4 (chain.c:80-81,101): with the committed constants (include/mm2chain_split.h, fitted by tools/fit_split_model.py on an MI355X box) the
+    reference's predictor `hw_ms < sw_ms` must agree with the measured faster side -- one synchronous per-read call into the library vs the
+    CPU port on one core -- on at least 80 % of a fresh set of tasks (other seeds than the fit)"""
+    import time
+    import mm2chain
+    from mm2chain import params, synth
+    P = params.map_ont()
+    c = mm2chain.split_model("map-ont")
+    rng = np.random.default_rng(987)
+    tasks = []
+    for prof in ("mixed", "dense", "colinear", "sparse"):
+        for n in rng.integers(60, 9000, 12):
+            tasks.append(synth.make_stream(prof, 1, int(n), seed=int(rng.integers(1 << 30)))[1].numpy().view(np.uint64))
+    for t in tasks[:6]:
+        mm2chain.chain_task(P, t, 0.15)
+    agree = 0
+    for t in tasks:
+        _, tot_sub, tot_trip = ob.predict(t, P.max_dist_x)
+        hw = min(_timed(lambda: mm2chain.chain_task(P, t, 0.15)) for _ in range(3))
+        sw = min(_timed(lambda: ob.chain_fpv(P, t, 0.15)) for _ in range(2))
+        pred_gpu = c["K1_HW"] * t.shape[0] + c["K2_HW"] * tot_sub + c["C_HW"] < c["K_SW"] * tot_trip + c["C_SW"]
+        agree += int(pred_gpu == (hw < sw))
+    assert agree >= 0.8 * len(tasks), f"the split model agrees with the measurement on {agree} of {len(tasks)} tasks"
+
+
+def _timed(fn):
+    import time
+    t0 = time.perf_counter(); fn(); return (time.perf_counter() - t0) * 1e3

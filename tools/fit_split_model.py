@@ -1,53 +1,141 @@
 #!/usr/bin/env python3
 """Re-fit of the reference's HW/SW split model for MI355X (reference: hw_sw_split/find_params.py fits the same two
-linear models from `param n total_subparts total_trip_count hw_ms sw_ms` lines printed at chain.c:333).
+linear models from the `param n total_subparts total_trip_count hw_ms sw_ms` lines chain.c:333 prints).
    hw_ms = K1_HW * n + K2_HW * total_subparts + C_HW          (chain.c:80)
    sw_ms = K_SW * total_trip_count + C_SW                      (chain.c:81)
-Here: hw_ms = one synchronous mm2c_chain_task_host call (PCIe + launch + DP, pieces cut at empty windows), sw_ms = the CPU oracle
-(port of chain.c:184-238) on one host core; tasks = anchor lists of simulated ONT reads on a synthetic genome, captured from the
-reference host objects, plus synthetic dense tasks to spread the regressors.  Prints constants in the form of chain_hardware.h:19-23."""
-import os, struct, subprocess, sys, time
+Here: hw_ms = one synchronous mm2c_chain_task_host call (PCIe + launch + DP; what run_chaining_on_hw costs a host that calls it per
+read), sw_ms = the CPU oracle (port of chain.c:184-238) on one host core.  Two presets as in chain_hardware.h:19-30: ONT (k = 15 spans;
+anchor lists of simulated reads on a synthetic genome captured from the reference's host objects, plus synthetic tasks that spread the
+regressors) and PBCCS (k = 19 spans, cleaner and longer chains).  The intercepts are what the smallest tasks cost; the slopes come from NON-NEGATIVE least squares
+(n and total_subparts are collinear; an unconstrained fit gives a negative per-anchor cost, which no host could use), on every second task; the
+other half is the hold-out on which the decision `hw_pred < sw_pred` (chain.c:101) is scored against the measured faster side.
+Runs on the GPU box:  python tools/fit_split_model.py  -> include/mm2chain_split.h, profiles/r2_split_model.{md,json}"""
+import json
+import os
+import struct
+import subprocess
+import sys
+import time
+
 import numpy as np
+from scipy.optimize import nnls
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import mm2chain
-from mm2chain import params, synth
-import oracle_binding as ob
-W = "/tmp/splitfit"; os.makedirs(W, exist_ok=True)
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools/make_synth_genome.py"), W + "/syn", "--genome-mb", "50", "--reads", "600"], stdout=subprocess.DEVNULL)
-dump = W + "/dump.bin"
-if os.path.exists(dump): os.unlink(dump)
-subprocess.check_call([os.path.join(ROOT, "oracle/_ref/mm2_refhost"), W + "/syn.ref.fa", W + "/syn.reads.fa"], env=dict(os.environ, MM2O_DUMP=dump), stdout=subprocess.DEVNULL)
-raw = open(dump, "rb").read(); pos = 0; tasks = []
-while pos < len(raw):
-    n, = struct.unpack_from("<q", raw, pos); pos += 8 + 40
-    tasks.append(np.frombuffer(raw, dtype=np.uint64, count=2 * n, offset=pos).reshape(n, 2).copy()); pos += 16 * n
-rng = np.random.default_rng(1)
-for prof in ("mixed", "dense", "colinear"):
-    for n in rng.integers(200, 8000, 60):
-        tasks.append(synth.make_stream(prof, 1, int(n), seed=int(rng.integers(1 << 30)))[1].numpy().view(np.uint64))
-mm2chain.init()
-P = params.map_ont()
-rows = []
-for t in tasks[:20]:
-    mm2chain.chain_task(P, t, 0.15)
-for t in tasks:
-    n = t.shape[0]
-    _, tot_sub, tot_trip = ob.predict(t, P.max_dist_x)
-    h = []
-    for _ in range(3):
-        t0 = time.perf_counter(); mm2chain.chain_task(P, t, 0.15); h.append(time.perf_counter() - t0)
-    t0 = time.perf_counter(); ob.chain_fpv(P, t, 0.15); sw = time.perf_counter() - t0
-    rows.append((n, tot_sub, tot_trip, min(h) * 1e3, sw * 1e3))
-R = np.array(rows, dtype=np.float64)
-A = np.stack((R[:, 0], R[:, 1], np.ones(len(R))), 1)
-(k1, k2, c_hw), *_ = np.linalg.lstsq(A, R[:, 3], rcond=None)
-B = np.stack((R[:, 2], np.ones(len(R))), 1)
-(k_sw, c_sw), *_ = np.linalg.lstsq(B, R[:, 4], rcond=None)
-r2 = lambda y, yh: 1 - ((y - yh) ** 2).sum() / ((y - y.mean()) ** 2).sum()
-print(f"tasks {len(R)}, n {R[:,0].min():.0f}..{R[:,0].max():.0f}, hw_ms {R[:,3].min():.3f}..{R[:,3].max():.3f}, sw_ms {R[:,4].min():.3f}..{R[:,4].max():.3f}")
-print(f"#define MI355X_ONT_K1_HW {k1:.10g}\n#define MI355X_ONT_K2_HW {k2:.10g}\n#define MI355X_ONT_C_HW {c_hw:.10g}   // R^2 {r2(R[:,3], A @ [k1,k2,c_hw]):.3f}")
-print(f"#define MI355X_ONT_K_SW {k_sw:.10g}\n#define MI355X_ONT_C_SW {c_sw:.10g}   // R^2 {r2(R[:,4], B @ [k_sw,c_sw]):.3f}")
-gpu_wins = (A @ [k1, k2, c_hw]) < (B @ [k_sw, c_sw])
-print(f"model sends {gpu_wins.mean()*100:.0f} % of these single-call tasks to the GPU; measured GPU faster in {(R[:,3] < R[:,4]).mean()*100:.0f} %")
-print("reference constants (VU9P, chain_hardware.h:19-23): K1_HW 2.992e-4, K2_HW 1.215e-5, C_HW 0.319, K_SW 5.234e-6, C_SW -1.0015")
+import mm2chain  # noqa: E402
+from mm2chain import params, synth  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+
+
+def real_like_tasks(n_reads, work="/tmp/splitfit"):
+    """anchor lists that reach mm_chain_dp for simulated ONT reads (reference host objects, CPU chaining)"""
+    os.makedirs(work, exist_ok=True)
+    host = os.path.join(ROOT, "oracle/_ref/mm2_refhost")
+    if not os.path.exists(host):
+        return []
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools/make_synth_genome.py"), work + "/syn", "--genome-mb", "30", "--reads", str(n_reads)],
+                          stdout=subprocess.DEVNULL)
+    dump = work + "/dump.bin"
+    if os.path.exists(dump):
+        os.unlink(dump)
+    subprocess.check_call([host, work + "/syn.ref.fa", work + "/syn.reads.fa"], env=dict(os.environ, MM2O_DUMP=dump), stdout=subprocess.DEVNULL)
+    raw = open(dump, "rb").read(); pos = 0; tasks = []
+    while pos < len(raw):
+        n, = struct.unpack_from("<q", raw, pos); pos += 8 + 40
+        tasks.append(np.frombuffer(raw, dtype=np.uint64, count=2 * n, offset=pos).reshape(n, 2).copy()); pos += 16 * n
+    return tasks
+
+
+def synthetic_tasks(rng, count, q_span, scale=1.0):
+    out = []
+    for prof in ("mixed", "dense", "colinear", "sparse"):
+        for n in rng.integers(60, int(9000 * scale), count):
+            out.append(synth.make_stream(prof, 1, int(n), seed=int(rng.integers(1 << 30)), q_span=q_span)[1].numpy().view(np.uint64))
+    return out
+
+
+def measure(P, tasks, avg):
+    rows = []
+    for t in tasks[:10]:
+        mm2chain.chain_task(P, t, avg)
+    for t in tasks:
+        _, tot_sub, tot_trip = ob.predict(t, P.max_dist_x)
+        h = []
+        for _ in range(3):
+            t0 = time.perf_counter(); mm2chain.chain_task(P, t, avg); h.append(time.perf_counter() - t0)
+        s = []
+        for _ in range(2):
+            t0 = time.perf_counter(); ob.chain_fpv(P, t, avg); s.append(time.perf_counter() - t0)
+        rows.append((t.shape[0], tot_sub, tot_trip, min(h) * 1e3, min(s) * 1e3))
+    return np.array(rows, dtype=np.float64)
+
+
+def fit(R):
+    tr, ho = R[0::2], R[1::2]
+    # the per-call cost (PCIe round trip, launches, synchronisation) is what the smallest tasks take; n and total_subparts are collinear, so
+    # the intercept is taken from them directly and the two slopes from a non-negative least-squares fit of the rest of the cost
+    small = tr[tr[:, 0] <= np.percentile(tr[:, 0], 15)]
+    c_hw = float(np.percentile(small[:, 3], 20))
+    A = np.stack((tr[:, 0], tr[:, 1]), 1)
+    (k1, k2), _ = nnls(A, np.maximum(tr[:, 3] - c_hw, 0))
+    small = tr[tr[:, 2] <= np.percentile(tr[:, 2], 15)]
+    c_sw = float(np.percentile(small[:, 4], 20))
+    (k_sw,), _ = nnls(tr[:, 2][:, None], np.maximum(tr[:, 4] - c_sw, 0))
+    return dict(K1_HW=float(k1), K2_HW=float(k2), C_HW=float(c_hw), K_SW=float(k_sw), C_SW=float(c_sw)), tr, ho
+
+
+def score(c, R):
+    hw = c["K1_HW"] * R[:, 0] + c["K2_HW"] * R[:, 1] + c["C_HW"]
+    sw = c["K_SW"] * R[:, 2] + c["C_SW"]
+    return float(((hw < sw) == (R[:, 3] < R[:, 4])).mean()), float((hw < sw).mean()), float((R[:, 3] < R[:, 4]).mean())
+
+
+def r2(y, yh):
+    return float(1 - ((y - yh) ** 2).sum() / ((y - y.mean()) ** 2).sum())
+
+
+if __name__ == "__main__":
+    mm2chain.init()
+    rng = np.random.default_rng(1)
+    P = params.map_ont()
+    out, md = {}, ["# HW/SW split model re-fit for MI355X (SURVEY §8 f4) — `tools/fit_split_model.py`", "",
+                   "Model of the reference (`chain.c:80-81,101`, constants `chain_hardware.h:19-30`): `hw_ms = K1_HW n + K2_HW total_subparts + C_HW`,",
+                   "`sw_ms = K_SW total_trip_count + C_SW`; a task goes to the device when `hw_ms < sw_ms`.  hw = one synchronous `mm2c_chain_task_host` call,",
+                   "sw = the CPU port on one host core of the GPU box.  Non-negative least squares on every second task, the rest is the hold-out.", ""]
+    for preset, q_span, avg, scale in (("ONT", 15, 0.15, 1.0), ("PBCCS", 19, 0.19, 1.5)):
+        tasks = synthetic_tasks(rng, 45, q_span, scale)
+        if preset == "ONT":
+            tasks = real_like_tasks(400) + tasks
+        order = rng.permutation(len(tasks))
+        R = measure(P, [tasks[i] for i in order], avg)
+        c, tr, ho = fit(R)
+        acc_ho, frac_model, frac_meas = score(c, ho)
+        acc_tr, _, _ = score(c, tr)
+        hw_hat = c["K1_HW"] * ho[:, 0] + c["K2_HW"] * ho[:, 1] + c["C_HW"]
+        sw_hat = c["K_SW"] * ho[:, 2] + c["C_SW"]
+        out[preset] = dict(c, tasks=int(len(R)), n_min=int(R[:, 0].min()), n_max=int(R[:, 0].max()), holdout_tasks=int(len(ho)),
+                           holdout_decision_accuracy=acc_ho, train_decision_accuracy=acc_tr, model_sends_to_gpu=frac_model,
+                           measured_gpu_faster=frac_meas, r2_hw_holdout=r2(ho[:, 3], hw_hat), r2_sw_holdout=r2(ho[:, 4], sw_hat))
+        md += [f"## {preset} (span {q_span}): {len(R)} tasks, n = {int(R[:,0].min())}…{int(R[:,0].max())}", "", "```"]
+        md += [f"#define MI355X_{preset}_{k} {v:.10g}" for k, v in c.items()]
+        md += ["```", f"hold-out ({len(ho)} tasks): decision equals the measured faster side on **{acc_ho*100:.0f} %** (training half {acc_tr*100:.0f} %); the model sends "
+               f"{frac_model*100:.0f} % of the tasks to the GPU, the GPU was faster on {frac_meas*100:.0f} %; R² hw {out[preset]['r2_hw_holdout']:.3f}, sw {out[preset]['r2_sw_holdout']:.3f}", ""]
+    md += ["Reference constants (VU9P / F1 host, `chain_hardware.h:19-30`): ONT K1_HW 2.992e-4, K2_HW 1.215e-5, C_HW 0.319, K_SW 5.234e-6, C_SW -1.0015.", ""]
+    hdr = ["/* mm2chain_split.h -- HW/SW split parameters for MI355X, in the form of the reference's chain_hardware.h:19-30 (ONT_* / PBCCS_*),",
+           " * for a host that keeps chain.c:80-81,101: set K1_HW..C_SW (options.c:6,95-99,118-122) from these, or ask mm2c_split_model().",
+           " * hw = one synchronous per-read call into the library (PCIe + launch + DP on a lone wave), sw = chain.c's loop on one host core.",
+           " * GENERATED by tools/fit_split_model.py on the MI355X box (non-negative least squares; hold-out accuracy in profiles/r2_split_model.md). */",
+           "#ifndef MM2CHAIN_SPLIT_H", "#define MM2CHAIN_SPLIT_H", ""]
+    for preset in ("ONT", "PBCCS"):
+        hdr += [f"// Parameters used for HW/SW split ({'ONT' if preset == 'ONT' else 'PacBio CCS'}), MI355X"]
+        hdr += [f"#define MI355X_{preset}_{k} {out[preset][k]:.10g}" for k in ("K1_HW", "K2_HW", "C_HW", "K_SW", "C_SW")] + [""]
+    hdr += ["#endif"]
+    open(os.path.join(ROOT, "include", "mm2chain_split.h"), "w").write("\n".join(hdr) + "\n")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    for d in ("profiles", "gpurun_out"):
+        open(os.path.join(ROOT, d, "r2_split_model.md"), "w").write("\n".join(md) + "\n")
+        json.dump(out, open(os.path.join(ROOT, d, "r2_split_model.json"), "w"), indent=1)
+    # the header is written inside the repo copy on the GPU box: leave a copy where gpurun collects files
+    open(os.path.join(ROOT, "gpurun_out", "mm2chain_split.h"), "w").write("\n".join(hdr) + "\n")
+    print("\n".join(md))
+    mm2chain.shutdown()
