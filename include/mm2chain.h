@@ -111,6 +111,11 @@ int64_t mm2c_plan_total_anchors(const mm2c_plan_t *plan);
 int mm2c_plan_run_device(mm2c_plan_t *plan, const void *d_anchors, const float *d_avg_qspan,
                          int32_t *d_f, int32_t *d_p, void *stream);
 
+/* Task sizes that only the device knows (anchors made by mm2c_seedplan_run_device_skip): from now on the plan's kernels take the CSR
+ * offsets from d_offsets (n_tasks + 1 entries, device memory, offsets[0] = 0, every task no longer than the plan was created for);
+ * NULL goes back to the plan's own.  The buffers handed to the run / chains entries keep the plan's (capacity) extents. */
+int mm2c_plan_set_device_offsets(mm2c_plan_t *plan, const int64_t *d_offsets);
+
 /* The same with the extent of every buffer stated (elements, not bytes): MM2C_E_TOOBIG when one is shorter than the plan needs, the way
  * the reference refuses n > BUFFER_N (chain_hardware.cpp:34-37).  The entries without _n trust the caller. */
 int mm2c_plan_run_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_anchors, const float *d_avg_qspan, int64_t n_avg,
@@ -193,7 +198,8 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
  * are hits[cr_off .. cr_off + n) of a hit pool (the arrays mm_idx_get returns: rid<<32 | pos<<1 | strand).  The anchors of read r are
  * written to anchors[anchor_off[r] .. anchor_off[r+1]) exactly as collect_seed_hits leaves them for mm_chain_dp (encoding map.c:232-241,
  * order of radix_sort_128x including its order among equal x), ready for mm2c_plan_run_device with the same offsets.
- * Covers the flag-free case (no MM_F_NO_DIAG / NO_DUAL / FOR_ONLY / REV_ONLY, skip_seed map.c:122-147), which is map-ont. */
+ * mm2c_seedplan_run_device(_n) covers the flag-free case (no MM_F_NO_DIAG / NO_DUAL / FOR_ONLY / REV_ONLY), which is map-ont;
+ * mm2c_seedplan_run_device_skip adds skip_seed (map.c:122-147) for ava-ont and the strand-restricted modes. */
 typedef struct {
 	int64_t cr_off;
 	uint32_t n;          /* mm_match_t.n */
@@ -212,6 +218,22 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *plan, const mm2c_match_t *d_matche
  * mm2c_seedplan_check (its read is not expanded) */
 int mm2c_seedplan_run_device_n(mm2c_seedplan_t *plan, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
                                const int32_t *d_qlen, int64_t n_qlen, void *d_anchors, int64_t n_anchors, void *stream);
+/* With skip_seed (map.c:122-147): all-vs-all and strand-restricted modes drop hits, so a read keeps FEWER anchors than its matches have hits.
+ * flag: MM_F_NO_DIAG 0x001 | MM_F_NO_DUAL 0x002 | MM_F_FOR_ONLY 0x100000 | MM_F_REV_ONLY 0x200000 (minimap.h:8-9,28-29; -x ava-ont sets the
+ * first two, options.c:84).  The name comparison strcmp(qname, name[rid]) of map.c:128 travels as ranks: d_ref_rank[rid] = rank of the
+ * reference sequence's name among the DISTINCT reference names in strcmp order, d_ref_len[rid] = its length (mm_idx_seq_t.len), and per read
+ * d_q_lo = number of those names below the read's name, d_q_eq = 1 when the read's name is one of them (cmp > 0 <=> rank < q_lo,
+ * cmp == 0 <=> q_eq && rank == q_lo); d_ref_rank == NULL stands for qname == NULL (map.c:125).  All arrays are device memory.
+ * The plan's anchor offsets are then capacities; the anchors of read r are written packed to d_anchors[off[r] .. off[r+1]) with
+ * off = d_anchor_off_out (n_reads + 1 entries, device) -- hand it to mm2c_plan_set_device_offsets to chain them.  MM_SEED_SELF (map.c:241) is set. */
+typedef struct {
+	int32_t flag;
+	const int32_t *d_ref_rank, *d_ref_len;   /* per reference sequence */
+	const int32_t *d_q_lo, *d_q_eq;          /* per read */
+} mm2c_seed_skip_t;
+int mm2c_seedplan_run_device_skip(mm2c_seedplan_t *plan, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
+                                  const int32_t *d_qlen, int64_t n_qlen, const mm2c_seed_skip_t *skip, void *d_anchors, int64_t n_anchors,
+                                  int64_t *d_anchor_off_out, void *stream);
 int mm2c_seedplan_check(mm2c_seedplan_t *plan, int64_t *n_reads_with_ties);   /* waits; MM2C_E_ARG if a read's counts disagreed */
 int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
 /* host buffers in, anchors out (computes the anchor offsets itself): anchor_off[n_reads+1], anchors with room for the sum of all n */

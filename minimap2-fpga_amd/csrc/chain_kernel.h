@@ -90,6 +90,12 @@ struct SeedArgs {
 	const Match *d_matches;
 	const uint64_t *d_hits;                      // the hit pool the matches point into
 	int64_t n_hits = 0;                          // its length when the caller declared it (0: matches are trusted)
+	// skip_seed (map.c:122-147): flag = MM_F_NO_DIAG 0x1 | MM_F_NO_DUAL 0x2 | MM_F_FOR_ONLY 0x100000 | MM_F_REV_ONLY 0x200000 (0: every hit is kept);
+	// names as ranks: per reference sequence the rank of its name and its length, per read q_lo / q_eq (include/mm2chain.h)
+	int32_t skip_flag = 0;
+	const int32_t *d_ref_rank = nullptr, *d_ref_len = nullptr, *d_q_lo = nullptr, *d_q_eq = nullptr;
+	int32_t *d_count = nullptr;                  // per read: anchors kept (nullptr: all, the plan's offsets are exact)
+	int64_t *d_out_off = nullptr;                // n_reads + 1: where the packed result of each read starts (written by seed_offsets)
 	const int32_t *d_qlen;
 	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
 	ulonglong2 *d_anchors;                       // out

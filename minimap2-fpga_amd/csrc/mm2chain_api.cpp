@@ -270,6 +270,7 @@ using namespace mm2c_api;
 struct mm2c_plan {
 	mm2c_params_t par;
 	int device = 0;                         // the device the plan's workspace lives on
+	const int64_t *d_off_user = nullptr;    // mm2c_plan_set_device_offsets: task sizes that only the device knows
 	int64_t n_tasks = 0, total = 0;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
@@ -506,6 +507,13 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 
 int64_t mm2c_plan_total_anchors(const mm2c_plan_t *pl) { return pl ? pl->total : 0; }
 
+int mm2c_plan_set_device_offsets(mm2c_plan_t *pl, const int64_t *d_offsets)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	pl->d_off_user = d_offsets;
+	return 0;
+}
+
 int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_avg_qspan, int32_t *d_f, int32_t *d_p, void *stream)
 {
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
@@ -516,7 +524,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
-	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off; L.d_order = pl->d_order;
+	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off_user ? pl->d_off_user : pl->d_off; L.d_order = pl->d_order;
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.d_avg_ws = pl->d_avg_ws;
 	L.ring_class = G.ring_class;
@@ -564,7 +572,7 @@ int mm2c_plan_predict_device(mm2c_plan_t *pl, const void *d_anchors, uint8_t *d_
 	if (pl->n_tasks == 0) return 0;
 	if (!d_anchors && pl->total > 0) return fail(MM2C_E_ARG, "device pointer is NULL");
 	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
-	HIP_TRY(mm2c::launch_predict(pl->par.max_dist_x, pl->n_tasks, pl->d_off, pl->d_order, d_anchors, d_num_subparts,
+	HIP_TRY(mm2c::launch_predict(pl->par.max_dist_x, pl->n_tasks, pl->d_off_user ? pl->d_off_user : pl->d_off, pl->d_order, d_anchors, d_num_subparts,
 	                             d_total_subparts, d_total_trip_count, st));
 	G.launches += 1;
 	return 0;
@@ -624,7 +632,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 		HIP_TRY(hipEventCreate(&pl->ev_e0));
 		HIP_TRY(hipEventCreate(&pl->ev_e1));
 	}
-	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off; E.d_order = pl->d_order;
+	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off_user ? pl->d_off_user : pl->d_off; E.d_order = pl->d_order;
 	E.d_a = (const ulonglong2 *)d_anchors; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
 	E.debug_phases = epilogue_debug_phases();
 	E.u_off = d_u_off; E.b_off = d_b_off; E.u_out = d_u; E.b_out = (ulonglong2 *)d_b;

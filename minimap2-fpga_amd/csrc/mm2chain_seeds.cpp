@@ -7,6 +7,8 @@ using namespace mm2c_api;
 struct mm2c_seedplan {
 	int64_t n_reads = 0, total = 0, n_matches = 0;
 	int device = 0;
+	int32_t *d_cnt = nullptr; int64_t *d_oo = nullptr;   // per-read anchor counts / packed offsets of runs with skip_seed
+	const mm2c_seed_skip_t *skip = nullptr;                // set by mm2c_seedplan_run_device_skip for the run it starts
 	int64_t n_hits_declared = 0;           // set by mm2c_seedplan_run_device_n for the run it starts
 	char *d_mem = nullptr;                 // [match_off | anchor_off | order | status | has_ties | stack | unsorted | scratch | big_id | big_dg]
 	mm2c::SeedArgs S;
@@ -39,7 +41,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
 	             o_stack = take(4 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
-	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1);
+	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
 	pl->device = cur_device();
 	hipError_t e = hipSetDevice(pl->device);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_mem, at);
@@ -69,6 +71,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	S.tiecnt = (int32_t *)(b + o_tc); S.xdiff = (uint64_t *)(b + o_xd); S.biggest = biggest;
 	S.stack = (int32_t *)(b + o_stack); S.unsorted = (ulonglong2 *)(b + o_un); S.scratch = (ulonglong2 *)(b + o_scr);
 	S.big_id = big ? (uint32_t *)(b + o_bid) : nullptr; S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
+	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);
 	return pl;
 }
 
@@ -96,6 +99,11 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	mm2c::SeedArgs &S = pl->S;
 	S.d_matches = (const mm2c::Match *)d_matches; S.d_hits = d_hits; S.d_qlen = d_qlen; S.d_anchors = (ulonglong2 *)d_anchors;
 	S.n_hits = pl->n_hits_declared; pl->n_hits_declared = 0;
+	if (pl->skip) {
+		S.skip_flag = pl->skip->flag; S.d_ref_rank = pl->skip->d_ref_rank; S.d_ref_len = pl->skip->d_ref_len; S.d_q_lo = pl->skip->d_q_lo; S.d_q_eq = pl->skip->d_q_eq;
+		S.d_count = pl->d_cnt; S.d_out_off = pl->d_oo;
+		pl->skip = nullptr;
+	} else { S.skip_flag = 0; S.d_ref_rank = S.d_ref_len = S.d_q_lo = S.d_q_eq = nullptr; S.d_count = nullptr; S.d_out_off = nullptr; }
 	HIP_TRY(hipMemsetAsync(S.status, 0, (size_t)pl->n_reads * 4, st));
 	HIP_TRY(hipMemsetAsync(S.has_ties, 0, (size_t)pl->n_reads * 4, st));
 	HIP_TRY(hipEventRecord(pl->ev0, st));
@@ -117,6 +125,23 @@ int mm2c_seedplan_run_device_n(mm2c_seedplan_t *pl, const mm2c_match_t *d_matche
 	if (pl->total > 0 && n_hits == 0) return fail(MM2C_E_TOOBIG, "the hit pool is empty but the plan expands %lld hits", (long long)pl->total);
 	pl->n_hits_declared = n_hits;                  // checked per match on the device (mm2c_seedplan_check reports it)
 	return mm2c_seedplan_run_device(pl, d_matches, d_hits, d_qlen, d_anchors, stream);
+}
+
+int mm2c_seedplan_run_device_skip(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
+                                  const int32_t *d_qlen, int64_t n_qlen, const mm2c_seed_skip_t *skip, void *d_anchors, int64_t n_anchors,
+                                  int64_t *d_anchor_off_out, void *stream)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	if (!skip || !d_anchor_off_out) return fail(MM2C_E_ARG, "skip description / offset output is NULL");
+	if ((skip->flag & (0x001 | 0x002)) && skip->d_ref_rank && (!skip->d_ref_len || !skip->d_q_lo || !skip->d_q_eq))
+		return fail(MM2C_E_ARG, "NO_DIAG / NO_DUAL need ref_rank, ref_len, q_lo and q_eq");
+	pl->skip = skip;
+	int rc = mm2c_seedplan_run_device_n(pl, d_matches, n_matches, d_hits, n_hits, d_qlen, n_qlen, d_anchors, n_anchors, stream);
+	pl->skip = nullptr;
+	if (rc != 0 || pl->n_reads == 0) return rc;
+	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;
+	HIP_TRY(hipMemcpyAsync(d_anchor_off_out, pl->d_oo, ((size_t)pl->n_reads + 1) * 8, hipMemcpyDeviceToDevice, st));
+	return 0;
 }
 
 int mm2c_seedplan_check(mm2c_seedplan_t *pl, int64_t *n_reads_with_ties)

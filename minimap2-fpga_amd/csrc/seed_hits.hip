@@ -38,6 +38,18 @@ __device__ __forceinline__ uint64_t wave_or(uint64_t v)
 	return v;
 }
 
+// where a read's anchors are: the plan's offsets give the CAPACITY of a read (every hit kept); with skip_seed (map.c:122-147) a read keeps
+// cnt[read] <= capacity anchors, the work arrays (unsorted, scratch, tiecnt) stay laid out by capacity and the result is packed by out_off
+struct ReadGeom { int64_t a0, o0; int na; };
+__device__ __forceinline__ ReadGeom read_geom(const SeedArgs &A, int read)
+{
+	ReadGeom g;
+	g.a0 = A.d_anchor_off[read];
+	g.na = A.d_count ? A.d_count[read] : (int)(A.d_anchor_off[read + 1] - g.a0);
+	g.o0 = A.d_out_off ? A.d_out_off[read] : g.a0;
+	return g;
+}
+
 // ---- kernel 1: expansion (map.c:222-243) ----------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 {
@@ -51,14 +63,15 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 	const int qlen = A.d_qlen[read];
 	const Match *m = A.d_matches + m0;
 	ulonglong2 *out = A.unsorted + a0;
-	int run = 0;                                                                // anchors written so far (wave uniform)
+	int run = 0, hits_seen = 0;                                                 // anchors written / hits looked at so far (wave uniform)
+	const int q_lo = A.d_q_lo ? A.d_q_lo[read] : 0, q_eq = A.d_q_eq ? A.d_q_eq[read] : 0;
 	uint64_t x_or = 0, x_and = ~0ull;                                           // -> the bits of x that are not the same in every anchor of the read
 	for (int c0 = 0; c0 < nm; c0 += 64) {
 		const int i = c0 + lane;
 		Match q = {};
 		if (i < nm) q = m[i];
 		if (A.n_hits > 0 && __ballot(i < nm && (q.cr_off < 0 || q.cr_off + (int64_t)q.n > A.n_hits))) {
-			if (lane == 0) A.status[read] = 2;                                   // a match reaches beyond the hit pool the caller declared
+			if (lane == 0) { A.status[read] = 2; if (A.d_count) A.d_count[read] = 0; }   // a match reaches beyond the hit pool the caller declared
 			return;
 		}
 		const int incl = wave_incl_scan((int)q.n, lane);
@@ -67,31 +80,72 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 		s_start[lane] = incl - (int)q.n; s_cr[lane] = q.cr_off; s_qpos[lane] = q.q_pos; s_span[lane] = q.q_span; s_segt[lane] = q.seg_tandem;
 		if (lane == 63) s_start[64] = total;
 		__syncthreads();
-		if (run + total > na) { if (lane == 0) A.status[read] = 1; return; }    // the caller's anchor offsets do not match the hit counts
-		for (int t = lane; t < total; t += 64) {
-			int lo = 0, hi = 63;                                                // last match of the chunk with start <= t
-			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid - 1; }
-			const uint64_t r = A.d_hits[s_cr[lo] + (t - s_start[lo])];
-			const uint32_t q_pos = s_qpos[lo], q_span = s_span[lo], segt = s_segt[lo];
-			const uint32_t rpos = (uint32_t)r >> 1;
-			ulonglong2 a;
-			if ((r & 1) == (q_pos & 1)) {                                       // forward strand, map.c:232-234
-				a.x = (r & 0xffffffff00000000ULL) | rpos;
-				a.y = (uint64_t)q_span << 32 | q_pos >> 1;
-			} else {                                                            // reverse strand, map.c:235-238
-				a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-				a.y = (uint64_t)q_span << 32 | (uint32_t)((uint32_t)qlen - ((q_pos >> 1) + 1 - q_span) - 1);
+		if (hits_seen + total > na) { if (lane == 0) { A.status[read] = 1; if (A.d_count) A.d_count[read] = 0; } return; }   // the caller's anchor offsets do not match the hit counts
+		for (int t0 = 0; t0 < total; t0 += 64) {
+			const int t = t0 + lane;
+			bool keep = t < total;
+			ulonglong2 a = {0, 0};
+			if (keep) {
+				int lo = 0, hi = 63;                                            // last match of the chunk with start <= t
+				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid - 1; }
+				const uint64_t r = A.d_hits[s_cr[lo] + (t - s_start[lo])];
+				const uint32_t q_pos = s_qpos[lo], q_span = s_span[lo], segt = s_segt[lo];
+				const uint32_t rpos = (uint32_t)r >> 1;
+				const bool fwd = (r & 1) == (q_pos & 1);
+				bool is_self = false;
+				if (A.skip_flag) {                                              // skip_seed, map.c:122-147 (names as ranks, see mm2chain.h)
+					if (A.d_ref_rank && (A.skip_flag & (0x001 | 0x002))) {
+						const int rid = (int)(r >> 32);
+						const int rr = A.d_ref_rank[rid];
+						const int cmp = rr < q_lo ? 1 : (q_eq && rr == q_lo) ? 0 : -1;
+						if ((A.skip_flag & 0x001) && cmp == 0 && A.d_ref_len[rid] == qlen) {   // MM_F_NO_DIAG
+							if (rpos == (q_pos >> 1)) keep = false;                 // the diagonal
+							if (fwd) is_self = true;
+						}
+						if ((A.skip_flag & 0x002) && cmp > 0) keep = false;         // MM_F_NO_DUAL: every pair once
+					}
+					if (fwd ? (A.skip_flag & 0x200000) : (A.skip_flag & 0x100000)) keep = false;   // MM_F_REV_ONLY / MM_F_FOR_ONLY
+				}
+				if (fwd) {                                                      // forward strand, map.c:232-234
+					a.x = (r & 0xffffffff00000000ULL) | rpos;
+					a.y = (uint64_t)q_span << 32 | q_pos >> 1;
+				} else {                                                        // reverse strand, map.c:235-238
+					a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+					a.y = (uint64_t)q_span << 32 | (uint32_t)((uint32_t)qlen - ((q_pos >> 1) + 1 - q_span) - 1);
+				}
+				a.y |= (uint64_t)(segt >> 1) << 48;                             // MM_SEED_SEG_SHIFT, map.c:239
+				if (segt & 1) a.y |= 1ULL << 42;                                // MM_SEED_TANDEM, map.c:240
+				if (is_self) a.y |= 1ULL << 43;                                 // MM_SEED_SELF, map.c:241
 			}
-			a.y |= (uint64_t)(segt >> 1) << 48;                                 // MM_SEED_SEG_SHIFT, map.c:239
-			if (segt & 1) a.y |= 1ULL << 42;                                    // MM_SEED_TANDEM, map.c:240
-			out[run + t] = a;
-			x_or |= a.x; x_and &= a.x;
+			const uint64_t km = __ballot(keep);                                 // kept hits stay in hit order (the order collect_seed_hits fills a[])
+			if (keep) {
+				out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0))] = a;
+				x_or |= a.x; x_and &= a.x;
+			}
+			run += (int)__builtin_popcountll(km);
 		}
-		run += total;
+		hits_seen += total;
 	}
-	if (run != na && lane == 0) A.status[read] = 1;
+	if (A.d_count) { if (lane == 0) A.d_count[read] = run; }
+	else if (run != na && lane == 0) A.status[read] = 1;
 	x_or = wave_or(x_or); x_and = ~wave_or(~x_and);
-	if (lane == 0) A.xdiff[read] = na > 0 ? x_or ^ x_and : 0;
+	if (lane == 0) A.xdiff[read] = run > 0 ? x_or ^ x_and : 0;
+}
+
+// ---- packed offsets of the result: exclusive prefix sums of the per-read counts (one block of 1024 threads) ----------------
+__global__ __launch_bounds__(1024) void seed_offsets(SeedArgs A)
+{
+	__shared__ int64_t s_part[1024];
+	const int tid = (int)threadIdx.x;
+	const int64_t per = (A.n_reads + 1023) / 1024, r0 = tid * per, r1 = r0 + per < A.n_reads ? r0 + per : A.n_reads;
+	int64_t sum = 0;
+	for (int64_t r = r0; r < r1; ++r) sum += A.d_count[r];
+	s_part[tid] = sum;
+	__syncthreads();
+	if (tid == 0) { int64_t at = 0; for (int k = 0; k < 1024; ++k) { const int64_t v = s_part[k]; s_part[k] = at; at += v; } A.d_out_off[A.n_reads] = at; }
+	__syncthreads();
+	int64_t at = s_part[tid];
+	for (int64_t r = r0; r < r1; ++r) { A.d_out_off[r] = at; at += A.d_count[r]; }
 }
 
 // ---- stable LSD radix sort of one read's anchors on x by one wave; the result ends in `dst` ------------------------
@@ -228,12 +282,13 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	__shared__ int s_cnt[256], s_hist[4 * 256];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int lane = (int)threadIdx.x;
-	const int64_t a0 = A.d_anchor_off[read];
-	const int na = (int)(A.d_anchor_off[read + 1] - a0);
+	const ReadGeom g = read_geom(A, read);
+	const int64_t a0 = g.a0;
+	const int na = g.na;
 	if (A.status[read] != 0 || na == 0) { if (lane == 0) A.has_ties[read] = 0; return; }
 	// the unsorted array must survive (the replay of kernel 3 starts from it): it is only read
 	const ulonglong2 *un = A.unsorted + a0;
-	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + a0;
+	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
 	int32_t *tiecnt = A.tiecnt + a0;
 	const uint64_t diff = A.xdiff[read];
 	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
@@ -293,10 +348,11 @@ __global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
 	const int lane = (int)threadIdx.x;
-	const int64_t a0 = A.d_anchor_off[read];
-	const int na = (int)(A.d_anchor_off[read + 1] - a0);
+	const ReadGeom g = read_geom(A, read);
+	const int64_t a0 = g.a0;
+	const int na = g.na;
 	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
-	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
+	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
 	int32_t *stack = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice (room for two such lists)
 	if (CAP) {
 		replay_passes<uint16_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
@@ -376,10 +432,11 @@ __global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
 	const int tid = (int)threadIdx.x;
-	const int64_t a0 = A.d_anchor_off[read];
-	const int na = (int)(A.d_anchor_off[read + 1] - a0);
+	const ReadGeom g = read_geom(A, read);
+	const int64_t a0 = g.a0;
+	const int na = g.na;
 	if (na <= TIE_MW_LO || na > TIE_MW_HI) return;
-	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + a0;
+	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
 	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);
 	replay_levels<uint16_t, true, TIE_MW_WAVES>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, lists, lists + 2 * (na / 64 + 2),
 	                                             (int32_t *)tmp, tid, s_cur, s_lo, s_hi, s_n);
@@ -421,6 +478,11 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	hipError_t e;
 	hipLaunchKernelGGL(seed_expand, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
+	if (A.d_count) {                                                             // skip_seed in force: the reads keep fewer anchors than they have hits
+		hipLaunchKernelGGL(seed_offsets, dim3(1), dim3(1024), 0, st, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (n_launches) ++*n_launches;
+	}
 	hipLaunchKernelGGL(seed_sort, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (n_launches) *n_launches += 2;

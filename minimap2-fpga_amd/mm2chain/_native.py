@@ -44,6 +44,7 @@ C_SYMBOLS = {
     "mm2c_plan_destroy": (None, [C.c_void_p]),
     "mm2c_plan_total_anchors": (C.c_int64, [C.c_void_p]),
     "mm2c_plan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_plan_set_device_offsets": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mm2c_plan_run_device_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "mm2c_plan_predict_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -68,6 +69,8 @@ C_SYMBOLS = {
     "mm2c_seedplan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_seedplan_run_device_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                              C.c_void_p]),
+    "mm2c_seedplan_run_device_skip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_seedplan_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mm2c_seedplan_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -105,6 +108,11 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+class SeedSkip(C.Structure):
+    """mm2c_seed_skip_t"""
+    _fields_ = [("flag", C.c_int32), ("d_ref_rank", C.c_void_p), ("d_ref_len", C.c_void_p), ("d_q_lo", C.c_void_p), ("d_q_eq", C.c_void_p)]
 
 
 class Mm2cError(RuntimeError):

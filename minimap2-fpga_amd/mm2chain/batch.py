@@ -105,6 +105,14 @@ class ChainPlan:
                                                 avg.numel() if avg is not None else 0, f.data_ptr(), f.numel(), p.data_ptr(), p.numel(), st),
                 "mm2c_plan_run_device_n")
 
+    def set_device_offsets(self, offsets: torch.Tensor = None):
+        """task sizes that only the device knows (SeedPlan.run_skip): the kernels take the CSR offsets from this int64 device tensor
+        [n_tasks + 1]; None goes back to the plan's own.  The tensor must stay alive while the plan uses it."""
+        if offsets is not None:
+            assert offsets.is_cuda and offsets.dtype == torch.int64 and offsets.numel() == self.n_tasks + 1 and offsets.is_contiguous()
+        self._dev_off = offsets
+        N.check(self.lib.mm2c_plan_set_device_offsets(self.handle, offsets.data_ptr() if offsets is not None else None), "mm2c_plan_set_device_offsets")
+
     def predict(self, anchors: torch.Tensor, stream=None):
         """chain.c:53-78 on the GPU: returns (num_subparts uint8 [total], total_subparts int64 [n_tasks],
         total_trip_count int64 [n_tasks]) as device tensors"""
@@ -292,6 +300,24 @@ class SeedPlan:
                                                     hits.numel(), qlen.data_ptr(), qlen.numel(), anchors.data_ptr(), anchors.numel() // 2, st),
                 "mm2c_seedplan_run_device_n")
         return anchors
+
+    def run_skip(self, matches, hits, qlen, flag, ref_rank, ref_len, q_lo, q_eq, anchors=None, stream=None):
+        """collect_seed_hits with skip_seed (map.c:122-147; -x ava-ont: flag = NO_DIAG | NO_DUAL): the reads keep fewer anchors than they have
+        hits.  ref_rank / ref_len: int32 per reference sequence, q_lo / q_eq: int32 per read (device tensors; names as ranks, mm2chain.h).
+        Returns (anchors int64 [capacity, 2] packed, offsets int64 [n_reads + 1] on the device)."""
+        assert matches.is_cuda and hits.is_cuda and qlen.is_cuda and qlen.dtype == torch.int32 and qlen.numel() == self.n_reads
+        for t in (ref_rank, ref_len, q_lo, q_eq):
+            assert t is None or (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous())
+        if anchors is None:
+            anchors = torch.empty((max(self.total, 1), 2), dtype=torch.int64, device=hits.device)
+        off = torch.empty(self.n_reads + 1, dtype=torch.int64, device=hits.device)
+        sk = N.SeedSkip(int(flag), ref_rank.data_ptr() if ref_rank is not None else None, ref_len.data_ptr() if ref_len is not None else None,
+                        q_lo.data_ptr() if q_lo is not None else None, q_eq.data_ptr() if q_eq is not None else None)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        N.check(self.lib.mm2c_seedplan_run_device_skip(self.handle, matches.data_ptr(), matches.numel() * matches.element_size() // 24, hits.data_ptr(),
+                                                       hits.numel(), qlen.data_ptr(), qlen.numel(), C.byref(sk), anchors.data_ptr(),
+                                                       anchors.numel() // 2, off.data_ptr(), st), "mm2c_seedplan_run_device_skip")
+        return anchors, off
 
     def check(self):
         """waits for the run; raises if a read's hit counts did not add up to its anchor range; returns the number of reads with equal x"""

@@ -350,9 +350,38 @@ double mm2o_bench_batch(const mm2o_params_t *par, int64_t n_tasks, const int64_t
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
-/* map.c:215-247 (collect_seed_hits); skip_seed (map.c:122-147) always returns 0 when no NO_DIAG / NO_DUAL / FOR_ONLY / REV_ONLY
- * flag is set, which is the map-ont case restated here */
+/* skip_seed, map.c:122-147.  The name comparison strcmp(qname, name[rid]) is carried by ranks: ref_rank[rid] = rank of the reference
+ * sequence's name among the distinct reference names (strcmp order), q_lo = number of those names below the read's, q_eq = the read's
+ * name is one of them -- so cmp > 0 <=> ref_rank[rid] < q_lo and cmp == 0 <=> q_eq && ref_rank[rid] == q_lo.  ref_rank == NULL stands
+ * for qname == NULL (no name-dependent skipping, map.c:125). */
+static int skip_seed(int32_t flag, uint64_t r, const mm2o_match_t *q, int32_t qlen, const int32_t *ref_rank, const int32_t *ref_len,
+                     int32_t q_lo, int32_t q_eq, int *is_self)
+{
+	*is_self = 0;
+	if (ref_rank && (flag & (MM2O_F_NO_DIAG | MM2O_F_NO_DUAL))) {
+		const int32_t rr = ref_rank[r >> 32];
+		const int cmp = rr < q_lo ? 1 : (q_eq && rr == q_lo) ? 0 : -1;
+		if ((flag & MM2O_F_NO_DIAG) && cmp == 0 && ref_len[r >> 32] == qlen) {
+			if ((uint32_t)r >> 1 == (q->q_pos >> 1)) return 1;                    /* the diagonal, map.c:131 */
+			if ((r & 1) == (q->q_pos & 1)) *is_self = 1;                           /* map.c:132 */
+		}
+		if ((flag & MM2O_F_NO_DUAL) && cmp > 0) return 1;                        /* all-vs-all: map once, map.c:134-135 */
+	}
+	if (flag & (MM2O_F_FOR_ONLY | MM2O_F_REV_ONLY)) {                            /* map.c:137-143 */
+		if ((r & 1) == (q->q_pos & 1)) { if (flag & MM2O_F_REV_ONLY) return 1; }
+		else if (flag & MM2O_F_FOR_ONLY) return 1;
+	}
+	return 0;
+}
+
 int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, mm2o_anchor_t *a)
+{
+	return mm2o_collect_seed_hits_flags(n_m, m, hits, qlen, 0, 0, 0, 0, 0, a);
+}
+
+/* map.c:215-247 (collect_seed_hits) */
+int64_t mm2o_collect_seed_hits_flags(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, int32_t flag,
+                                     const int32_t *ref_rank, const int32_t *ref_len, int32_t q_lo, int32_t q_eq, mm2o_anchor_t *a)
 {
 	int64_t i, n_a = 0;
 	for (i = 0; i < n_m; ++i) {
@@ -361,7 +390,10 @@ int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_
 		uint32_t k;
 		for (k = 0; k < q->n; ++k) {
 			const int32_t rpos = (uint32_t)r[k] >> 1;
-			mm2o_anchor_t *p = &a[n_a++];
+			int is_self;
+			mm2o_anchor_t *p;
+			if (skip_seed(flag, r[k], q, qlen, ref_rank, ref_len, q_lo, q_eq, &is_self)) continue;
+			p = &a[n_a++];
 			if ((r[k] & 1) == (q->q_pos & 1)) {                                  /* forward strand, map.c:232-234 */
 				p->x = (r[k] & 0xffffffff00000000ULL) | (uint32_t)rpos;
 				p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
@@ -371,6 +403,7 @@ int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_
 			}
 			p->y |= (uint64_t)(q->seg_tandem >> 1) << 48;                        /* MM_SEED_SEG_SHIFT, map.c:239 */
 			if (q->seg_tandem & 1) p->y |= 1ULL << 42;                           /* MM_SEED_TANDEM, map.c:240 */
+			if (is_self) p->y |= 1ULL << 43;                                     /* MM_SEED_SELF, map.c:241, mmpriv.h:20 */
 		}
 	}
 	sort_128x(a, a + n_a);                                                       /* map.c:245 */

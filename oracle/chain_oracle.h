@@ -85,6 +85,15 @@ typedef struct {
  * map.c:232-241, then radix_sort_128x.  a needs room for the sum of n; returns the number of anchors. */
 int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, mm2o_anchor_t *a);
 
+/* the same with skip_seed (map.c:122-147) and MM_SEED_SELF (map.c:241): flag = the MM_F_* bits below (minimap.h:8-9,28-29); the name
+ * comparison is carried by ranks (see chain_oracle.c); ref_rank == NULL: no read name (map.c:125).  Returns the number of anchors kept. */
+#define MM2O_F_NO_DIAG  0x001
+#define MM2O_F_NO_DUAL  0x002
+#define MM2O_F_FOR_ONLY 0x100000
+#define MM2O_F_REV_ONLY 0x200000
+int64_t mm2o_collect_seed_hits_flags(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, int32_t flag,
+                                     const int32_t *ref_rank, const int32_t *ref_len, int32_t q_lo, int32_t q_eq, mm2o_anchor_t *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,13 @@ mm128_t *mm_chain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int m
 	const char *dump = getenv("MM2O_DUMP");
 	(void)tid;
 	if (_u) *_u = 0, *n_u_ = 0;
+	if ((n == 0 || a == 0) && dump && getenv("MM2O_DUMP_ALL")) {      /* a record for calls without anchors too (all-vs-all fixtures) */
+		FILE *fp = fopen(dump, "ab");
+		int64_t zero = 0;
+		int32_t h[9] = { max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, is_cdna, n_segs };
+		fwrite(&zero, 8, 1, fp); fwrite(h, 4, 9, fp); fwrite(&gap_scale, 4, 1, fp);
+		fclose(fp);
+	}
 	if (n == 0 || a == 0) { kfree(km, a); return 0; }
 	if (dump) {
 		FILE *fp = fopen(dump, "ab");

@@ -1,6 +1,6 @@
 /* driver.c -- test infrastructure: `minimap2 -x map-ont -t 1 <ref.fa> <query.fa>` without main.c / options.c (which need
  * the Xilinx header).  Option values restated from options.c:8-57 (defaults) and :93-94 (map-ont: k=15, flag 0); flow as
- * main.c:286-287,371-410.  Links the reference's own index / sketch / map / hit / format objects. */
+ * main.c:286-287,371-410; `-x ava-ont` adds options.c:82-86.  Links the reference's own index / sketch / map / hit / format objects. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,9 +48,10 @@ int main(int argc, char *argv[])
 	mm_mapopt_t mo;
 	mm_idx_reader_t *r;
 	mm_idx_t *mi;
-	int n_threads = 1;
+	int n_threads = 1, ava = 0;
+	if (argc >= 5 && strcmp(argv[1], "-x") == 0 && strcmp(argv[2], "ava-ont") == 0) { ava = 1; argv += 2; argc -= 2; }   /* main.c -x */
 	if (argc >= 5 && strcmp(argv[1], "-t") == 0) { n_threads = atoi(argv[2]); argv += 2; argc -= 2; }   /* main.c:153 -t */
-	if (argc < 3) { fprintf(stderr, "usage: %s [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
+	if (argc < 3) { fprintf(stderr, "usage: %s [-x ava-ont] [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
 #ifdef MM2_GPU_CHAINING
 	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
@@ -60,6 +61,11 @@ int main(int argc, char *argv[])
 	defaults(&io, &mo);
 	if (getenv("MM2_MINI_BATCH")) mo.mini_batch_size = atoll(getenv("MM2_MINI_BATCH"));   /* main.c -K */
 	io.flag = 0; io.k = 15;                              /* -x map-ont, options.c:93-94 */
+	if (ava) {                                           /* -x ava-ont, options.c:82-86 */
+		io.w = 5;
+		mo.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN;
+		mo.min_chain_score = 100; mo.pri_ratio = 0.0f; mo.max_gap = 10000; mo.max_chain_skip = 25; mo.bw = 2000;
+	}
 	io.flag |= MM_I_NO_SEQ;                              /* main.c:286-287: no -d, no CIGAR */
 	r = mm_idx_reader_open(argv[1], &io, 0);
 	if (!r) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }

@@ -57,6 +57,8 @@ def load():
         lib.mm2o_radix_sort_128x.argtypes = [vp, C.c_int64]
         lib.mm2o_collect_seed_hits.restype = C.c_int64
         lib.mm2o_collect_seed_hits.argtypes = [C.c_int64, vp, vp, C.c_int32, vp]
+        lib.mm2o_collect_seed_hits_flags.restype = C.c_int64
+        lib.mm2o_collect_seed_hits_flags.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]
         _lib = lib
     return _lib
 
@@ -153,12 +155,21 @@ def backtrack(min_cnt, min_sc, anchors, f, p):
 MATCH_DTYPE = np.dtype([("cr_off", "<i8"), ("n", "<u4"), ("q_pos", "<u4"), ("q_span", "<u4"), ("seg_tandem", "<u4")])   # mm2o_match_t / mm2c_match_t
 
 
-def collect_seed_hits(matches, hits, qlen):
-    """collect_seed_hits (map.c:215-247) of one read: matches (MATCH_DTYPE), hit pool (uint64) -> sorted anchors uint64 [n, 2]"""
+F_NO_DIAG, F_NO_DUAL, F_FOR_ONLY, F_REV_ONLY = 0x001, 0x002, 0x100000, 0x200000      # minimap.h:8-9,28-29
+
+
+def collect_seed_hits(matches, hits, qlen, flag=0, ref_rank=None, ref_len=None, q_lo=0, q_eq=0):
+    """collect_seed_hits (map.c:215-247) of one read: matches (MATCH_DTYPE), hit pool (uint64) -> sorted anchors uint64 [n, 2].
+    flag / ref_rank / ref_len / q_lo / q_eq: skip_seed (map.c:122-147), names carried by ranks (oracle/chain_oracle.c)"""
     m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
     h = np.ascontiguousarray(hits, dtype=np.uint64)
     if m.size and int((m["cr_off"] + m["n"]).max()) > h.size:
         raise ValueError("matches reach beyond the hit pool")
     a = np.zeros((max(int(m["n"].sum()), 1), 2), np.uint64)
-    n = load().mm2o_collect_seed_hits(m.size, _ptr(m), _ptr(h), int(qlen), _ptr(a))
+    rr = np.ascontiguousarray(ref_rank, dtype=np.int32) if ref_rank is not None else None
+    rl = np.ascontiguousarray(ref_len, dtype=np.int32) if ref_len is not None else None
+    if rr is not None and h.size and int((h >> np.uint64(32)).max()) >= rr.size:
+        raise ValueError("a hit names a reference sequence beyond ref_rank")
+    n = load().mm2o_collect_seed_hits_flags(m.size, _ptr(m), _ptr(h), int(qlen), int(flag), _ptr(rr) if rr is not None else None,
+                                            _ptr(rl) if rl is not None else None, int(q_lo), int(q_eq), _ptr(a))
     return a[:n]

@@ -259,6 +259,24 @@ def test_seed_hits_oracle_equals_the_reference_anchor_lists():
     assert n_ties > 1000
 
 
+def test_seed_hits_oracle_with_skip_seed_equals_the_reference_all_vs_all_anchor_lists():
+    """`-x ava-ont` (options.c:82-86: NO_DIAG | NO_DUAL): mm2o_collect_seed_hits_flags -- skip_seed (map.c:122-147) with the name comparison
+    carried by ranks, MM_SEED_SELF (map.c:241) -- against the anchor lists the reference's own map.o handed to mm_chain_dp when 37 reads
+    were mapped against themselves (tests/golden/make_ref_ava_fixtures.py); incl. a read whose name matches another of different length"""
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits_ava.npz"))
+    n_self = n_drop = 0
+    for k in range(int(d["n_reads"])):
+        a = ob.collect_seed_hits(d[f"r{k}_matches"], d[f"r{k}_hits"], int(d[f"r{k}_qlen"]), int(d["flag"]), d["ref_rank"], d["ref_len"],
+                                 int(d[f"r{k}_qlo"]), int(d[f"r{k}_qeq"]))
+        ref = d[f"r{k}_anchors"]
+        assert np.array_equal(a, ref), f"read {k}: anchors differ from the reference's ({a.shape[0]} vs {ref.shape[0]})"
+        n_self += int(((ref[:, 1] >> np.uint64(43)) & np.uint64(1)).sum())
+        n_drop += int(d[f"r{k}_matches"]["n"].sum()) - ref.shape[0]
+        # without the flags every hit becomes an anchor: the fixture really exercises the skipping
+        assert ob.collect_seed_hits(d[f"r{k}_matches"], d[f"r{k}_hits"], int(d[f"r{k}_qlen"])).shape[0] == int(d[f"r{k}_matches"]["n"].sum())
+    assert n_self > 20 and n_drop > 30000
+
+
 def test_matches_from_anchors_expand_back_into_the_same_anchors():
     """synth.matches_from_anchors (the seed-hit input of bench.py and tools/seed_probe.py): collect_seed_hits of the derived matches gives the
     anchors of the stream again (as a multiset, sorted by x; the order among equal x is the sort's)"""

@@ -182,3 +182,66 @@ def test_matches_in_chains_out_host_entry():
         assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), f"read {k}: chains differ"
         n_chains += u_ref.size
     assert n_chains > 27
+
+
+def test_all_vs_all_seed_hits_with_skip_seed_equal_the_reference_and_chain_on_the_device():
+    """`-x ava-ont` (BASELINE config 5; options.c:82-86: NO_DIAG | NO_DUAL): the matches of 37 reads mapped against themselves go through
+    mm2c_seedplan_run_device_skip -- skip_seed (map.c:122-147) with the name comparison as ranks, MM_SEED_SELF (map.c:241), reads that keep
+    fewer anchors than they have hits, packed by offsets the device computes -- and must equal, read by read, the anchor lists the
+    reference's own map.o handed to mm_chain_dp (tests/golden/ref_seed_hits_ava.npz).  Then the anchors are chained where they are:
+    plan over the capacity offsets + mm2c_plan_set_device_offsets; f / p against the oracle on the reference's anchors."""
+    import mm2chain
+    from mm2chain import params
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_seed_hits_ava.npz"))
+    n = int(d["n_reads"])
+    ms, hs, mo, cap = [], [], [0], [0]
+    for k in range(n):
+        m = d[f"r{k}_matches"].copy(); m["cr_off"] += cap[-1]
+        ms.append(m); hs.append(d[f"r{k}_hits"]); mo.append(mo[-1] + m.size); cap.append(cap[-1] + int(m["n"].sum()))
+    m_all = np.concatenate(ms); h_all = np.concatenate(hs)
+    if True:
+        sp = mm2chain.SeedPlan(np.array(mo, np.int64), np.array(cap, np.int64))
+        dev = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).astype(dt)).cuda()
+        d_m = torch.from_numpy(m_all.view(np.uint8).copy()).cuda(); d_h = torch.from_numpy(h_all.view(np.int64)).cuda()
+        d_q = dev([int(d[f"r{k}_qlen"]) for k in range(n)], np.int32)
+        d_lo = dev([int(d[f"r{k}_qlo"]) for k in range(n)], np.int32); d_eq = dev([int(d[f"r{k}_qeq"]) for k in range(n)], np.int32)
+        d_rr = dev(d["ref_rank"], np.int32); d_rl = dev(d["ref_len"], np.int32)
+        anchors, off = sp.run_skip(d_m, d_h, d_q, int(d["flag"]), d_rr, d_rl, d_lo, d_eq)
+        sp.check()
+        off_h = off.cpu().numpy()
+        a_h = anchors.cpu().numpy().view(np.uint64)
+        assert off_h[0] == 0
+        n_self = 0
+        for k in range(n):
+            ref = d[f"r{k}_anchors"]
+            got = a_h[off_h[k]:off_h[k + 1]]
+            assert np.array_equal(got, ref), f"read {k}: {got.shape[0]} anchors, the reference kept {ref.shape[0]}"
+            n_self += int(((ref[:, 1] >> np.uint64(43)) & np.uint64(1)).sum())
+        assert n_self > 20 and int(off_h[-1]) < cap[-1] // 4          # most hits are dropped (the diagonal and the second copy of every pair)
+        # the flag-free entry on the same plan still keeps everything
+        a2 = sp.run(d_m, d_h, d_q); sp.check()
+        assert np.array_equal(a2.cpu().numpy().view(np.uint64)[:cap[1]], ob.collect_seed_hits(d["r0_matches"], d["r0_hits"], int(d["r0_qlen"])))
+        # ---- chain them where they are, with the sizes only the device knows
+        h = [int(v) for v in d["chain_scalars"]]
+        P = params.make_params(h[0], h[1], h[2], h[3], h[4], 1.0, h[7], h[8])
+        plan = mm2chain.ChainPlan(P, np.array(cap, np.int64))
+        plan.set_device_offsets(off)
+        d_f = torch.full((cap[-1],), -9, dtype=torch.int32, device="cuda"); d_p = torch.full_like(d_f, -9)
+        plan.run(anchors, d_f, d_p)
+        u_off, u, b_off, b = plan.chains(anchors, d_f, d_p, h[5], h[6])
+        f_h, p_h = d_f.cpu().numpy(), d_p.cpu().numpy()
+        uo, bo = u_off.cpu().numpy(), b_off.cpu().numpy()
+        u_h, b_h = u.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64)
+        n_chains = 0
+        for k in range(n):
+            ref = d[f"r{k}_anchors"]
+            if ref.shape[0] == 0:
+                assert uo[k + 1] == uo[k]
+                continue
+            f_ref, p_ref, _ = ob.chain_fpv(P, ref)
+            assert np.array_equal(f_h[off_h[k]:off_h[k + 1]], f_ref) and np.array_equal(p_h[off_h[k]:off_h[k + 1]], p_ref), k
+            u_ref, b_ref = ob.mm_chain_dp(P, h[5], h[6], ref)
+            assert np.array_equal(u_h[uo[k]:uo[k + 1]], u_ref) and np.array_equal(b_h[bo[k]:bo[k + 1]], b_ref), k
+            n_chains += u_ref.size
+        assert n_chains > 20
+        plan.close(); sp.close()
