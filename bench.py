@@ -52,12 +52,18 @@ def host_cores():
 
 def measured_traffic(profile, total_anchors):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
-    (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads + WRITE_SIZE, separate
+    (profiles/traffic.json: FETCH_SIZE + 8 B per anchor for the half-counted dwordx4 anchor loads + WRITE_SIZE, separate
     --pmc passes).  PMC counters cannot be read from inside this process, so the value is the profiled one, scaled by
     anchors when the batch size differs; None when no summary exists for the profile."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
+        import hashlib
         rec = json.load(open(path))[profile]
+        h = hashlib.sha256()
+        for fn in ("chain_dp_tile.h", "chain_wave.h", "chain_kernel.hip", "chain_kernel.h"):
+            h.update(open(os.path.join(PKG, "csrc", fn), "rb").read())
+        if rec.get("kernel_source_sha") != h.hexdigest()[:16]:
+            return None                                        # the kernel changed since it was profiled: no stale number
         return rec["hbm_bytes_per_launch"] * (total_anchors / rec["anchors_per_launch"])
     except Exception:
         return None
@@ -244,7 +250,7 @@ def main():
                    "parallelism": f"read-sharded x{world}" + (" (one batch, tasks dealt longest-first)" if args.strong else "")},
         "verified_vs_oracle": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_wave", "kernel_ms_avg": k_avg_ms,
+                     "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_tile", "kernel_ms_avg": k_avg_ms,
                      "prepass_kernel_ms_avg": float(np.mean(prepass_ms)),
                      "algorithmic_bytes_per_launch": total * ALGO_BYTES_PER_ANCHOR},
     }

@@ -68,9 +68,10 @@ def test_parameter_corners(max_skip, max_iter, gap_scale, bw):
     assert_same(f, p, f_ref, p_ref, off, f"corner {max_skip},{max_iter},{gap_scale},{bw}")
 
 
-@pytest.mark.parametrize("ring_class", [0, 1, 2])
+@pytest.mark.parametrize("ring_class", [3, 0, 1, 2])
 def test_ring_classes_and_far_lookback(ring_class):
-    """look-back far beyond the LDS ring: a very dense locus (window ~ max_iter) with the early exit mostly disabled"""
+    """look-back far beyond the LDS ring: a very dense locus (window ~ max_iter) with the early exit mostly disabled; ring class 3 = the tile
+    kernel (the default), 0 / 1 / 2 = the first-generation kernel with 256 / 512 / 1024 anchors of ring"""
     import mm2chain
     from mm2chain import params
     mm2chain.tune("ring_class", ring_class)
@@ -81,16 +82,17 @@ def test_ring_classes_and_far_lookback(ring_class):
             f, p = gpu_batch(P, off, a)
             assert_same(f, p, f_ref, p_ref, off, f"ring {ring_class}")
     finally:
-        mm2chain.tune("ring_class", 0)
+        mm2chain.tune("ring_class", 3)
 
 
 @pytest.mark.parametrize("max_skip", [25, 1000, INT32_MAX])
 def test_window_lengths_around_ring_and_victim_boundaries(max_skip):
-    """one dense cluster per task (every anchor within max_dist_x of every other): look-back lengths of exactly
-    ring (256), ring + 1..3 register tiles (320/384/448) and beyond (L2/HBM), +-1 anchor each"""
+    """one dense cluster per task (every anchor within max_dist_x of every other): look-back lengths around every boundary of the tile
+    kernel -- the tile (64), the f / p rings (128 anchors before the own tile), the x / q rings (448 before the own tile), beyond (L2/HBM)
+    -- and of the first-generation kernel (256, 320/384/448), +-1 anchor each"""
     from mm2chain import params
     rng = np.random.default_rng(int(max_skip) % 1000)
-    sizes = [63, 64, 65, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 511, 512, 513, 640, 900]
+    sizes = [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448, 449, 511, 512, 513, 575, 576, 577, 640, 900, 1500]
     tasks = []
     for n in sizes:
         pos = 50000 + np.cumsum(rng.integers(0, 3, n))           # spans < 2n bp, far below max_dist_x
@@ -104,6 +106,33 @@ def test_window_lengths_around_ring_and_victim_boundaries(max_skip):
     f_ref, p_ref = oracle_batch(P, off, a)
     f, p = gpu_batch(P, off, a)
     assert_same(f, p, f_ref, p_ref, off, f"boundaries max_skip={max_skip}")
+
+
+@pytest.mark.parametrize("max_skip,gap_scale,bw", [(25, 1.0, 500), (3, 1.0, 500), (0, 1.0, 500), (25, 0.8, 500), (25, 1.3, 600), (7, 1.0, 5000), (25, 1.0, 4999)])
+def test_tile_kernel_paths(max_skip, gap_scale, bw):
+    """what selects the code paths of the second-generation kernel: runs of equal x shorter and longer than a tile (the hand-written scan hands
+    an anchor whose x equals its predecessor's to the C++ scan; a run that crosses the tile start needs the per-lane dr != 0 test), per-anchor
+    spans, windows that end inside / at / beyond the f-p rings and the x-q rings with the early exit firing at different depths, gap_scale != 1
+    with and without the cost table (bw <= 511 or not), max_dq - 1 >= bw or not (the three-instruction filter needs it)"""
+    from mm2chain import params
+    rng = np.random.default_rng(1000 * max_skip + bw)
+    tasks = []
+    for n, dup, dens in [(700, 0.0, 1), (900, 0.3, 1), (1300, 0.9, 2), (2500, 0.5, 6), (4000, 0.2, 10), (130, 0.97, 1), (3000, 0.0, 20)]:
+        step = np.where(rng.random(n) < dup, 0, rng.integers(1, 12 * dens + 2, n))     # dup: fraction of anchors with the x of their predecessor
+        pos = (1 << 22) + np.cumsum(step)
+        q = 50 + np.cumsum(np.where(rng.random(n) < 0.15, rng.integers(-400, 400, n), rng.integers(0, 14 * dens, n)))
+        span = np.where(rng.random(n) < 0.5, 15, rng.integers(8, 40, n))
+        x = (np.uint64(1) << np.uint64(32)) | pos.astype(np.uint64)
+        y = (span.astype(np.uint64) << np.uint64(32)) | (np.maximum(q, 1).astype(np.uint64) & np.uint64(0xffffffff))
+        o = np.argsort(x, kind="stable")
+        tasks.append(np.stack((x[o], y[o]), 1))
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    P = params.make_params(max_skip=max_skip, gap_scale=gap_scale, bw=bw)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    f, p = gpu_batch(P, off, a)
+    assert_same(f, p, f_ref, p_ref, off, f"tile kernel paths max_skip={max_skip} gap_scale={gap_scale} bw={bw}")
+    assert int((p_ref >= 0).sum()) > a.shape[0] // 3
 
 
 def test_ava_ont_and_asm20_shapes():

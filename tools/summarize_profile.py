@@ -9,6 +9,17 @@ import os
 import sys
 
 src, name, bench_profile, anchors = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+
+
+def kernel_sha():
+    """identity of the DP kernel's sources: bench.py reports the profiled traffic only while it matches"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("chain_dp_tile.h", "chain_wave.h", "chain_kernel.hip", "chain_kernel.h"):
+        h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minimap2-fpga_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_md = os.path.join(root, "profiles", name + ".md")
 
@@ -35,26 +46,37 @@ for k, d in sorted(agg.items()):
     lines += [f"### `{k}`", "", "| counter | mean per launch | per anchor |", "|---|---|---|"]
     for c, v in sorted(d.items()):
         # the same templated name is launched twice per step (main pass + flagged-task redo pass): report the big one
-        v = sorted(v)[len(v) // 2:] if "chain_dp_wave" in k else v
+        v = sorted(v)[len(v) // 2:] if ("chain_dp_wave" in k or "chain_dp_tile" in k) else v
         m = sum(v) / len(v)
         lines.append(f"| {c} | {m:.6g} | {m / anchors:.4g} |")
-    if "chain_dp_wave" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    if ("chain_dp_wave" in k or "chain_dp_tile" in k) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fs = sorted(d["FETCH_SIZE"])[len(d["FETCH_SIZE"]) // 2:]
         ws = sorted(d["WRITE_SIZE"])[len(d["WRITE_SIZE"]) // 2:]
         fetch_kb, write_kb = sum(fs) / len(fs), sum(ws) / len(ws)
         if traffic is not None and traffic["fetch_size_kb"] >= fetch_kb:
             lines.append("")
             continue
+        # gfx950 tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 bytes (MI355X_MICROARCH.md, HBM section).  In this
+        # kernel exactly one such load exists per anchor (the anchor itself, global_load_dwordx4: 16 B per anchor, read once); everything else
+        # (window starts, far / deep f, p, x, q, stamps) is 4 bytes per lane and counted in full.  So the corrected read traffic is
+        # FETCH_SIZE + 8 B per anchor; doubling the whole counter (what round 1 reported) is an upper bound.
+        raw_rd = fetch_kb * 1024
         traffic = {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-                   "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024, "anchors_per_launch": anchors,
-                   "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
-                           "WRITE_SIZE as reported; separate --pmc passes", "source": name}
+                   "hbm_bytes_per_launch": raw_rd + 8.0 * anchors + write_kb * 1024, "hbm_bytes_per_launch_upper": (2 * fetch_kb + write_kb) * 1024,
+                   "anchors_per_launch": anchors, "kernel_source_sha": kernel_sha(),
+                   "note": "FETCH_SIZE + 8 B per anchor (the one dwordx4 load per anchor is tallied at half its bytes on gfx950, "
+                           "MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes; _upper doubles the whole FETCH_SIZE", "source": name}
     lines.append("")
 if traffic:
-    lines += ["## HBM traffic of chain_dp_wave", "",
-              f"FETCH_SIZE {traffic['fetch_size_kb']:.4g} KB (x2 correction) + WRITE_SIZE {traffic['write_size_kb']:.4g} KB = "
-              f"{traffic['hbm_bytes_per_launch']/1e9:.2f} GB per launch = {traffic['hbm_bytes_per_launch']/anchors:.1f} B per anchor "
-              f"(algorithmic: 24 B per anchor)", ""]
+    rd_raw = traffic['fetch_size_kb'] * 1024 / anchors
+    wr = traffic['write_size_kb'] * 1024 / anchors
+    lines += ["## HBM traffic of the DP kernel", "",
+              "| source | B per anchor |", "|---|---|",
+              f"| FETCH_SIZE as reported | {rd_raw:.1f} |",
+              "| + the anchor loads (one global_load_dwordx4 per anchor: 16 B, tallied at 8 B on gfx950) | +8.0 |",
+              f"| = reads, corrected | {rd_raw + 8:.1f} (16 B anchors + {rd_raw - 8:.1f} B of 4-byte loads: window starts 4 B, deep / far f, p, x, q, stamps) |",
+              f"| WRITE_SIZE | {wr:.1f} (8 B f, p + stamp scratch) |",
+              f"| total | **{rd_raw + 8 + wr:.1f}** (algorithmic 24; upper bound with the whole FETCH_SIZE doubled: {2 * rd_raw + wr:.1f}) |", ""]
     tj = os.path.join(root, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt[bench_profile] = traffic
