@@ -56,7 +56,9 @@ typedef struct {
 } mm2c_params_t;
 
 /* ---- lifecycle: replaces hardware_init(BUFFER_N, XCLBIN_FILE) / cleanup() (chain_hardware.h:70-71, main.c:367,430) ---- */
-int  mm2c_init(int device_ordinal);           /* -1: current device.  Idempotent. */
+int  mm2c_init(int device_ordinal);           /* -1: current device -- or, when the environment variable MM2C_DEVICES is set ("all" or a
+                                               * comma-separated list of ordinals), those devices as with mm2c_init_devices: the route for a host
+                                               * whose init hook carries no ordinals (hardware_init, chain_hardware.h:69).  Idempotent. */
 /* Several devices in one process (the reference scaffolds NUM_HW_KERNELS command queues / buffer sets / locks, chain_hardware.cpp:9-23,
  * chain_hardware.h:57): mm2c_init_devices instead of mm2c_init.  ordinals[0] is the primary device (plans, the per-read entries and
  * the call combiner run there); the host-batch entries (mm2c_chain_batch_host, mm2c_mm_chain_dp_batch_host, mm2c_seed_chain_batch_host)

@@ -295,11 +295,33 @@ int mm2c_init(int device_ordinal)
 	if (e != hipSuccess || n_dev <= 0)
 		return fail(MM2C_E_NODEVICE, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
 	int dev = device_ordinal;
+	std::vector<int> env_devices;
+	if (dev < 0 && G.devices.empty()) {
+		// a host that cannot pass ordinals (hardware_init(long, char *), chain_hardware.h:69) names its devices in the environment:
+		// MM2C_DEVICES=all, or a comma-separated list of ordinals; batches are then split across them as after mm2c_init_devices
+		const char *env = getenv("MM2C_DEVICES");
+		if (env && *env) {
+			std::vector<int> ds;
+			if (strcmp(env, "all") == 0) { for (int k = 0; k < n_dev && k < 64; ++k) ds.push_back(k); }
+			else {
+				for (const char *c = env; *c;) {
+					char *end = nullptr;
+					const long v = strtol(c, &end, 10);
+					if (end == c || v < 0 || v >= n_dev || ds.size() >= 64) return fail(MM2C_E_NODEVICE, "MM2C_DEVICES=%s: bad ordinal (%d devices)", env, n_dev);
+					ds.push_back((int)v);
+					c = (*end == ',') ? end + 1 : end;
+					if (*end != ',' && *end != 0) return fail(MM2C_E_ARG, "MM2C_DEVICES=%s: comma-separated ordinals or `all` expected", env);
+				}
+			}
+			if (!ds.empty()) { env_devices = ds; dev = ds[0]; }
+		}
+	}
 	if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
 	if (dev >= n_dev) return fail(MM2C_E_NODEVICE, "device ordinal %d out of range (%d devices)", dev, n_dev);
 	HIP_TRY(hipSetDevice(dev));
 	HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
 	G.device = dev;
+	if (!env_devices.empty()) G.devices = env_devices;
 	if (G.devices.empty()) G.devices.assign(1, dev);
 	const char *rc = getenv("MM2C_RING_CLASS");
 	G.ring_class = rc ? std::max(0, std::min(3, atoi(rc))) : 3;

@@ -8,19 +8,22 @@
  *
  * PARITY PINNING STATUS (details: DESIGN.md section 4).  The reference's own chain.c cannot be built in this image
  * (chain.c -> chain_hardware.h:6 -> xcl2.hpp:34 includes <CL/cl_ext_xilinx.h>, a Xilinx XRT vendor header that is absent;
- * no stand-in header is written) and the reference tree holds no f[]/p[] known-answer vectors.  The restatement is pinned
- *  (a) END TO END AGAINST THE REFERENCE'S RECORDED OUTPUT: oracle/ref_host links the reference's own non-path host objects
+ * no stand-in header is written).  The restatement is pinned
+ *  (a) ELEMENT BY ELEMENT AGAINST f[]/p[] PRODUCED BY THE REFERENCE'S OWN DEVICE KERNEL: device/minimap2_opencl.cl compiles, unmodified,
+ *      for the host CPU with the image's clang OpenCL front end (oracle/ref_host/Makefile, libref_cl_chain.so); its outputs for 18 tasks
+ *      (30 996 anchors) are committed as tests/golden/ref_cl_kernel_fp.npz and reproduced by mm2o_chain_fpv under V2 parameters, by
+ *      mm2o_chain_hw_literal and by the HIP kernel.  This pins the window, the filters, the score and gap cost, ties and the strict `>`.
+ *      The branches only the V1 loop has (max_skip, max_iter other than 1024, per-anchor spans, segments, gap_scale) are pinned by (b)-(d);
+ *  (b) END TO END AGAINST THE REFERENCE'S RECORDED OUTPUT: oracle/ref_host links the reference's own non-path host objects
  *      (index, sketch, seeding, hit, format; built in place from /root/reference) with mm2o_mm_chain_dp and reproduces,
  *      byte for byte, the PAF the real reference prints for its test data (MT-human vs MT-orang,
  *      md5 f49a6331..., cm:i:342 s1:i:3189; t-inv vs q-inv; t2 vs q2) -- tests/test_cpu_ref_host.py;
- *  (b) by hand-derived known-answer cases from the recurrence and an independent Python restatement;
- *  (c) by a literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree under V2 parameters.
- *  (d) mm2o_collect_seed_hits (map.c:215-247, incl. the unstable radix_sort_128x) against the anchor lists the reference's own map.o
- *      produced for 27 reads, four of them with equal-x anchors (tests/golden/ref_seed_hits.npz, tests/test_cpu_oracle.py);
- *  (e) the same end-to-end check as (a) at scale on the GPU box: the reference host objects with the oracle's mm_chain_dp and with the
- *      product library print identical PAF for 400 000 simulated reads (profiles/r1_e2e_synth.md).
- * (a) constrains f[]/p[] through the chains they produce on three real anchor lists (n = 346, 223, 732), not element by
- * element on arbitrary inputs: element-wise coverage rests on (b) and (c).
+ *  (c) by hand-derived known-answer cases from the recurrence and an independent Python restatement;
+ *  (d) by a literal restatement of the FPGA kernel (mm2o_chain_hw_literal) that must agree under V2 parameters;
+ *  (e) mm2o_collect_seed_hits / _flags (map.c:122-147,215-247, incl. the unstable radix_sort_128x) against the anchor lists the reference's
+ *      own map.o produced (tests/golden/ref_seed_hits.npz: 27 reads; ref_seed_hits_ava.npz: all-vs-all under -x ava-ont);
+ *  (f) the same end-to-end check as (b) at scale on the GPU box: the reference host objects with the oracle's mm_chain_dp and with the
+ *      product library print identical PAF for 120 000 - 400 000 simulated reads (profiles/r1_e2e_synth.md, r2_e2e_synth.md).
  */
 #ifndef MM2_CHAIN_ORACLE_H
 #define MM2_CHAIN_ORACLE_H

@@ -142,6 +142,25 @@ def test_wave_formulation_model_equals_oracle(profile):
             assert np.array_equal(f, fm) and np.array_equal(p, pm)
 
 
+@pytest.mark.parametrize("profile", ["mixed", "dense", "colinear"])
+def test_tile_formulation_model_equals_oracle(profile):
+    """the tile-aligned formulation of the round-2 kernel (csrc/chain_dp_tile.h): rings addressed by the anchor index, three-instruction
+    filter, equal-x runs, 16-bit / far stamps, fold paths A / B1 / B2"""
+    from tile_model import chain_tile_model
+    off, a = _stream(profile, 2, 900, seed=4)
+    for par in (P(), P(max_skip=2, max_iter=300), P(max_skip=INT32_MAX, max_iter=150), P(gap_scale=0.8, bw=100),
+                P(max_iter=5000, max_dist_x=20000, max_dist_y=20000)):
+        for k in range(2):
+            t = a[off[k]:off[k + 1]]
+            avg = ob.avg_qspan(t)
+            f, p, _ = ob.chain_fpv(par, t, avg)
+            st = {}
+            fm, pm = chain_tile_model(par, t, avg, stats=st)
+            assert np.array_equal(f, fm) and np.array_equal(p, pm)
+            assert st["anchors"] == t.shape[0] and st["fold_a"] + st["fold_b1"] + st["fold_b2_closed"] + st["fold_b2_scan"] == \
+                st["own_pass"] + st["ring_pass"] + st["far_pass"]
+
+
 def test_fpga_literal_equals_v1_with_v2_parameters():
     """device/minimap2_opencl.cl emulated literally == chain.c loop with max_skip=inf, max_iter=1024"""
     off, a = _stream("dense", 2, 2500, seed=8, locus=9000)

@@ -66,3 +66,32 @@ def test_host_batches_split_across_device_contexts(n_ctx):
     for k in range(40):
         assert np.array_equal(out[k][0], out1[k][0]) and np.array_equal(out[k][1], out1[k][1]), k
         assert np.array_equal(out[k][0], res1[k][0]), k          # seeds -> chains == anchors -> chains (scores and counts; the order among equal x is the sort's)
+
+
+def test_devices_named_in_the_environment_for_hosts_whose_init_hook_carries_no_ordinals(monkeypatch):
+    """hardware_init(long, char *) (chain_hardware.h:69) -> mm2c_init(-1): MM2C_DEVICES names the devices"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 120, (200, 3000), seed=77)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    mm2chain.shutdown()
+    try:
+        monkeypatch.setenv("MM2C_DEVICES", "0,0")
+        mm2chain.init(-1)
+        assert mm2chain.device_count() == 2
+        mm2chain.tune("multi_min_anchors", 1000)
+        f, p = mm2chain.chain_batch_host(P, off, a)
+        assert_same(f, p, f_ref, p_ref, off, "MM2C_DEVICES=0,0")
+        mm2chain.shutdown()
+        monkeypatch.setenv("MM2C_DEVICES", "all")
+        mm2chain.init(-1)
+        assert mm2chain.device_count() == torch.cuda.device_count()
+        mm2chain.shutdown()
+        monkeypatch.setenv("MM2C_DEVICES", "0,99")
+        with pytest.raises(Exception):
+            mm2chain.init(-1)
+    finally:
+        monkeypatch.delenv("MM2C_DEVICES", raising=False)
+        mm2chain.shutdown()
+        mm2chain.init(0)
