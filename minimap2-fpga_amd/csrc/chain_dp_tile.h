@@ -155,7 +155,7 @@ __device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, i
 	if (depth <= NF) {
 		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 4
 		fj = *(const int *)(M.lds + LY::F + o);
-		pj = max(*(const int *)(M.lds + LY::Pp + o) - M.pbase, -1);   // the ring holds p as memory does: relative to the caller's task
+		pj = *(const int *)(M.lds + LY::Pp + o);                  // the ring holds p relative to the piece, as the scan uses it
 	} else {
 		const int j = max(base + rl, 0);                          // lanes before the window of a partly covered tile may point before the task
 		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -317,7 +317,128 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t"
 #define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t"
 
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF) \
+// ---- the segments in which the two instantiations of the loop differ.  `far`: the tile holds an anchor whose window reaches beyond the LDS ring
+// (bit 30 of its tw word): stamps with a target before the ring go to the global scratch, and a scan that runs through the whole ring without
+// the `break` goes on from memory (bit 28 set at run time).  `lean`: no such anchor in the tile, so nothing of that is tested; the stamp store
+// needs no exec mask either: lanes that must not stamp (filtered out, or p before the window) write the slot of anchor lo - 1 instead, which
+// no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (slots are compared with 1 + i mod 16384).
+#define MM2C_LK_FAR \
+	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
+	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t"
+#define MM2C_LK_LEAN \
+	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
+	"s_add_i32 %[lo0], %[lo], -1\n\t" \
+	"v_mov_b32 %[lom1v], %[lo0]\n\t"
+#define MM2C_HF_FAR \
+	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
+	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
+	"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
+	"s_mov_b64 exec, %[mk]\n\t" \
+	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
+	"s_mov_b64 exec, -1\n\t" \
+	"ds_read_u16 %[vb], %[vb]\n\t" \
+	"s_bitcmp1_b32 %[pk], 30\n\t" \
+	"s_cbranch_scc0 Lmk_%=\n\t" \
+	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
+	"s_and_b64 %[mask], vcc, %[valid]\n\t" \
+	"s_andn2_b64 %[mask], %[mask], %[mk]\n\t" \
+	"s_cbranch_scc0 Lmk_%=\n\t" \
+	"s_sub_i32 %[t0], %[i0], %[L]\n\t" \
+	"s_add_i32 %[t0], %[t0], 64\n\t" \
+	"v_mov_b32 %[u1], %[t0]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
+	"s_mov_b64 exec, %[mask]\n\t" \
+	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
+	"s_mov_b64 exec, -1\n"
+#define MM2C_HF_LEAN \
+	"v_cndmask_b32_e64 %[u2], -1, %[vp], %[valid]\n\t" \
+	"v_max_i32 %[u2], %[u2], %[lom1v]\n\t" \
+	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
+	"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
+	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
+	"ds_read_u16 %[vb], %[vb]\n"
+#define MM2C_TAIL_FAR \
+	"s_cbranch_scc0 Lret_%=\n\t" \
+	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
+	"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
+	"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
+	"s_cbranch_scc1 Ldone_%=\n" \
+	"Lret_%=:\n\t" \
+	"s_bitcmp1_b32 %[pk], 28\n\t" \
+	"s_cbranch_scc0 Lloop_%=\n\t" \
+	"s_branch Lfloop_%=\n"
+#define MM2C_TAIL_LEAN \
+	"s_cbranch_scc0 Lloop_%=\n\t" \
+	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
+	"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
+	"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
+	"s_cbranch_scc1 Ldone_%=\n" \
+	"Lret_%=:\n\t" \
+	"s_branch Lloop_%=\n"
+#define MM2C_END_FAR(SCORE) \
+	"Lend_%=:\n\t" \
+	"s_bitcmp1_b32 %[pk], 30\n\t" \
+	"s_cbranch_scc0 Ldone_%=\n\t" \
+	"s_bitset1_b32 %[pk], 28\n\t" \
+	"s_sub_i32 %[t0], %[i0], %[lo0]\n\t" \
+	"s_and_b32 %[part], %[t0], 63\n\t" \
+	"s_lshr_b32 %[nfull], %[t0], 6\n\t" \
+	"s_sub_i32 %[n], %[nfull], %[NXM1]\n\t" \
+	"s_mov_b32 %[d], %[NXM1]\n\t" \
+	"s_mov_b32 %[lo], %[lo0]\n\t" \
+	"s_sub_i32 %[s16], %[i0], %[L]\n\t" \
+	"s_add_i32 %[s16], %[s16], 64\n\t" \
+	"v_mov_b32 %[s16v], %[s16]\n\t" \
+	"s_sub_i32 %[fb], %[i0], %[REACH]\n" \
+	"Lfloop_%=:\n\t" \
+	"s_add_u32 %[d], %[d], 1\n\t" \
+	"s_sub_u32 %[n], %[n], 1\n\t" \
+	"s_cbranch_scc1 Lfpart_%=\n\t" \
+	MM2C_FAR_REQ \
+	"s_waitcnt vmcnt(0)\n\t" \
+	MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+	"s_cbranch_vccz Lfloop_%=\n\t" \
+	"s_mov_b64 %[valid], vcc\n\t" \
+	"s_branch Lfold_%=\n" \
+	"Lfpart_%=:\n\t" \
+	"s_mov_b32 %[n], 0\n\t" \
+	"s_cmp_eq_u32 %[part], 0\n\t" \
+	"s_cbranch_scc1 Ldone_%=\n\t" \
+	MM2C_FAR_REQ \
+	"s_waitcnt vmcnt(0)\n\t" \
+	MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+	"s_sub_i32 %[t0], 64, %[part]\n\t" \
+	"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
+	"s_mov_b32 %[part], 0\n\t" \
+	"s_and_b64 %[valid], vcc, %[mask]\n\t" \
+	"s_cbranch_scc0 Ldone_%=\n" \
+	"Lfold_%=:\n\t" \
+	"s_lshl_b32 %[t0], %[d], 6\n\t" \
+	"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+	"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+	"v_max_i32 %[u2], 0, %[u2]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+	"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
+	"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+	SCORE \
+	"s_waitcnt vmcnt(0)\n\t" \
+	"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
+	"v_max_i32 %[vp], -1, %[vp]\n\t" \
+	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
+	"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
+	"s_mov_b64 exec, %[mk]\n\t" \
+	"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
+	"s_mov_b64 exec, -1\n\t" \
+	"s_waitcnt vmcnt(0)\n\t" \
+	"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
+	"s_waitcnt vmcnt(0)\n\t" \
+	"s_branch Lmk_%=\n"
+#define MM2C_END_LEAN(SCORE) \
+	"Lend_%=:\n"
+
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tbef, int tw, int ts16, int &own_f, int &own_p, \
@@ -327,7 +448,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	typedef Lds<NX, NF, false, true> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
 	mask_t mask, valid, mk, marked, nm, se; \
-	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v; \
+	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v; \
 	asm volatile( \
 		"s_sub_i32 %[L], 63, %[kstart]\n" \
 		"Lk_%=:\n\t" \
@@ -338,8 +459,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc1 Lexit_%=\n\t" \
 		"s_bitcmp1_b32 %[pk], 29\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
-		"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
-		"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
+		SEG_LK \
 		"v_readlane_b32 %[nfull], %[tbef], %[L]\n\t" \
 		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
 		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
@@ -354,7 +474,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_mov_b32 %[s16v], %[s16]\n\t" \
 		"s_and_b32 %[t0], %[pk], 63\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
-		"s_add_i32 %[t1], %[L], 1\n\t" \
+		"s_bfe_u32 %[t1], %[pk], 0x70008\n\t" \
 		"s_bfm_b64 %[mask], %[t0], %[t1]\n\t" \
 		MM2C_FILTER("%[tx]", "%[tq]") MM2C_FILTER2 \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
@@ -386,7 +506,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"ds_read_b32 %[vf], %[u2] offset:%[FOFF]\n\t" \
 		SCORE \
 		"s_waitcnt lgkmcnt(0)\n\t" \
-		"s_branch Lfx_%=\n" \
+		"s_branch Lhf_%=\n" \
 		"Lfg_%=:\n\t" \
 		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
 		"v_max_i32 %[u2], 0, %[u2]\n\t" \
@@ -395,33 +515,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
 		SCORE \
 		"s_waitcnt vmcnt(0)\n" \
-		"Lfx_%=:\n\t" \
-		"s_cmp_eq_u32 %[pbase], 0\n\t" \
-		"s_cbranch_scc1 Lhf_%=\n\t" \
 		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
 		"v_max_i32 %[vp], -1, %[vp]\n" \
 		"Lhf_%=:\n\t" \
-		"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
-		"s_and_b64 %[mk], vcc, %[valid]\n\t" \
-		"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
-		"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
-		"s_mov_b64 exec, %[mk]\n\t" \
-		"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-		"s_mov_b64 exec, -1\n\t" \
-		"ds_read_u16 %[vb], %[vb]\n\t" \
-		"s_bitcmp1_b32 %[pk], 30\n\t" \
-		"s_cbranch_scc0 Lmk_%=\n\t" \
-		"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
-		"s_and_b64 %[mask], vcc, %[valid]\n\t" \
-		"s_andn2_b64 %[mask], %[mask], %[mk]\n\t" \
-		"s_cbranch_scc0 Lmk_%=\n\t" \
-		"s_sub_i32 %[t0], %[i0], %[L]\n\t" \
-		"s_add_i32 %[t0], %[t0], 64\n\t" \
-		"v_mov_b32 %[u1], %[t0]\n\t" \
-		"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
-		"s_mov_b64 exec, %[mask]\n\t" \
-		"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
-		"s_mov_b64 exec, -1\n" \
+		SEG_HF \
 		"Lmk_%=:\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
 		ADDF \
@@ -430,15 +527,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_and_b64 %[marked], vcc, %[valid]\n\t" \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n\t" \
 		"s_cbranch_vccnz Limp_%=\n\t" \
-		"s_cbranch_scc0 Lret_%=\n\t" \
-		"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
-		"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
-		"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
-		"s_cbranch_scc1 Ldone_%=\n" \
-		"Lret_%=:\n\t" \
-		"s_bitcmp1_b32 %[pk], 28\n\t" \
-		"s_cbranch_scc0 Lloop_%=\n\t" \
-		"s_branch Lfloop_%=\n" \
+		SEG_TAIL \
 		"Lpart_%=:\n\t" \
 		"s_mov_b32 %[n], 0\n\t" \
 		"s_cmp_eq_u32 %[part], 0\n\t" \
@@ -559,64 +648,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cmp_eq_u32 %[last], 63\n\t" \
 		"s_cbranch_scc1 Lret_%=\n\t" \
 		"s_branch Ldone_%=\n" \
-		"Lend_%=:\n\t" \
-		"s_bitcmp1_b32 %[pk], 30\n\t" \
-		"s_cbranch_scc0 Ldone_%=\n\t" \
-		"s_bitset1_b32 %[pk], 28\n\t" \
-		"s_sub_i32 %[t0], %[i0], %[lo0]\n\t" \
-		"s_and_b32 %[part], %[t0], 63\n\t" \
-		"s_lshr_b32 %[nfull], %[t0], 6\n\t" \
-		"s_sub_i32 %[n], %[nfull], %[NXM1]\n\t" \
-		"s_mov_b32 %[d], %[NXM1]\n\t" \
-		"s_mov_b32 %[lo], %[lo0]\n\t" \
-		"s_sub_i32 %[s16], %[i0], %[L]\n\t" \
-		"s_add_i32 %[s16], %[s16], 64\n\t" \
-		"v_mov_b32 %[s16v], %[s16]\n\t" \
-		"s_sub_i32 %[fb], %[i0], %[REACH]\n" \
-		"Lfloop_%=:\n\t" \
-		"s_add_u32 %[d], %[d], 1\n\t" \
-		"s_sub_u32 %[n], %[n], 1\n\t" \
-		"s_cbranch_scc1 Lfpart_%=\n\t" \
-		MM2C_FAR_REQ \
-		"s_waitcnt vmcnt(0)\n\t" \
-		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
-		"s_cbranch_vccz Lfloop_%=\n\t" \
-		"s_mov_b64 %[valid], vcc\n\t" \
-		"s_branch Lfold_%=\n" \
-		"Lfpart_%=:\n\t" \
-		"s_mov_b32 %[n], 0\n\t" \
-		"s_cmp_eq_u32 %[part], 0\n\t" \
-		"s_cbranch_scc1 Ldone_%=\n\t" \
-		MM2C_FAR_REQ \
-		"s_waitcnt vmcnt(0)\n\t" \
-		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
-		"s_sub_i32 %[t0], 64, %[part]\n\t" \
-		"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
-		"s_mov_b32 %[part], 0\n\t" \
-		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
-		"s_cbranch_scc0 Ldone_%=\n" \
-		"Lfold_%=:\n\t" \
-		"s_lshl_b32 %[t0], %[d], 6\n\t" \
-		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
-		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
-		"v_max_i32 %[u2], 0, %[u2]\n\t" \
-		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
-		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
-		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
-		SCORE \
-		"s_waitcnt vmcnt(0)\n\t" \
-		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
-		"v_max_i32 %[vp], -1, %[vp]\n\t" \
-		"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
-		"s_and_b64 %[mk], vcc, %[valid]\n\t" \
-		"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
-		"s_mov_b64 exec, %[mk]\n\t" \
-		"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
-		"s_mov_b64 exec, -1\n\t" \
-		"s_waitcnt vmcnt(0)\n\t" \
-		"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
-		"s_waitcnt vmcnt(0)\n\t" \
-		"s_branch Lmk_%=\n" \
+		SEG_END(SCORE) \
 		"Ldone_%=:\n\t" \
 		"s_mov_b32 m0, %[L]\n\t" \
 		"s_nop 0\n\t" \
@@ -632,7 +664,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), \
 		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
-		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), \
+		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tbef] "v"(tbef), [tw] "v"(tw), [ts16] "v"(ts16), \
@@ -643,8 +675,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	return 63 - L; \
 }
 
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP)
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB)
+// two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
+// without touching exec), `far` for the others
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR)
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
@@ -764,20 +800,27 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// predecessor's).  An anchor whose window reaches beyond the ring is scanned as far as the ring goes; only if that scan runs out without
 		// the `break` of chain.c:231 does the hand-written loop hand the anchor back to the C++ path
 		const int lo_l = no_pairs ? idx : min(cur_st, idx);
-		int tw_l = min(rl, idx - lo_l);
+		// An anchor at the end of a run of e anchors with its x: the e lanes above it are not predecessors (dr == 0); a run that reaches the
+		// tile's first anchor may go on in the tile before, and such an anchor takes the C++ path (per-lane test in every chunk)
+		const mask_t above = ~(eq_prev >> lane);                  // bit 0: this anchor's x differs from its predecessor's, bit 1: the predecessor's from ...
+		const int e_l = above ? (int)__builtin_ctzll(above) : 64;
+		const int w_l = min(rl, idx - lo_l);                      // own-tile predecessors inside the window: lanes lane + 1 .. lane + w
+		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8);   // bits 0-5: lanes to scan, bits 8-14: the first of them
 		if (lo_l >= idx) tw_l |= 1 << 29;
 		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
-		if (eq_prev >> lane & 1) tw_l |= (int)0x80000000;
+		if (e_l > rl) tw_l |= (int)0x80000000;
+		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
 		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);
 		const int s16_l = 1 + (idx & 0x3fff), ownst = LY::ST + ((idx & (SN - 1)) << 1);
 		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
-				if (TAB) k = scan_tile_asm_tab<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c,
-				                                       lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v);
-				else k = scan_tile_asm_cmp<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c,
-				                                   lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v);
+#define MM2C_CALL(FN) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
+                                 lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v)
+				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far) : MM2C_CALL(scan_tile_asm_cmp_far);
+				else k = TAB ? MM2C_CALL(scan_tile_asm_tab) : MM2C_CALL(scan_tile_asm_cmp);
+#undef MM2C_CALL
 				k = __builtin_amdgcn_readfirstlane(k);
 				if (k >= cnt) break;
 			}
@@ -810,7 +853,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		{
 			const int o = (idx << 2) & LY::FMASK;    // ... and enters the f / p rings
 			*(int *)(lds + LY::F + o) = own_f;
-			*(int *)(lds + LY::Pp + o) = own_p < 0 ? own_p : own_p + pbase;
+			*(int *)(lds + LY::Pp + o) = own_p;
 		}
 		cur = nxt; cur_st = nxt_st;
 	}
