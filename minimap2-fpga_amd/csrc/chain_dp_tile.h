@@ -292,7 +292,9 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // Per anchor: the own tile (lanes L+1 .. L+w), then `nfull` whole older tiles in a count-down loop that branches on VCC (7 VALU + 2 LDS
 // + 1 SALU + 2 branches per tile; x / q of the next tile are requested while this one is filtered), then the partly covered tile.
 // A chunk with a surviving lane goes through Lhf: f / p of its tile (registers, LDS, or L2 beyond NF tiles), stamps, score, fold.
-// The fold: A no lane beats the running best; B1 some does and neither marks nor skips exist (one candidate: no reduction at all);
+// The fold: A no lane beats the running best; B0 the first surviving lane does and no other lane beats IT (the usual case on a real chain: the
+// nearest predecessor is the best) -- it is the only new maximum, every marked lane behind it is a skip event, so counter and `break` have a
+// closed form; B1 some lane does and neither marks nor skips exist (one candidate: no reduction at all);
 // B2 general: prefix max by DPP -> lanes that raise the best (nm), skip events (se); closed form when every nm precedes every se,
 // else the max-plus scan n <- max(n + d, 0) over the lanes.
 // Wait states the assembler does not insert for inline asm (gfx940): VALU write -> DPP read of that VGPR: 2 (s_nop 1); VALU write ->
@@ -542,6 +544,26 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_add_i32 %[d], %[nfull], 1\n\t" \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
+		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
+		"v_readlane_b32 %[t1], %[sc], %[t0]\n\t" \
+		"s_cmp_gt_i32 %[t1], %[best]\n\t" \
+		"s_cbranch_scc0 Lslow_%=\n\t" \
+		"v_cmp_lt_i32 vcc, %[t1], %[sc]\n\t" \
+		"s_cbranch_vccnz Lslow2_%=\n\t" \
+		"s_mov_b32 %[best], %[t1]\n\t" \
+		"s_add_i32 %[t1], %[base], 63\n\t" \
+		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
+		"s_sub_i32 %[nskip], %[nskip], 1\n\t" \
+		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
+		"s_bitset0_b64 %[marked], %[t0]\n\t" \
+		"s_bcnt1_i32_b64 %[t1], %[marked]\n\t" \
+		"s_add_i32 %[nskip], %[nskip], %[t1]\n\t" \
+		"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n\t" \
+		"s_branch Lret_%=\n" \
+		"Lslow2_%=:\n\t" \
+		"v_cmp_lt_i32 vcc, %[best], %[sc]\n" \
+		"Lslow_%=:\n\t" \
 		"s_cmp_lg_u64 %[marked], 0\n\t" \
 		"s_cbranch_scc1 Lb2_%=\n\t" \
 		"s_cmp_lg_u32 %[nskip], 0\n\t" \

@@ -157,7 +157,7 @@ def test_tile_formulation_model_equals_oracle(profile):
             st = {}
             fm, pm = chain_tile_model(par, t, avg, stats=st)
             assert np.array_equal(f, fm) and np.array_equal(p, pm)
-            assert st["anchors"] == t.shape[0] and st["fold_a"] + st["fold_b1"] + st["fold_b2_closed"] + st["fold_b2_scan"] == \
+            assert st["anchors"] == t.shape[0] and st["fold_a"] + st["fold_b0"] + st["fold_b1"] + st["fold_b2_closed"] + st["fold_b2_scan"] == \
                 st["own_pass"] + st["ring_pass"] + st["far_pass"]
 
 

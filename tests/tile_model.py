@@ -1,8 +1,8 @@
 """NumPy model of the control flow of the round-2 HIP kernel (csrc/chain_dp_tile.h), lane for lane: tile-aligned chunks scanned
 nearest-first (own tile from "registers", NX - 1 older tiles from the x / q ring, f / p of the NF nearest from the ring and deeper ones
 from the task's own stores, anything older from "global" memory), the three-instruction filter, equal-x runs found per tile, 16-bit
-stamps in a ring of 64 NX slots with 32-bit stamps beyond it, and the three fold paths (A: no lane beats the running best, B1: a single
-candidate, B2: prefix max + closed-form or max-plus skip counter).  It exists so that the formulation can be checked against the oracle
+stamps in a ring of 64 NX slots with 32-bit stamps beyond it, and the fold paths (A: no lane beats the running best, B0: the first surviving
+lane is the only new maximum, B1: a single candidate, B2: prefix max + closed-form or max-plus skip counter).  It exists so that the formulation can be checked against the oracle
 WITHOUT a GPU (-m "not gpu"), and so that tools/chunk_stats.py can count how often each path of the hand-written loop is taken
 (profiles/r2_isa_budget.md); the GPU tests check the real kernel.  One segment, no cDNA (the variant the hand-written loop covers)."""
 import numpy as np
@@ -40,7 +40,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
     fast_filter = P.bw >= 0 and max_dq - 1 >= P.bw
     lane = np.arange(64)
     S = dict(anchors=0, no_window=0, own_chunks=0, own_pass=0, ring_chunks=0, ring_pass=0, deep_fp=0, far_chunks=0, far_pass=0,
-             fold_a=0, fold_b1=0, fold_b2_closed=0, fold_b2_scan=0, breaks=0, eq_run_anchors=0)
+             fold_a=0, fold_b0=0, fold_b1=0, fold_b2_closed=0, fold_b2_scan=0, breaks=0, eq_run_anchors=0)
     for i0 in range(0, n, 64):
         cnt = min(64, n - i0)
         stamp_lo = i0 - 64 * (NX - 1)
@@ -130,6 +130,18 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     base -= 64
                     if broke:
                         S["breaks"] += 1
+                    continue
+                l0 = int(np.argmax(valid))
+                if scv[l0] > best and not (scv > scv[l0]).any():                   # fold B0: the first surviving lane is the only new maximum
+                    S["fold_b0"] += 1
+                    best, best_j = int(scv[l0]), base + 63 - l0
+                    n_skip = max(n_skip - 1, 0)
+                    se = marked.copy(); se[l0] = False                             # every marked lane behind it is a skip event
+                    n_skip += int(se.sum())
+                    if n_skip > P.max_skip:
+                        broke = True
+                        S["breaks"] += 1
+                    base -= 64
                     continue
                 incl = np.maximum.accumulate(scv)
                 if not marked.any() and n_skip == 0 and int(cand.sum()) == 1:      # fold B1

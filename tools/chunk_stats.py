@@ -24,7 +24,7 @@ if __name__ == "__main__":
     m = int(args[args.index("--anchors") + 1]) if "--anchors" in args else 5000
     profiles = [a for a in args if not a.startswith("--") and not a.isdigit()] or ["mixed", "dense", "colinear"]
     P = params.map_ont()
-    keys = ("no_window", "own_chunks", "own_pass", "ring_chunks", "ring_pass", "deep_fp", "far_chunks", "far_pass", "fold_a", "fold_b1",
+    keys = ("no_window", "own_chunks", "own_pass", "ring_chunks", "ring_pass", "deep_fp", "far_chunks", "far_pass", "fold_a", "fold_b0", "fold_b1",
             "fold_b2_closed", "fold_b2_scan", "breaks", "eq_run_anchors")
     print(f"Per anchor, map-ont parameters, {reads} reads x {m} anchors of each bench.py stream (seed 1), NX 8 / NF 2:\n")
     print("| stream | " + " | ".join(keys) + " |")

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "minimap2-fpga_amd/csrc/chain_dp_tile.h")).read()
 
-TOKEN = re.compile(r'"((?:[^"\\]|\\.)*)"|(MM2C_[A-Z0-9_]+)(\(([^()]*)\))?|\b(SCORE|ADDF|R|CTRL|X|Q)\b')
+TOKEN = re.compile(r'"((?:[^"\\]|\\.)*)"|(MM2C_[A-Z0-9_]+)(\(([^()]*)\))?|\b(SCORE|ADDF|SEG_LK|SEG_HF|SEG_TAIL|SEG_END|R|CTRL|X|Q)\b')
 
 
 def logical_defines(src):
@@ -80,11 +80,13 @@ def classify(ins):
     return "other"
 
 
-def blocks(tab):
+def blocks(tab, far=False):
     params, body = DEFS["MM2C_SCAN_TILE_ASM"]
     body = body[body.index("asm volatile("):]
-    body = body[:body.index(": [best]")]
-    env = {"SCORE": "MM2C_SCORE_TAB" if tab else "MM2C_SCORE_CMP", "ADDF": "MM2C_ADDF_TAB" if tab else "MM2C_ADDF_CMP"}
+    body = body[:body.index(": [best]")].replace("SEG_END(SCORE)", "SEG_END")
+    v = "FAR" if far else "LEAN"
+    env = {"SCORE": "MM2C_SCORE_TAB" if tab else "MM2C_SCORE_CMP", "ADDF": "MM2C_ADDF_TAB" if tab else "MM2C_ADDF_CMP",
+           "SEG_LK": "MM2C_LK_" + v, "SEG_HF": "MM2C_HF_" + v, "SEG_TAIL": "MM2C_TAIL_" + v, "SEG_END": "MM2C_END_" + v}
     text = expand(body, env)
     out, cur = [], ("entry", [])
     for line in text.split("\n"):
@@ -124,10 +126,10 @@ def cut(instrs, until=None, after=None):
 
 
 if __name__ == "__main__":
-    tab = "--tab" in sys.argv
-    B = dict(blocks(tab))
-    order = [n for n, _ in blocks(tab)]
-    print(f"# Instruction budget of the hand-written anchor loop (`scan_tile_asm_{'tab' if tab else 'cmp'}`), from `tools/isa_budget.py`\n")
+    tab, far = "--tab" in sys.argv, "--far" in sys.argv
+    B = dict(blocks(tab, far))
+    order = [n for n, _ in blocks(tab, far)]
+    print(f"# Instruction budget of the hand-written anchor loop (`scan_tile_asm_{'tab' if tab else 'cmp'}{'_far' if far else ''}`), from `tools/isa_budget.py`\n")
     print("Classes as measured by `tools/ubench/issue_rate.hip` (`profiles/r2_issue_rate.md`): plain VALU ≈0.84 per SIMD and ns; VALU that involves the scalar side")
     print("(`v_cmp`, `v_readlane`/`v_writelane`, DPP, `v_cndmask` with an SGPR mask, `v_mbcnt`) and SALU ≈0.55; `ds_read` 0.29.\n")
     print("## Blocks between labels (straight-line instruction counts)\n")
@@ -148,8 +150,11 @@ if __name__ == "__main__":
     own = path(cut(cut(B["Lk"], after="s_cbranch_scc0 Lloop"), until="s_cbranch_scc0 Lloop"))
     empty = path(cut(B["Lloop"], until="s_cbranch_vccz"))
     # chunk with a surviving lane from the f / p ring, fold A (no lane beats the running best, no marked lane), back to the loop
-    scored = path(cut(B["Lloop"], after="s_cbranch_vccz"), cut(B["Lold"], until="s_branch Lfx"), cut(B["Lfx"], until="s_cbranch_scc1 Lhf"), cut(B["Lhf"], until="s_cbranch_scc0 Lmk"),
-                  cut(B["Lmk"], until="s_cbranch_scc0 Lret"), cut(B["Lret"], until="s_cbranch_scc0 Lloop"))
+    if far:
+        scored = path(cut(B["Lloop"], after="s_cbranch_vccz"), cut(B["Lold"], until="s_branch Lhf"), cut(B["Lhf"], until="s_cbranch_scc0 Lmk"),
+                      cut(B["Lmk"], until="s_cbranch_scc0 Lret"), cut(B["Lret"], until="s_cbranch_scc0 Lloop"))
+    else:
+        scored = path(cut(B["Lloop"], after="s_cbranch_vccz"), cut(B["Lold"], until="s_branch Lhf"), B["Lhf"], cut(B["Lmk"], until="s_cbranch_scc0 Lloop"))
     b1 = path(cut(B["Limp"], until="s_branch Lret"))
     b2 = path(cut(B["Limp"], until="s_cbranch_scc1 Lb2"), cut(B["Lb2"], until="s_branch Ltk"), cut(B["Ltk"], until="s_ff1"), B["Laf"][:2])
     print("\n## Paths\n")
