@@ -339,7 +339,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"s_mov_b64 exec, -1\n\t" \
-	"ds_read_u16 %[vb], %[vb]\n\t" \
+	"ds_read_u16 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
@@ -359,7 +359,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
 	"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
 	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-	"ds_read_u16 %[vb], %[vb]\n"
+	"ds_read_u16 %[vb], %[vb] offset:%[STOFF]\n"
 #define MM2C_TAIL_FAR \
 	"s_cbranch_scc0 Lret_%=\n\t" \
 	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
@@ -481,7 +481,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		MM2C_FILTER("%[tx]", "%[tq]") MM2C_FILTER2 \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
-		"s_mov_b32 %[base], %[i0]\n\t" \
+		"s_mov_b32 %[d], 0\n\t" \
 		"v_mov_b32 %[vf], %[own_f]\n\t" \
 		"v_mov_b32 %[vp], %[own_p]\n\t" \
 		"v_mov_b32 %[vb], %[ownst]\n\t" \
@@ -496,29 +496,15 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b64 %[valid], vcc\n\t" \
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
-		"s_lshl_b32 %[t0], %[d], 6\n\t" \
-		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
-		"s_and_b32 %[t0], %[base], %[RMASK]\n\t" \
-		"v_lshl_add_u32 %[vb], %[t0], 1, %[own2s]\n\t" \
+		"v_add_u32 %[vb], 0x200, %[addr]\n\t" \
+		"v_bfe_u32 %[vb], %[vb], 1, %[RBBITS]\n\t" \
 		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
 		"s_cbranch_scc1 Lfg_%=\n\t" \
-		"v_lshl_add_u32 %[u2], %[t0], 2, %[rl4]\n\t" \
-		"v_and_b32 %[u2], %[FMASK], %[u2]\n\t" \
+		"v_and_b32 %[u2], %[FMASK], %[addr]\n\t" \
 		"ds_read_b32 %[vp], %[u2] offset:%[POFF]\n\t" \
 		"ds_read_b32 %[vf], %[u2] offset:%[FOFF]\n\t" \
 		SCORE \
-		"s_waitcnt lgkmcnt(0)\n\t" \
-		"s_branch Lhf_%=\n" \
-		"Lfg_%=:\n\t" \
-		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
-		"v_max_i32 %[u2], 0, %[u2]\n\t" \
-		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
-		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
-		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
-		SCORE \
-		"s_waitcnt vmcnt(0)\n" \
-		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
-		"v_max_i32 %[vp], -1, %[vp]\n" \
+		"s_waitcnt lgkmcnt(0)\n" \
 		"Lhf_%=:\n\t" \
 		SEG_HF \
 		"Lmk_%=:\n\t" \
@@ -530,6 +516,19 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n\t" \
 		"s_cbranch_vccnz Limp_%=\n\t" \
 		SEG_TAIL \
+		"Lfg_%=:\n\t" \
+		"s_lshl_b32 %[t0], %[d], 6\n\t" \
+		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+		"v_max_i32 %[u2], 0, %[u2]\n\t" \
+		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
+		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+		SCORE \
+		"s_waitcnt vmcnt(0)\n\t" \
+		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
+		"v_max_i32 %[vp], -1, %[vp]\n\t" \
+		"s_branch Lhf_%=\n" \
 		"Lpart_%=:\n\t" \
 		"s_mov_b32 %[n], 0\n\t" \
 		"s_cmp_eq_u32 %[part], 0\n\t" \
@@ -542,8 +541,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lend_%=\n\t" \
 		"s_add_i32 %[d], %[nfull], 1\n\t" \
+		"v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" \
+		"v_and_b32 %[addr], %[RBM1], %[addr]\n\t" \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
+		"s_lshl_b32 %[t0], %[d], 6\n\t" \
+		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
 		"v_readlane_b32 %[t1], %[sc], %[t0]\n\t" \
 		"s_cmp_gt_i32 %[t1], %[best]\n\t" \
@@ -692,7 +695,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tbef] "v"(tbef), [tw] "v"(tw), [ts16] "v"(ts16), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [own2s] "v"(own2s), [rl4] "v"(rl4), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
-		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc"); \
 	return 63 - L; \
 }
@@ -714,6 +717,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
               int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
 {
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
+	static_assert(512 % (NF * 256) == 0, "the hand-written loop takes a tile's f / p ring slot from the x / q ring address two tiles further on");
 	typedef Lds<NX, NF, GEN, TAB> LY;
 	constexpr int SN = LY::SN;
 	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...
@@ -833,7 +837,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
 		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);
-		const int s16_l = 1 + (idx & 0x3fff), ownst = LY::ST + ((idx & (SN - 1)) << 1);
+		const int s16_l = 1 + (idx & 0x3fff), ownst = (idx & (SN - 1)) << 1;   // LDS stamp; byte offset of the anchor's slot in the stamp ring
 		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
 		for (int k = 0; k < cnt; ++k) {
