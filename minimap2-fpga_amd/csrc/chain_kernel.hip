@@ -43,6 +43,7 @@
 // with -ffp-contract=off and uses __dmul_rn/__dadd_rn so no FMA is ever formed.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -606,7 +607,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	// the gap-cost table of the tile kernel: dd <= bw <= 511 entries of int16 (cost <= 2.55 * 511 + 4, times gap_scale)
 	// used when gap_scale != 1 (it takes the f64 path of chain.c:219 out of the loop); with gap_scale 1 computing the cost is as fast and the
 	// kernel's LDS stays at 6 KB (measured: 62.8 vs 66.3 ms on the headline batch)
-	const bool tab = tile && !gs1 && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
+	static const bool force_tab = getenv("MM2C_FORCE_TAB") != nullptr;   // experiment switch: the table also for gap_scale == 1
+	const bool tab = tile && (!gs1 || force_tab) && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
