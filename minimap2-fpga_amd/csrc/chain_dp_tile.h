@@ -80,7 +80,7 @@ struct AnchorCtx {
 	int xi1, qi1;            // x_i - 1, q_i - 1 (so that dr - 1 and dq - 1 come out of one subtraction each)
 	int span_i, seg_i;
 	int lo;                  // start of the window (chain.c:192-193)
-	int stamp, s16;          // i + 1 (global scratch t[]), 1 + i % 16384 (LDS stamp ring)
+	int stamp, s16;          // i + 1 (global scratch t[]), 1 + i % 1024 (LDS stamp ring)
 	int stamp_lo;            // oldest anchor whose stamp slot is in the LDS ring
 	int far_mode;            // the window reaches beyond the LDS ring (FAR variants)
 	float avg;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // max_skip on, one segment, max_dq - 1 >= bw; gap cost computed (gap_scale 1) or read from the per-task table.  One instruction sequence
 // per TILE: anchors k_start .. of the tile with first anchor i0, one after the other; lane L = 63 - k holds anchor i0 + k in the per-tile
 // registers: tx / tq = x, q; tx1 / tq1 = x - 1, q - 1; tspan = span; tlo = window start, tbef = anchors of older tiles inside the window
-// (both clamped to what the ring holds); ts16 = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
+// (both clamped to what the ring holds; tbef travels in bits 15-23 of tw); tb16 - L = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
 // all, bit 30: window clamped, bit 31: anchor not handled here.  Results go into the anchor's lane of own_f / own_p.  Returns the position
 // of the first anchor it did not process (cnt when the tile is done, else a bit-31 anchor).  A clamped window that the ring part of the scan
 // does not end (no `break` of chain.c:231) goes on tile by tile from L2 / HBM: x, q from the anchor array, f / p from the task's own
@@ -323,7 +323,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // (bit 30 of its tw word): stamps with a target before the ring go to the global scratch, and a scan that runs through the whole ring without
 // the `break` goes on from memory (bit 28 set at run time).  `lean`: no such anchor in the tile, so nothing of that is tested; the stamp store
 // needs no exec mask either: lanes that must not stamp (filtered out, or p before the window) write the slot of anchor lo - 1 instead, which
-// no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (slots are compared with 1 + i mod 16384).
+// no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (slots are compared with 1 + i mod 1024, a slot lives for 64 NX anchors).
 #define MM2C_LK_FAR \
 	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
 	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t"
@@ -443,7 +443,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
-                                    int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tbef, int tw, int ts16, int &own_f, int &own_p, \
+                                    int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int tb16, int &own_f, int &own_p, \
                                     int addr1, int ownst, int own2s, int rl4, int rl, int mdqbw_v, int bw_v, int sent_v) \
 { \
 	typedef Lds<NX, NF, false, TABV> LY; \
@@ -462,10 +462,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_bitcmp1_b32 %[pk], 29\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
 		SEG_LK \
-		"v_readlane_b32 %[nfull], %[tbef], %[L]\n\t" \
+		"s_bfe_u32 %[nfull], %[pk], 0x9000f\n\t" \
 		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
 		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
-		"v_readlane_b32 %[s16], %[ts16], %[L]\n\t" \
+		"s_sub_i32 %[s16], %[tb16], %[L]\n\t" \
 		"v_mov_b32 %[addr], %[addr1]\n\t" \
 		MM2C_NEXT_XQ \
 		"s_add_i32 %[span1], %[best], -1\n\t" \
@@ -692,7 +692,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
-		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tbef] "v"(tbef), [tw] "v"(tw), [ts16] "v"(ts16), \
+		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), [tb16] "s"(tb16), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [own2s] "v"(own2s), [rl4] "v"(rl4), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
@@ -831,19 +831,19 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		const mask_t above = ~(eq_prev >> lane);                  // bit 0: this anchor's x differs from its predecessor's, bit 1: the predecessor's from ...
 		const int e_l = above ? (int)__builtin_ctzll(above) : 64;
 		const int w_l = min(rl, idx - lo_l);                      // own-tile predecessors inside the window: lanes lane + 1 .. lane + w
-		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8);   // bits 0-5: lanes to scan, bits 8-14: the first of them
+		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);   // the window clamped to what the ring holds; its anchors in older tiles (<= 64 (NX - 1))
+		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);   // bits 0-5: lanes to scan, bits 8-14: the first of them, bits 15-23: bef
 		if (lo_l >= idx) tw_l |= 1 << 29;
 		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
-		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);
-		const int s16_l = 1 + (idx & 0x3fff), ownst = (idx & (SN - 1)) << 1;   // LDS stamp; byte offset of the anchor's slot in the stamp ring
+		const int ownst = (idx & (SN - 1)) << 1;              // byte offset of the anchor's slot in the stamp ring
 		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 lo_l, bef_l, tw_l, s16_l, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v)
+                                 lo_l, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v)
 				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far) : MM2C_CALL(scan_tile_asm_cmp_far);
 				else k = TAB ? MM2C_CALL(scan_tile_asm_tab) : MM2C_CALL(scan_tile_asm_cmp);
 #undef MM2C_CALL
@@ -866,7 +866,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				}
 				X.xi1 = xi - 1; X.qi1 = qi - 1; X.span_i = span_i; X.span1_v = span_i - 1;
 				if (GEN) X.seg_i = rdlane(own_g, L);                                                 // chain.c:191
-				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + (i & 0x3fff); X.s16_v = X.s16;
+				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + (i & 1023); X.s16_v = X.s16;   // LDS stamps need to be unique over the life of a slot (64 NX anchors) only
 				X.far_mode = FAR && lo < stamp_lo;
 				if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
 				else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);

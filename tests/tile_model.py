@@ -63,7 +63,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                 e += 1
             if e:
                 S["eq_run_anchors"] += 1
-            s16 = 1 + (i & 0x3fff)
+            s16 = 1 + (i & 1023)
             broke = False
             base = i0
             while base + 63 >= lo and not broke:
