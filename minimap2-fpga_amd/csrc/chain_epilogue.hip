@@ -67,7 +67,16 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane)
 // Bytes in which all keys agree are skipped, so (score << 32 | index) keys cost about four passes.  Per 64 records: the lanes with
 // the same digit find each other with eight ballots; rank among them = position in lane order (stable).  `vals` may be NULL.
 // The result ends in (k1, v1).  No host involvement -- rocPRIM's segmented sort synchronises the stream on the host.
-template <bool DESC>
+// SOLO: the wave runs alone inside a bigger block (the other waves wait at the next __syncthreads): its own LDS and memory operations are
+// ordered by a workgroup fence, without the barrier.
+template <bool SOLO>
+__device__ __forceinline__ void sort_sync()
+{
+	if (SOLO) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+	else __syncthreads();
+}
+#define __syncthreads_sort() sort_sync<SOLO>()
+template <bool DESC, bool SOLO = false>
 __device__ void wave_sort64(uint64_t *k0, uint64_t *k1, int32_t *v0, int32_t *v1, int m, int lane, int *s_cnt /* 256 ints of LDS */)
 {
 	if (m <= 0) return;
@@ -80,22 +89,22 @@ __device__ void wave_sort64(uint64_t *k0, uint64_t *k1, int32_t *v0, int32_t *v1
 	for (int shift = 0; shift < 64; shift += 8) {
 		if (((diff >> shift) & 255) == 0) continue;
 		for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
-		__syncthreads();
+		__syncthreads_sort();
 		for (int i = lane; i < m; i += 64) {
 			const int d = (int)(src[i] >> shift) & 255;
 			atomicAdd(&s_cnt[DESC ? 255 - d : d], 1);
 		}
-		__syncthreads();
+		__syncthreads_sort();
 		{
 			int h[4], sum = 0;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) { h[k] = s_cnt[4 * lane + k]; sum += h[k]; }
 			int at = wave_incl_scan(sum, lane) - sum;
-			__syncthreads();
+			__syncthreads_sort();
 #pragma unroll
 			for (int k = 0; k < 4; ++k) { s_cnt[4 * lane + k] = at; at += h[k]; }
 		}
-		__syncthreads();
+		__syncthreads_sort();
 		for (int i0 = 0; i0 < m; i0 += 64) {
 			const int i = i0 + lane;
 			const bool valid = i < m;
@@ -115,9 +124,9 @@ __device__ void wave_sort64(uint64_t *k0, uint64_t *k1, int32_t *v0, int32_t *v1
 				dst[pos] = key;
 				if (vdst) vdst[pos] = val;
 			}
-			__syncthreads();
+			__syncthreads_sort();
 			if (valid && lanes_before(peers) == 0) s_cnt[d] += __popcll(peers);
-			__syncthreads();
+			__syncthreads_sort();
 		}
 		{ uint64_t *t = src; src = dst; dst = t; }
 		{ int32_t *t = vsrc; vsrc = vdst; vdst = t; }
@@ -125,13 +134,20 @@ __device__ void wave_sort64(uint64_t *k0, uint64_t *k1, int32_t *v0, int32_t *v1
 	if (src != k1) {                                                             // even number of passes: the result is in (k0, v0)
 		for (int i = lane; i < m; i += 64) { k1[i] = src[i]; if (v1) v1[i] = vsrc[i]; }
 	}
-	__syncthreads();
+	__syncthreads_sort();
 }
+
+#undef __syncthreads_sort
 
 // The three chunked passes below walk a task in chunks of W = 64*K anchors (K per lane), because the passes are sequential from chunk
 // to chunk (a chunk needs the finished values of the chunks before it) and every step costs a global-memory round trip: wide
 // chunks mean few steps.  Links that stay inside a chunk are resolved by pointer jumping through LDS (log2 W rounds at most).
 constexpr int K = 4, W = 64 * K;
+// tasks of at most FUSE_L anchors can keep their per-anchor state in LDS (epi_fused below): two size classes
+constexpr int FUSE_S = 5120, FUSE_L = 7680;        // 52.9 KB of LDS -> three tasks per CU; 78.8 KB -> two
+constexpr int NONE16 = 0xffff;
+constexpr int FNT = 512;                           // epi_fused: threads per task
+constexpr int NOT_MINE = 1 << 30;                   // rk2kk flag: the chain kept only its peak, which belongs to an earlier chain (chain.c:381-383)
 
 // ---- kernel A: v[], child marks, chain ends -> unsorted keys (chain.c:106-111, 349-367) -------------------------------
 __global__ __launch_bounds__(64) void epi_ends(EpiArgs A)
@@ -140,6 +156,7 @@ __global__ __launch_bounds__(64) void epi_ends(EpiArgs A)
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
+	if (A.fused && n <= FUSE_L) return;                                          // epi_fused has it
 	const int lane = (int)threadIdx.x;
 	const int32_t *__restrict__ f = A.d_f + base, *__restrict__ p = A.d_p + base;
 	int32_t *v = A.v + base, *mark = A.own + base, *peak = A.ctop + base;
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
+	if (A.fused && n <= FUSE_L) return;
 	const int lane = (int)threadIdx.x;
 	const int nu = (int)(A.seg_end1[task] - (uint32_t)base);
 	const int32_t *__restrict__ f = A.d_f + base, *__restrict__ p = A.d_p + base;
@@ -361,6 +379,219 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 	wave_sort64<false>(rkey, A.rkey1 + base, val0, A.val1 + base, kept, lane, s_val);
 }
 
+
+// ---- the passes of kernels A and B for a task that fits the LDS -------------------------------------------------------------------------
+// Kernels A and B move every per-anchor quantity (marks, v, peaks, owners, depths) through global scratch arrays several times: 156 bytes
+// of HBM traffic per anchor against 8 bytes of input (profiles/r1_seed_hits.md).  For a task of at most CAP anchors the same passes run
+// with those arrays in LDS (indices fit 16 bits): parent 2 B, v / owner 4 B, peak / depth 2 B, child mark 1 bit per anchor.  Global traffic
+// is then f and p once, the chain records (per chain, not per anchor) and one word per anchor for kernel C: (chain << 16 | depth), or -1.
+
+template <int CAP>
+__global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
+{
+	static_assert(CAP % 64 == 0 && CAP < NONE16, "indices and NONE16 in 16 bits");
+	// one 8-byte cell per anchor, read and written whole (so that another wave sees a consistent pair), used three times:
+	//   v / peaks:  low = running maximum of f over the path walked so far, high = position of that maximum << 16 | next ancestor to visit
+	//   owners:     low = owner (rank of the chain that takes the anchor),  high = jump pointer of the doubling rounds
+	//   depths:     low = owner,                                            high = links counted so far << 16 | next ancestor to visit
+	// and in between as the two buffers of the sorts
+	__shared__ uint64_t s_a[CAP];
+	__shared__ uint16_t s_p[CAP];                   // parent (NONE16: none)
+	__shared__ uint32_t s_mark[CAP / 32];           // has a child (chain.c:350)
+	__shared__ int s_cnt[256];
+	__shared__ int s_n;
+	int *const s_w = (int *)s_a;                    // word 2i = low, 2i + 1 = high
+	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	const int64_t base = A.d_off[task];
+	const int n = (int)(A.d_off[task + 1] - base);
+	if (n > CAP || n <= n_above) return;            // another class, or kernels A / B
+	const int tid = (int)threadIdx.x, lane = tid & 63;
+	const bool wave0 = tid < 64;
+	const int32_t *__restrict__ f = A.d_f + base, *__restrict__ p = A.d_p + base;
+	if (tid == 0) { A.seg_begin[task] = (uint32_t)base; s_n = 0; }
+	if (A.debug_phases && tid == 0) { A.seg_end1[task] = (uint32_t)base; A.seg_end2[task] = (uint32_t)base; A.cnt_u[task] = 0; A.cnt_b[task] = 0; }   // development aid: cut after phase N
+	for (int w = tid; w < (n + 31) / 32; w += FNT) s_mark[w] = 0;
+	__syncthreads();
+	for (int i = tid; i < n; i += FNT) {
+		const int pi = p[i];
+		const int q = pi < 0 ? NONE16 : pi;
+		s_p[i] = (uint16_t)q;
+		if (pi >= 0) atomicOr(&s_mark[pi >> 5], 1u << (pi & 31));
+		s_a[i] = (uint64_t)(uint32_t)(i << 16 | q) << 32 | (uint32_t)f[i];
+	}
+	__syncthreads();
+	if (A.debug_phases == 1) return;
+	// ---- v[] and peaks by pointer jumping over the whole task, every thread at its own pace.  peak[i], the first anchor on the way up with
+	// f >= v (chain.c:360-361), is the NEAREST ancestor-or-self whose f equals the maximum over the path (everything nearer has f < v[i] = its
+	// own v; there f = v): a running (maximum, nearest position of it), which composes over path segments.  A cell always describes the path
+	// from its anchor up to (excluding) `next`; cells are read and written in one piece, so whatever state another cell is in, appending it is valid.
+	for (;;) {
+		bool again = false;
+		for (int i = tid; i < n; i += FNT) {
+			const uint64_t e = s_a[i];
+			const int nxt = (int)(e >> 32) & 0xffff;
+			if (nxt == NONE16) continue;
+			const uint64_t q = __hip_atomic_load(&s_a[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // another thread's cell, in one piece
+			int v = (int32_t)e, pk = (int)(e >> 48);
+			if ((int32_t)q > v) { v = (int32_t)q; pk = (int)(q >> 48); }
+			const int nn = (int)(q >> 32) & 0xffff;
+			__hip_atomic_store(&s_a[i], (uint64_t)(uint32_t)(pk << 16 | nn) << 32 | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			again |= nn != NONE16;
+		}
+		if (!again) break;
+	}
+	__syncthreads();
+	if (A.debug_phases == 2) return;
+	// ---- chain ends -> keys f[peak] << 32 | peak with f[peak] = v (any order: they are sorted next), collected in the cells' place
+	{
+		constexpr int KE = CAP / FNT;
+		uint64_t key[KE]; bool is_end[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const int i = tid + FNT * k;
+			is_end[k] = i < n && !((s_mark[i >> 5] >> (i & 31)) & 1) && (int32_t)s_a[i < n ? i : 0] >= A.min_sc;   // chain.c:352
+			key[k] = is_end[k] ? (s_a[i] << 32 | s_a[i] >> 48) : 0;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const uint64_t m = __ballot(is_end[k]);
+			int at = 0;
+			if (m != 0 && lane == 0) at = atomicAdd(&s_n, __popcll(m));
+			at = __shfl(at, 0);
+			if (is_end[k]) s_a[at + lanes_before(m)] = key[k];
+		}
+	}
+	__syncthreads();
+	const int nu = s_n;
+	if (A.debug_phases == 3) return;
+	int32_t *ctop = A.ctop + base, *rk2kk = A.rk2kk + base, *val0 = A.val0 + base;
+	uint64_t *us = A.key1 + base;
+	uint64_t *u2 = A.u2 + base, *rkey = A.key0 + base;
+	if (wave0) {
+		if (lane == 0) A.seg_end1[task] = (uint32_t)(base + nu);
+		// chain.c:368-372: best peak first.  In LDS while both buffers fit beside each other, else through global memory
+		if (nu <= CAP / 2) wave_sort64<true, true>(s_a, s_a + CAP / 2, nullptr, nullptr, nu, lane, s_cnt);
+		else {
+			for (int r = lane; r < nu; r += 64) rkey[r] = s_a[r];
+			wave_sort64<true, true>(rkey, us, nullptr, nullptr, nu, lane, s_cnt);
+		}
+	}
+	__syncthreads();
+	if (nu <= CAP / 2) for (int r = tid; r < nu; r += FNT) us[r] = s_a[CAP / 2 + r];
+	__syncthreads();
+	if (A.debug_phases == 4) return;
+	// ---- owners: owner(x) = min rank over the peaks in the subtree of x, pushed towards the roots in doubling rounds
+	for (int i = tid; i < n; i += FNT) s_a[i] = (uint64_t)(uint32_t)(s_p[i] == NONE16 ? -1 : (int)s_p[i]) << 32 | (uint32_t)NONE;
+	__syncthreads();
+	for (int r = tid; r < nu; r += FNT) atomicMin(&s_w[2 * (int32_t)us[r]], r);   // a peak listed twice belongs to the first listing
+	__syncthreads();
+	{
+		// round t: every anchor pushes what has reached it to its 2^t-th ancestor, then its jump pointer doubles.  A value that arrives early
+		// (a push of the same round that lands before the anchor reads its own cell) is still the rank of a peak below it: harmless
+		constexpr int KE = CAP / FNT;
+		int up[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; up[k] = i < n ? s_w[2 * i + 1] : -1; }
+		for (;;) {
+			bool open = false;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) open |= up[k] >= 0;
+			if (!__syncthreads_or(open)) break;         // also: the jump pointers written at the end of the round before are in place
+#pragma unroll
+			for (int k = 0; k < KE; ++k)
+				if (up[k] >= 0) {
+					const int acc = __hip_atomic_load(&s_w[2 * (tid + FNT * k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (acc != NONE) atomicMin(&s_w[2 * up[k]], acc);
+					up[k] = s_w[2 * up[k] + 1];
+				}
+			__syncthreads();                              // all jump pointers read before any is replaced
+#pragma unroll
+			for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; if (i < n) s_w[2 * i + 1] = up[k]; }
+		}
+	}
+	__syncthreads();
+	if (A.debug_phases == 5) return;
+	// ---- depth inside the owner path (links to the path's top) and the top of every path: pulled, like v
+	for (int i = tid; i < n; i += FNT) {
+		const int o = s_w[2 * i], pi = s_p[i];
+		const bool claimed = o != NONE, link = claimed && pi != NONE16 && s_w[2 * pi] == o;
+		if (claimed && !link) ctop[o] = i;
+		s_w[2 * i + 1] = link ? (1 << 16 | pi) : NONE16;
+	}
+	__syncthreads();
+	for (;;) {
+		bool again = false;
+		for (int i = tid; i < n; i += FNT) {
+			const int e = s_w[2 * i + 1], nxt = e & 0xffff;
+			if (nxt == NONE16) continue;
+			const int q = __hip_atomic_load(&s_w[2 * nxt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), nn = q & 0xffff;
+			__hip_atomic_store(&s_w[2 * i + 1], (int)(((unsigned)e >> 16) + ((unsigned)q >> 16)) << 16 | nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			again |= nn != NONE16;
+		}
+		if (!again) break;
+	}
+	__syncthreads();
+	if (A.debug_phases == 6) return;
+	// ---- one lane per chain, in rank order (chain.c:377-389): the first wave alone
+	if (wave0) {
+		int kept = 0, n_b = 0;
+		for (int r0 = 0; r0 < nu; r0 += 64) {
+			const int r = r0 + lane;
+			const bool valid = r < nu;
+			bool keep = false, mine = false;
+			int len = 0, sc = 0, top = 0;
+			if (valid) {
+				const uint64_t key = us[r];
+				const int j = (int32_t)key, peak = (int32_t)(key >> 32);
+				mine = s_w[2 * j] == r;
+				len = mine ? (int)((unsigned)s_w[2 * j + 1] >> 16) + 1 : 1;
+				top = mine ? ctop[r] : j;
+				const int stop = s_p[top] == NONE16 ? -1 : (int)s_p[top];
+				sc = stop < 0 ? peak : peak - f[stop];
+				keep = (stop < 0 || sc >= A.min_sc) && len >= A.min_cnt;
+			}
+			const uint64_t m = __ballot(keep);
+			const int kk = kept + lanes_before(m);
+			if (keep) {
+				u2[kk] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)len;
+				rkey[kk] = A.d_a[base + top].x;
+				val0[kk] = kk;
+			}
+			if (valid) rk2kk[r] = keep ? (mine ? kk : kk | NOT_MINE) : -1;
+			kept += __popcll(m);
+			n_b += wave_sum(keep ? len : 0);
+		}
+		if (lane == 0) {
+			A.seg_end2[task] = (uint32_t)(base + kept);
+			A.cnt_u[task] = kept;
+			A.cnt_b[task] = n_b;
+			s_n = kept;
+		}
+	}
+	__syncthreads();
+	if (A.debug_phases == 7) return;
+	// what kernel C needs per anchor: the kept chain that takes it and its position inside that chain
+	int32_t *cd = A.own + base;
+	for (int i = tid; i < n; i += FNT) {
+		const int o = s_w[2 * i];
+		const int kk = o != NONE ? rk2kk[o] : -1;        // the owner of an anchor is always `mine` for it: no flag
+		cd[i] = kk >= 0 ? (kk << 16 | (int)((unsigned)s_w[2 * i + 1] >> 16)) : -1;
+	}
+	// chain.c:406-411: chains by the x of their first anchor (stable here; kernel T replays the reference's sort where that matters)
+	__syncthreads();                                  // the cells are free again
+	if (wave0) {
+		const int nk = s_n;
+		if (nk <= CAP / 3) {                            // keys and values of both buffers fit the cells' space
+			uint64_t *k0 = s_a, *k1 = s_a + CAP / 3;
+			int32_t *v0 = (int32_t *)(s_a + 2 * (CAP / 3)), *v1 = v0 + CAP / 3;
+			for (int i = lane; i < nk; i += 64) { k0[i] = rkey[i]; v0[i] = i; }
+			wave_sort64<false, true>(k0, k1, v0, v1, nk, lane, s_cnt);
+			for (int i = lane; i < nk; i += 64) { A.rkey1[base + i] = k1[i]; A.val1[base + i] = v1[i]; }
+		} else wave_sort64<false, true>(rkey, A.rkey1 + base, val0, A.val1 + base, nk, lane, s_cnt);
+	}
+}
+
 // ---- exclusive scans of the per-task chain / anchor counts -> compact output offsets ---------------------------------------
 __global__ __launch_bounds__(1024) void epi_offsets(EpiArgs A)
 {
@@ -431,6 +662,7 @@ __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 	const int64_t base = A.d_off[task];
 	const int n = (int)(A.d_off[task + 1] - base);
 	const int lane = (int)threadIdx.x;
+	if (A.fused && n <= FUSE_L) return;                                          // epi_emit_cd has it
 	const int nu = (int)(A.seg_end1[task] - (uint32_t)base), nk = (int)(A.seg_end2[task] - (uint32_t)base);
 	if (nk == 0) return;
 	const int32_t *own = A.own + base, *dep = A.v + base, *rk2kk = A.rk2kk + base;
@@ -475,6 +707,56 @@ __global__ __launch_bounds__(64) void epi_emit(EpiArgs A)
 	}
 }
 
+
+// ---- kernel C for the tasks of epi_fused: b[] from one word per anchor ------------------------------------------------------------------
+__global__ __launch_bounds__(64) void epi_emit_cd(EpiArgs A)
+{
+	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	const int64_t base = A.d_off[task];
+	const int n = (int)(A.d_off[task + 1] - base);
+	if (n > FUSE_L) return;                                                      // kernel C proper
+	const int lane = (int)threadIdx.x;
+	const int nu = (int)(A.seg_end1[task] - (uint32_t)base), nk = (int)(A.seg_end2[task] - (uint32_t)base);
+	if (nk == 0) return;
+	const int32_t *cd = A.own + base, *rk2kk = A.rk2kk + base;
+	int32_t *dest = A.dest + base;
+	const int32_t *ord = A.val1 + base;
+	const uint64_t *u2 = A.u2 + base, *us = A.key1 + base;
+	uint64_t *u_out = A.u_out + A.u_off[task];
+	ulonglong2 *b_out = A.b_out + A.b_off[task];
+	const int n_b = (int)(A.b_off[task + 1] - A.b_off[task]);
+	int run = 0;
+	for (int i0 = 0; i0 < nk; i0 += 64) {
+		const int i = i0 + lane;
+		const bool valid = i < nk;
+		const int kk = valid ? ord[i] : 0;
+		const uint64_t uu = valid ? u2[kk] : 0;
+		const int len = valid ? (int32_t)uu : 0;
+		const int incl = wave_incl_scan(len, lane);
+		if (valid) { dest[kk] = run + incl - len; u_out[i] = uu; }
+		run += __shfl(incl, 63);
+	}
+	__syncthreads();
+	for (int i0 = 0; i0 < n; i0 += W) {
+		int at[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = i0 + lane + 64 * k;
+			const int c = i < n ? cd[i] : -1;
+			at[k] = c >= 0 ? dest[c >> 16] + (c & 0xffff) : -1;                    // ascending along the chain (chain.c:399-400)
+		}
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			if (at[k] >= 0 && at[k] < n_b) b_out[at[k]] = A.d_a[base + i0 + lane + 64 * k];
+	}
+	for (int r = lane; r < nu; r += 64) {                                        // chains that kept only their (already taken) peak
+		const int kk = rk2kk[r];
+		if (kk < 0 || !(kk & NOT_MINE)) continue;
+		const int at = dest[kk & ~NOT_MINE];
+		if (at >= 0 && at < n_b) b_out[at] = A.d_a[base + (int32_t)us[r]];
+	}
+}
+
 } // namespace
 
 size_t epilogue_sort_temp_bytes(int64_t, int64_t) { return 0; }   // the sorts run inside epi_claim (wave_sort64); no library scratch
@@ -484,16 +766,26 @@ hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launch
 	if (A.n_tasks <= 0) return hipSuccess;
 	const unsigned nt = (unsigned)A.n_tasks;
 	hipError_t e;
-	hipLaunchKernelGGL(epi_ends, dim3(nt), dim3(64), 0, st, A);
-	if ((e = hipGetLastError()) != hipSuccess) return e;
-	hipLaunchKernelGGL(epi_claim, dim3(nt), dim3(64), 0, st, A);
-	if ((e = hipGetLastError()) != hipSuccess) return e;
+	// tasks that fit the LDS (two size classes) take the fused kernel; the others kernels A, B, C.  max_task < 0: sizes known to the device only
+	const bool fused = A.fused != 0, small = fused, large = fused && (A.max_task < 0 || A.max_task > FUSE_S),
+	           huge = !fused || A.max_task < 0 || A.max_task > FUSE_L;
+	int nl = 2;
+	if (small) { hipLaunchKernelGGL(epi_fused<FUSE_S>, dim3(nt), dim3(FNT), 0, st, A, -1); ++nl; if ((e = hipGetLastError()) != hipSuccess) return e; }
+	if (large) { hipLaunchKernelGGL(epi_fused<FUSE_L>, dim3(nt), dim3(FNT), 0, st, A, FUSE_S); ++nl; if ((e = hipGetLastError()) != hipSuccess) return e; }
+	if (huge) {
+		hipLaunchKernelGGL(epi_ends, dim3(nt), dim3(64), 0, st, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		hipLaunchKernelGGL(epi_claim, dim3(nt), dim3(64), 0, st, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		nl += 2;
+	}
 	hipLaunchKernelGGL(epi_offsets, dim3(1), dim3(1024), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_tiesort, dim3(nt), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	hipLaunchKernelGGL(epi_emit, dim3(nt), dim3(64), 0, st, A);
-	if (n_launches) *n_launches += 5;
+	if (fused) { hipLaunchKernelGGL(epi_emit_cd, dim3(nt), dim3(64), 0, st, A); ++nl; if ((e = hipGetLastError()) != hipSuccess) return e; }
+	if (huge) { hipLaunchKernelGGL(epi_emit, dim3(nt), dim3(64), 0, st, A); ++nl; }
+	if (n_launches) *n_launches += nl;
 	return hipGetLastError();
 }
 

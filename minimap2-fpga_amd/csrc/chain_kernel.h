@@ -55,60 +55,9 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 // ev_dp_begin (optional) is recorded between the window-start prepass and the DP kernel
 hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin);
 
-// ---- device epilogue of mm_chain_dp (chain.c:106-111,348-422), chain_epilogue.hip ----
-struct EpiArgs {
-	int64_t n_tasks, total;
-	const int64_t *d_off;       // n_tasks+1, CSR (task 0 at 0)
-	const int32_t *d_order;     // longest task first, or nullptr
-	const ulonglong2 *d_a;      // anchors
-	const int32_t *d_f, *d_p;   // DP result
-	int32_t min_cnt, min_sc;
-	int32_t debug_phases;       // development aid (MM2C_EPI_PHASES): kernels return after that many of their phases; 0 = run everything
-	// scratch, `total` entries each unless noted
-	int32_t *v;                 // v[] (chain.c:106-111), later the depth of an anchor inside its chain
-	int32_t *own;               // child marks, later the rank of the chain that takes the anchor
-	int32_t *ctop, *rk2kk, *dest, *val0, *val1;
-	uint64_t *key0, *key1;      // chain-end keys (f[peak]<<32 | peak) unsorted / sorted; key0 is reused for the first-x keys
-	uint64_t *u2, *rkey1;       // score<<32|count per kept chain; first-x keys sorted
-	uint32_t *seg_begin, *seg_end1, *seg_end2;   // per task: segment bounds for the two sorts
-	int32_t *cnt_u, *cnt_b;     // per task: kept chains, their anchors
-	void *sort_tmp; size_t sort_tmp_bytes;
-	// outputs (compact): chains of task k are u_out[u_off[k] .. u_off[k+1]), their anchors b_out[b_off[k] .. b_off[k+1])
-	int64_t *u_off, *b_off;     // n_tasks+1 each
-	uint64_t *u_out;
-	ulonglong2 *b_out;
-};
-size_t epilogue_sort_temp_bytes(int64_t total, int64_t n_tasks);
-hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launches);
-
-// ---- seed hits -> sorted anchors (collect_seed_hits, map.c:215-247), seed_hits.hip ----
-struct Match { int64_t cr_off; uint32_t n, q_pos, q_span, seg_tandem; };   // = mm2c_match_t
-struct SeedArgs {
-	int64_t n_reads;
-	const int64_t *d_match_off, *d_anchor_off;   // n_reads+1 each
-	const int32_t *d_order;                      // reads by anchor count, biggest first, or nullptr
-	const Match *d_matches;
-	const uint64_t *d_hits;                      // the hit pool the matches point into
-	int64_t n_hits = 0;                          // its length when the caller declared it (0: matches are trusted)
-	// skip_seed (map.c:122-147): flag = MM_F_NO_DIAG 0x1 | MM_F_NO_DUAL 0x2 | MM_F_FOR_ONLY 0x100000 | MM_F_REV_ONLY 0x200000 (0: every hit is kept);
-	// names as ranks: per reference sequence the rank of its name and its length, per read q_lo / q_eq (include/mm2chain.h)
-	int32_t skip_flag = 0;
-	const int32_t *d_ref_rank = nullptr, *d_ref_len = nullptr, *d_q_lo = nullptr, *d_q_eq = nullptr;
-	int32_t *d_count = nullptr;                  // per read: anchors kept (nullptr: all, the plan's offsets are exact)
-	int64_t *d_out_off = nullptr;                // n_reads + 1: where the packed result of each read starts (written by seed_offsets)
-	const int32_t *d_qlen;
-	ulonglong2 *unsorted, *scratch;              // anchors in expansion order; second buffer of the sorts
-	ulonglong2 *d_anchors;                       // out
-	int32_t *status, *has_ties;                  // per read; status must be zero on entry (1: hit counts and anchor offsets disagree)
-	uint64_t *xdiff;                             // per read: the bits of x that differ among its anchors (written by seed_expand)
-	int32_t *tiecnt;                             // per anchor: equal-x neighbours before this position of the sorted read
-	int64_t biggest;                             // anchors of the longest read
-	int32_t *stack;                              // pending buckets of the tie replay: 4 * (total / 64 + 2 * n_reads + 2) ints
-	uint32_t *big_id; uint8_t *big_dg;           // replay arrays for reads too long for the LDS (nullptr when there is none)
-};
-int seed_tie_lds_max();
-// aux: three helper streams (or nullptr: everything on st), ev: four events without timing
-hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev);
-
 } // namespace mm2c
+
+// argument blocks of the kernels around the DP (device epilogue, seed hits); kept in a file of their own because this header and the DP kernel
+// sources are what profiles/traffic.json is tied to by hash
+#include "chain_aux.h"
 #endif

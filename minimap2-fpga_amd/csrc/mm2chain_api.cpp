@@ -325,6 +325,8 @@ int mm2c_init(int device_ordinal)
 	if (G.devices.empty()) G.devices.assign(1, dev);
 	const char *rc = getenv("MM2C_RING_CLASS");
 	G.ring_class = rc ? std::max(0, std::min(3, atoi(rc))) : 3;
+	const char *ef = getenv("MM2C_EPI_FUSED");           // 0: the device epilogue works in HBM for every task (kernels A, B, C)
+	if (ef) G.epi_fused = atoi(ef) != 0;
 	G.ready = true;
 	return 0;
 }
@@ -405,6 +407,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "ring_class") == 0) {
 		if (value < 0 || value > 3) return fail(MM2C_E_ARG, "ring_class must be 0, 1, 2 or 3");
 		G.ring_class = value;
+		return 0;
+	}
+	if (strcmp(key, "epi_fused") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "epi_fused must be 0 or 1");
+		G.epi_fused = value;
 		return 0;
 	}
 	if (strcmp(key, "pipeline_chunk_anchors") == 0) {
@@ -657,6 +664,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	E.n_tasks = pl->n_tasks; E.total = pl->total; E.d_off = pl->d_off_user ? pl->d_off_user : pl->d_off; E.d_order = pl->d_order;
 	E.d_a = (const ulonglong2 *)d_anchors; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
 	E.debug_phases = epilogue_debug_phases();
+	E.fused = G.epi_fused.load(); E.max_task = pl->sizes_desc.empty() ? -1 : (int64_t)pl->sizes_desc[0];
 	E.u_off = d_u_off; E.b_off = d_b_off; E.u_out = d_u; E.b_out = (ulonglong2 *)d_b;
 	int nl = 0;
 	HIP_TRY(hipEventRecord(pl->ev_e0, st));

@@ -401,6 +401,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		E.n_tasks = (int64_t)nt; E.total = (int64_t)tot; E.d_off = L.d_offsets; E.d_order = L.d_order;
 		E.d_a = (const ulonglong2 *)w.d_in; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
 		E.debug_phases = epilogue_debug_phases();
+		E.fused = G.epi_fused.load(); E.max_task = -1;
 		E.u_off = (int64_t *)w.d_res; E.b_off = (int64_t *)(w.d_res + o_boff);
 		E.u_out = (uint64_t *)(w.d_res + w.o_res_u); E.b_out = (ulonglong2 *)(w.d_res + w.o_res_b);
 		HIP_TRY(mm2c::launch_chain_epilogue(E, w.st, &nl));

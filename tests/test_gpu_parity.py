@@ -408,6 +408,15 @@ def _assert_chains(res, P, min_cnt, min_sc, off, a, what):
     return n_chains
 
 
+@pytest.fixture(params=[1, 0], ids=["epi-lds", "epi-hbm"])
+def epi_path(request):
+    """the two forms of the device epilogue: tasks that fit the LDS in the fused kernel (default), or kernels A / B / C for every task"""
+    import mm2chain
+    mm2chain.tune("epi_fused", request.param)
+    yield request.param
+    mm2chain.tune("epi_fused", 1)
+
+
 @pytest.mark.parametrize("epilogue_threads", [0, 1, 5])
 def test_batched_mm_chain_dp_equals_task_by_task_calls(epilogue_threads):
     """mm2c_mm_chain_dp_batch_host (0: DP + epilogue on the GPU; > 0: epilogue on host threads) against the oracle's
@@ -442,7 +451,7 @@ def test_batched_mm_chain_dp_pipelined_in_chunks():
 
 
 @pytest.mark.parametrize("min_cnt,min_sc", [(1, 0), (1, 40), (2, 15), (3, 100), (5, 1000), (0, -5)])
-def test_device_epilogue_filter_corners(min_cnt, min_sc):
+def test_device_epilogue_filter_corners(min_cnt, min_sc, epi_path):
     """chain.c:385-388 with thresholds that keep one-anchor chains (incl. chains that keep only an already taken peak) or
     drop nearly everything"""
     import mm2chain
@@ -453,7 +462,7 @@ def test_device_epilogue_filter_corners(min_cnt, min_sc):
     _assert_chains(res, P, min_cnt, min_sc, off, a, f"min_cnt={min_cnt} min_sc={min_sc}")
 
 
-def test_device_epilogue_on_dense_and_colinear_streams():
+def test_device_epilogue_on_dense_and_colinear_streams(epi_path):
     import mm2chain
     from mm2chain import params
     P = params.map_ont()
@@ -461,6 +470,23 @@ def test_device_epilogue_on_dense_and_colinear_streams():
         off, a = _stream(profile, 6, (1000, 5000), seed=seed)
         res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
         _assert_chains(res, P, 3, 40, off, a, profile)
+
+
+def test_device_epilogue_size_classes_in_one_batch():
+    """tasks of every size class of the device epilogue in one batch (LDS classes up to 5120 and 8192 anchors, beyond that the kernels that
+    work in HBM), in an order that is not by size; chains against the oracle's mm_chain_dp"""
+    import mm2chain
+    from mm2chain import params, synth
+    P = params.map_ont()
+    sizes = [300, 9000, 5120, 6000, 12, 7680, 5121, 20000, 0, 4000, 7681]
+    parts, off = [], [0]
+    for k, n in enumerate(sizes):
+        if n:
+            parts.append(synth.make_stream(("mixed", "dense", "colinear")[k % 3], 1, n, seed=300 + k)[1].numpy().view(np.uint64))
+        off.append(off[-1] + n)
+    off = np.array(off, np.int64); a = np.concatenate(parts)
+    res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
+    assert _assert_chains(res, P, 3, 40, off, a, "size classes") > 100
 
 
 def _tandem_task(n_groups, copies, seed):
@@ -477,7 +503,7 @@ def _tandem_task(n_groups, copies, seed):
     return pack(rows)
 
 
-def test_device_epilogue_equal_first_x_replays_the_reference_sort():
+def test_device_epilogue_equal_first_x_replays_the_reference_sort(epi_path):
     """more than 64 chains with equal first-anchor x: the order is that of radix_sort_128x's passes (ksort.h:101-151), which
     is not stable; also <= 64 chains with ties (insertion sort, stable) and > 64 chains without ties"""
     import mm2chain
@@ -495,7 +521,7 @@ def test_device_epilogue_equal_first_x_replays_the_reference_sort():
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_device_epilogue_on_arbitrary_forests(seed):
+def test_device_epilogue_on_arbitrary_forests(seed, epi_path):
     """the epilogue kernels on f[] / p[] that no DP produced (random forests: long paths, bushy trees, deep in-chunk chains,
     equal scores) against the ORACLE's backtrack (mm2o_fill_v + mm2o_backtrack = chain.c:106-111,348-422) and, beside it, the library's host
     epilogue; device-resident plan API"""
@@ -503,7 +529,8 @@ def test_device_epilogue_on_arbitrary_forests(seed):
     from mm2chain import params
     rng = np.random.default_rng(1000 + seed)
     P = params.map_ont()
-    sizes = [1, 2, 63, 64, 65, 130, 1000, 3000, int(rng.integers(1, 5000)), 0, 4097]
+    sizes = [1, 2, 63, 64, 65, 130, 1000, 3000, int(rng.integers(1, 5000)), 0, 4097, 5120, 5121, 7680, 7681] if seed < 2 else \
+        [1, 2, 63, 64, 65, 130, 1000, 3000, int(rng.integers(1, 5000)), 0, 4097]   # seeds 0, 1: the boundaries of the LDS size classes too
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     total = int(off[-1])
     a = np.zeros((total, 2), np.uint64)
