@@ -61,7 +61,7 @@ def measured_traffic(profile, total_anchors):
         rec = json.load(open(path))[profile]
         h = hashlib.sha256()
         for fn in ("chain_dp_tile.h", "chain_wave.h", "chain_kernel.hip", "chain_kernel.h"):
-            h.update(open(os.path.join(PKG, "csrc", fn), "rb").read())
+            h.update(open(os.path.join(ROOT, "minimap2-fpga_amd", "csrc", fn), "rb").read())
         if rec.get("kernel_source_sha") != h.hexdigest()[:16]:
             return None                                        # the kernel changed since it was profiled: no stale number
         return rec["hbm_bytes_per_launch"] * (total_anchors / rec["anchors_per_launch"])

@@ -117,3 +117,23 @@ def test_split_model_getter_returns_the_header_constants():
         assert c["K1_HW"] >= 0 and c["K2_HW"] >= 0 and c["K_SW"] > 0 and c["C_HW"] > 0
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.split_model("no-such-preset")
+
+
+def test_bench_reports_profiled_traffic_only_for_the_profiled_kernel_sources():
+    """bench.py's roofline.traffic comes from profiles/traffic.json; it must be a number exactly when the hash recorded there is the hash of
+    the DP kernel's current sources, and None (never a stale figure) otherwise"""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["mixed"]
+    h = hashlib.sha256()
+    for fn in ("chain_dp_tile.h", "chain_wave.h", "chain_kernel.hip", "chain_kernel.h"):
+        h.update(open(os.path.join(ROOT, "minimap2-fpga_amd", "csrc", fn), "rb").read())
+    got = bench.measured_traffic("mixed", rec["anchors_per_launch"])
+    if rec["kernel_source_sha"] == h.hexdigest()[:16]:
+        assert got == rec["hbm_bytes_per_launch"]
+    else:
+        assert got is None
+    assert bench.measured_traffic("no such profile", 1) is None
