@@ -155,8 +155,9 @@ if __name__ == "__main__":
                       cut(B["Lmk"], until="s_cbranch_scc0 Lret"), cut(B["Lret"], until="s_cbranch_scc0 Lloop"))
     else:
         scored = path(cut(B["Lloop"], after="s_cbranch_vccz"), cut(B["Lold"], until="s_branch Lhf"), B["Lhf"], cut(B["Lmk"], until="s_cbranch_scc0 Lloop"))
-    b1 = path(cut(B["Limp"], until="s_branch Lret"))
-    b2 = path(cut(B["Limp"], until="s_cbranch_scc1 Lb2"), cut(B["Lb2"], until="s_branch Ltk"), cut(B["Ltk"], until="s_ff1"), B["Laf"][:2])
+    b0 = path(cut(B["Limp"], until="s_branch Lret"))
+    b1 = path(cut(B["Limp"], until="s_cbranch_scc0 Lslow"), cut(B["Lslow"], until="s_branch Lret"))
+    b2 = path(cut(B["Limp"], until="s_cbranch_vccnz Lslow2"), B["Lslow2"], cut(B["Lslow"], until="s_cbranch_scc1 Lb2"), cut(B["Lb2"], until="s_branch Ltk"), cut(B["Ltk"], until="s_ff1"), B["Laf"][:2])
     print("\n## Paths\n")
     print("| path | plain VALU | scalar-side VALU | SALU | branch | LDS | VMEM | waitcnt / nop |")
     print("|---|---|---|---|---|---|---|---|")
@@ -164,6 +165,7 @@ if __name__ == "__main__":
                     ("+ own-tile chunk, no lane passes the filters", own),
                     ("per older tile, no lane passes (`Lloop` … `s_cbranch_vccz`)", empty),
                     ("+ a lane passes, f/p from the LDS ring, stamps, score, fold A (no lane beats the best)", scored),
-                    ("+ fold B1 (one candidate, no marks, no skips so far)", b1),
+                    ("+ fold B0 (the first surviving lane is the only new maximum: closed form)", b0),
+                    ("+ fold B1 (one candidate that is not the first surviving lane, no marks, no skips so far)", b1),
                     ("+ fold B2 (prefix max by DPP, closed-form skip counter, take the result)", b2)):
         print(f"| {name} | " + " | ".join(str(c[k]) for k in CLASSES) + " |")
