@@ -103,6 +103,7 @@ int grow_pinned(char **p, size_t *cap, size_t need);
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 int check_params(const mm2c_params_t *p);
 mm2c::KParams to_kparams(const mm2c_params_t *p);
+int check_offsets(int64_t n_tasks, const int64_t *off);
 int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order);
 size_t layout_epilogue(mm2c::EpiArgs &E, char *base, size_t tot, size_t nt, size_t sort_tmp);
 int epilogue_debug_phases();

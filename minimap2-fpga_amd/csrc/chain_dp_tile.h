@@ -294,7 +294,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // A chunk with a surviving lane goes through Lhf: f / p of its tile (registers, LDS, or L2 beyond NF tiles), stamps, score, fold.
 // The fold: A no lane beats the running best; B0 the first surviving lane does and no other lane beats IT (the usual case on a real chain: the
 // nearest predecessor is the best) -- it is the only new maximum, every marked lane behind it is a skip event, so counter and `break` have a
-// closed form; B1 some lane does and neither marks nor skips exist (one candidate: no reduction at all);
+// closed form (the `break` needs a skip event: without one the counter is not even compared, max_skip may be negative); B1 some lane does and neither marks nor skips exist (one candidate: no reduction at all);
 // B2 general: prefix max by DPP -> lanes that raise the best (nm), skip events (se); closed form when every nm precedes every se,
 // else the max-plus scan n <- max(n + d, 0) over the lanes.
 // Wait states the assembler does not insert for inline asm (gfx940): VALU write -> DPP read of that VGPR: 2 (s_nop 1); VALU write ->
@@ -560,6 +560,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
 		"s_bitset0_b64 %[marked], %[t0]\n\t" \
 		"s_bcnt1_i32_b64 %[t1], %[marked]\n\t" \
+		"s_cbranch_scc0 Lret_%=\n\t" \
 		"s_add_i32 %[nskip], %[nskip], %[t1]\n\t" \
 		"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
@@ -774,7 +775,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;   // the own tile: lane L = anchor i0 + 63 - L
 	int seg0 = 0;
 	bool t_ready = false;                                     // t[0 .. i0) has been zeroed (wave-uniform)
-	const bool no_pairs = !GEN && P.max_dq <= 0;              // chain.c:203 lets nothing through
+	const bool no_pairs = !GEN && (P.max_dq <= 0 || P.bw < 0);   // chain.c:203 / chain.c:205 (dd >= 0 > bw) let nothing through
 
 	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
 	int cur_st = (rl < n) ? st[rl] - st_sub : 0;

@@ -229,8 +229,8 @@ mm2c::KParams to_kparams(const mm2c_params_t *p)
 	return k;
 }
 
-// offsets sanity + longest-first launch order (so the tail of the grid is made of short tasks)
-int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order)
+// offsets sanity alone (what a per-read call needs: no allocation, no sort)
+int check_offsets(int64_t n_tasks, const int64_t *off)
 {
 	if (n_tasks < 0 || n_tasks > INT32_MAX) return fail(MM2C_E_ARG, "n_tasks out of range");
 	if (n_tasks > 0 && !off) return fail(MM2C_E_ARG, "offsets is NULL");
@@ -240,6 +240,13 @@ int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order
 		if (n >= (int64_t)INT32_MAX - 64)
 			return fail(MM2C_E_TOOBIG, "task %lld has %lld anchors; the limit is 2^31-65 (cf. chain_hardware.cpp:34)", (long long)k, (long long)n);
 	}
+	return 0;
+}
+
+// offsets sanity + longest-first launch order (so the tail of the grid is made of short tasks)
+int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order)
+{
+	if (const int rc = check_offsets(n_tasks, off)) return rc;
 	order.resize((size_t)n_tasks);
 	std::iota(order.begin(), order.end(), 0);
 	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });

@@ -264,8 +264,7 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	int rc;
 	const auto t_begin = std::chrono::steady_clock::now();
 	if ((rc = check_params(par))) return rc;
-	std::vector<int32_t> order;
-	if ((rc = build_order(n_tasks, h_offsets, order))) return rc;      // validates the offsets
+	if ((rc = check_offsets(n_tasks, h_offsets))) return rc;            // the launch order is built where the pass is put together (run_requests)
 	if (n_tasks == 0) return 0;
 	const int64_t total = h_offsets[n_tasks] - h_offsets[0];
 	if (total == 0) return 0;

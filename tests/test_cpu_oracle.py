@@ -149,7 +149,7 @@ def test_tile_formulation_model_equals_oracle(profile):
     from tile_model import chain_tile_model
     off, a = _stream(profile, 2, 900, seed=4)
     for par in (P(), P(max_skip=2, max_iter=300), P(max_skip=INT32_MAX, max_iter=150), P(gap_scale=0.8, bw=100),
-                P(max_iter=5000, max_dist_x=20000, max_dist_y=20000)):
+                P(max_iter=5000, max_dist_x=20000, max_dist_y=20000), P(max_skip=-1), P(max_skip=0), P(bw=-1), P(bw=0)):
         for k in range(2):
             t = a[off[k]:off[k + 1]]
             avg = ob.avg_qspan(t)

@@ -38,6 +38,8 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
     st = np.maximum(np.searchsorted(x64, np.where(x64 >= D, x64 - D, np.uint64(0)), side="left"), np.arange(n) - P.max_iter)
     max_dq = min(P.max_dist_x, P.max_dist_y)
     fast_filter = P.bw >= 0 and max_dq - 1 >= P.bw
+    if P.bw < 0:
+        max_dq = 0                                                                # chain.c:205: dd >= 0 > bw, nothing passes
     lane = np.arange(64)
     S = dict(anchors=0, no_window=0, own_chunks=0, own_pass=0, ring_chunks=0, ring_pass=0, deep_fp=0, far_chunks=0, far_pass=0,
              fold_a=0, fold_b0=0, fold_b1=0, fold_b2_closed=0, fold_b2_scan=0, breaks=0, eq_run_anchors=0)
@@ -125,7 +127,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                 if not cand.any():                                                 # fold A
                     S["fold_a"] += 1
                     n_skip += int(marked.sum())
-                    if n_skip > P.max_skip:                                        # the break of chain.c:231; nothing before it changes the best
+                    if marked.any() and n_skip > P.max_skip:                       # the break of chain.c:231; nothing before it changes the best
                         broke = True
                     base -= 64
                     if broke:
@@ -138,7 +140,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     n_skip = max(n_skip - 1, 0)
                     se = marked.copy(); se[l0] = False                             # every marked lane behind it is a skip event
                     n_skip += int(se.sum())
-                    if n_skip > P.max_skip:
+                    if se.any() and n_skip > P.max_skip:                           # chain.c:231 is only reached by a skip event
                         broke = True
                         S["breaks"] += 1
                     base -= 64

@@ -24,11 +24,14 @@ for r in range(rounds):
                            max_iter=int(rng.choice([-3, 0, 1, 63, 64, 65, 200, 1024, 5000, 5000, INT32_MAX])),
                            gap_scale=float(rng.choice([1.0, 1.0, 0.5, 0.8, 2.25, 0.0])), is_cdna=int(rng.integers(0, 2)) if n_segs > 1 or rng.random() < .2 else 0,
                            n_segs=n_segs)
-    mm2chain.tune("ring_class", int(rng.choice([0, 0, 0, 1, 2])))
+    mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 3, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
         kind = rng.random()
-        if kind < 0.5:
+        if kind < 0.08:      # long dense tasks: windows of several hundred anchors (look-back beyond the LDS rings), pieces cut on the device
+            _, a = synth.make_stream("dense", 1, int(rng.integers(3000, 14000)), seed=int(rng.integers(0, 1 << 30)), locus=int(rng.choice([1500, 3000, 9000])))
+            tasks.append(a.numpy().view(np.uint64))
+        elif kind < 0.5:
             tasks.append(_random_task(rng, int(rng.integers(1, 2500)), int(rng.integers(1, 4)), n_segs, bool(rng.integers(0, 2))))
         else:
             prof = str(rng.choice(["mixed", "dense", "colinear", "sparse"]))
@@ -43,5 +46,5 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 0)
+mm2chain.tune("ring_class", 3)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")

@@ -67,7 +67,7 @@ def device_chains(off, a, f, p, min_cnt, min_sc):
 for r in range(rounds):
     rng = np.random.default_rng(seed0 * 100003 + r)
     # 1. arbitrary forests
-    sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 6000))])) for _ in range(int(rng.integers(1, 12)))]
+    sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 9000))])) for _ in range(int(rng.integers(1, 12)))]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     parts = [forest(rng, n, k) for k, n in enumerate(sizes) if n > 0]
     if parts:
