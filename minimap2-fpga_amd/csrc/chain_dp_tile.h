@@ -310,7 +310,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
 // x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
 #define MM2C_FAR_REQ "v_add_u32 %[u2], %[fb], %[rl]\n\t" "v_max_i32 %[u2], 0, %[u2]\n\t" "v_lshlrev_b32 %[u2], 4, %[u2]\n\t" \
-	"global_load_dword %[nx], %[u2], %[aptr]\n\t" "global_load_dword %[nq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
+	"global_load_dword %[fx], %[u2], %[aptr]\n\t" "global_load_dword %[fq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
 #define MM2C_SCORE_CMP "v_or_b32 %[va], 1, %[dd]\n\t" "v_ffbh_u32 %[va], %[va]\n\t" "v_lshrrev_b32 %[va], 1, %[va]\n\t" "v_cvt_f32_u32 %[vc], %[dd]\n\t" \
 	"v_mul_f32 %[vc], %[avg], %[vc]\n\t" "v_cvt_i32_f32 %[vc], %[vc]\n\t" "v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t" "v_sub_u32 %[sc], %[sc], %[vc]\n\t" \
 	"v_add3_u32 %[sc], %[sc], %[va], -14\n\t"
@@ -324,9 +324,21 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // the `break` goes on from memory (bit 28 set at run time).  `lean`: no such anchor in the tile, so nothing of that is tested; the stamp store
 // needs no exec mask either: lanes that must not stamp (filtered out, or p before the window) write the slot of anchor lo - 1 instead, which
 // no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (slots are compared with 1 + i mod 1024, a slot lives for 64 NX anchors).
+// Requests for tiles beyond the ring: the one for the first such tile goes out when an anchor with a clamped window starts (it is needed unless
+// the scan of the ring ends with the `break`), the one for each further tile while the tile before it is filtered.  A request that the `break`
+// has made useless is not awaited when the anchor is committed (that wait cost 5 % on colinear streams): loads return in order, so a later
+// request into the same registers lands later, and everything is awaited where the block ends (Lexit) -- nothing may be in flight there, the
+// compiler does not know about these loads.  Measured (dense / ava-ont colinear, ms): no prefetch 90.0 / 37.7; first request only once the ring is
+// exhausted 87.6 / 37.9; at the anchor's start 85.5 / 39.4 (kept); at the start only if the last such anchor went beyond the ring 87.0 / 38.8.
+#define MM2C_DONE_FAR ""
 #define MM2C_LK_FAR \
 	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
-	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t"
+	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
+	"s_sub_i32 %[fb], %[i0], %[REACH]\n\t" \
+	"s_bitcmp1_b32 %[pk], 30\n\t" \
+	"s_cbranch_scc0 Lnf_%=\n\t" \
+	MM2C_FAR_REQ \
+	"Lnf_%=:\n\t"
 #define MM2C_LK_LEAN \
 	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
 	"s_add_i32 %[lo0], %[lo], -1\n\t" \
@@ -391,15 +403,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b32 %[lo], %[lo0]\n\t" \
 	"s_sub_i32 %[s16], %[i0], %[L]\n\t" \
 	"s_add_i32 %[s16], %[s16], 64\n\t" \
-	"v_mov_b32 %[s16v], %[s16]\n\t" \
-	"s_sub_i32 %[fb], %[i0], %[REACH]\n" \
+	"v_mov_b32 %[s16v], %[s16]\n" \
 	"Lfloop_%=:\n\t" \
 	"s_add_u32 %[d], %[d], 1\n\t" \
 	"s_sub_u32 %[n], %[n], 1\n\t" \
 	"s_cbranch_scc1 Lfpart_%=\n\t" \
-	MM2C_FAR_REQ \
 	"s_waitcnt vmcnt(0)\n\t" \
-	MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+	MM2C_FILTER("%[fx]", "%[fq]") MM2C_FAR_REQ MM2C_FILTER2 \
 	"s_cbranch_vccz Lfloop_%=\n\t" \
 	"s_mov_b64 %[valid], vcc\n\t" \
 	"s_branch Lfold_%=\n" \
@@ -407,9 +417,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b32 %[n], 0\n\t" \
 	"s_cmp_eq_u32 %[part], 0\n\t" \
 	"s_cbranch_scc1 Ldone_%=\n\t" \
-	MM2C_FAR_REQ \
 	"s_waitcnt vmcnt(0)\n\t" \
-	MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+	MM2C_FILTER("%[fx]", "%[fq]") MM2C_FILTER2 \
 	"s_sub_i32 %[t0], 64, %[part]\n\t" \
 	"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
 	"s_mov_b32 %[part], 0\n\t" \
@@ -440,7 +449,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_END_LEAN(SCORE) \
 	"Lend_%=:\n"
 
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END) \
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int tb16, int &own_f, int &own_p, \
@@ -450,7 +459,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	typedef Lds<NX, NF, false, true> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
 	mask_t mask, valid, mk, marked, nm, se; \
-	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v; \
+	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
 		"s_sub_i32 %[L], 63, %[kstart]\n" \
 		"Lk_%=:\n\t" \
@@ -676,6 +685,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_branch Ldone_%=\n" \
 		SEG_END(SCORE) \
 		"Ldone_%=:\n\t" \
+		SEG_DONE \
 		"s_mov_b32 m0, %[L]\n\t" \
 		"s_nop 0\n\t" \
 		"v_writelane_b32 %[own_f], %[best], m0\n\t" \
@@ -684,13 +694,13 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cmp_ge_i32 %[L], %[Lend]\n\t" \
 		"s_cbranch_scc1 Lk_%=\n" \
 		"Lexit_%=:\n\t" \
-		"s_waitcnt lgkmcnt(0)\n\t" \
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
 		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
 		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [L] "=&s"(L), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), \
 		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
-		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), \
+		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), [tb16] "s"(tb16), \
@@ -703,10 +713,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN)
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN)
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR)
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR)
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
