@@ -44,7 +44,7 @@ struct LaunchArgs {
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
-	int ring_class;             // 3: tile kernel (4 register tiles + 3 LDS tiles); 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
+	int ring_class;             // 3: tile kernel (general variant: first-generation kernel); 4: tile kernel for every variant; 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
 	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
 };
 

@@ -591,7 +591,7 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 	return hipGetLastError();
 }
 
-int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }
+int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }   // 3, 4: the tile kernel
 
 hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin)
 {
@@ -603,7 +603,11 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
 	const bool tile = L.ring_class >= 3;                   // second-generation kernel: 448 anchors before the current tile without global memory
+	// the general variant (segment ids / cDNA) has no hand-written loop in the tile kernel and is faster in the first-generation one (headline
+	// stream with --general: 92.0 vs 108.7 ms, dense 151.8 vs 163.8): ring_class 3 sends it there, ring_class 4 keeps it in the tile kernel
+	const bool tile_gen = L.ring_class >= 4;
 	const bool far_ = (int64_t)P.max_iter > (int64_t)R;   // the ring always holds the R anchors before the current tile
+	const bool far_old = (int64_t)P.max_iter > 256;       // ... of the first-generation kernel when it stands in (R = 256)
 	// the gap-cost table of the tile kernel: dd <= bw <= 511 entries of int16 (cost <= 2.55 * 511 + 4, times gap_scale)
 	// used when gap_scale != 1 (it takes the f64 path of chain.c:219 out of the loop); with gap_scale 1 computing the cost is as fast and the
 	// kernel's LDS stays at 6 KB (measured: 62.8 vs 66.3 ms on the headline batch)
@@ -630,7 +634,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 		const bool gen = want_gen || pass == 1;
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
-		if (tile) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged); if (n_launches) ++*n_launches; continue; }
+		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged); if (n_launches) ++*n_launches; continue; }
+		if (tile) { e = launch_r<256>(L1, st, skip, gen, gs1, far_old, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {
 		case 256: e = launch_r<256>(L1, st, skip, gen, gs1, far_, flagged); break;
 		case 512: e = launch_r<512>(L1, st, skip, gen, gs1, far_, flagged); break;

@@ -331,7 +331,7 @@ int mm2c_init(int device_ordinal)
 	if (!env_devices.empty()) G.devices = env_devices;
 	if (G.devices.empty()) G.devices.assign(1, dev);
 	const char *rc = getenv("MM2C_RING_CLASS");
-	G.ring_class = rc ? std::max(0, std::min(3, atoi(rc))) : 3;
+	G.ring_class = rc ? std::max(0, std::min(4, atoi(rc))) : 3;
 	const char *ef = getenv("MM2C_EPI_FUSED");           // 0: the device epilogue works in HBM for every task (kernels A, B, C)
 	if (ef) G.epi_fused = atoi(ef) != 0;
 	G.ready = true;
@@ -412,7 +412,7 @@ int mm2c_tune(const char *key, int value)
 	if (key && strcmp(key, "trim") == 0) { dev_cache_release(); return 0; }   // give the cached device memory back to the runtime
 	if (!key) return fail(MM2C_E_ARG, "key is NULL");
 	if (strcmp(key, "ring_class") == 0) {
-		if (value < 0 || value > 3) return fail(MM2C_E_ARG, "ring_class must be 0, 1, 2 or 3");
+		if (value < 0 || value > 4) return fail(MM2C_E_ARG, "ring_class must be 0 .. 4");
 		G.ring_class = value;
 		return 0;
 	}

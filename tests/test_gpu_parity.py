@@ -68,7 +68,7 @@ def test_parameter_corners(max_skip, max_iter, gap_scale, bw):
     assert_same(f, p, f_ref, p_ref, off, f"corner {max_skip},{max_iter},{gap_scale},{bw}")
 
 
-@pytest.mark.parametrize("ring_class", [3, 0, 1, 2])
+@pytest.mark.parametrize("ring_class", [3, 4, 0, 1, 2])
 def test_ring_classes_and_far_lookback(ring_class):
     """look-back far beyond the LDS ring: a very dense locus (window ~ max_iter) with the early exit mostly disabled; ring class 3 = the tile
     kernel (the default), 0 / 1 / 2 = the first-generation kernel with 256 / 512 / 1024 anchors of ring"""
@@ -156,8 +156,17 @@ def _multiseg_task(rng, n, n_segs):
     return pack(rows)
 
 
+@pytest.fixture(params=[3, 4], ids=["general-in-wave-kernel", "general-in-tile-kernel"])
+def general_kernel(request):
+    """the segment / cDNA variant runs in the first-generation kernel by default (ring_class 3) and in the tile kernel on request (4)"""
+    import mm2chain
+    mm2chain.tune("ring_class", request.param)
+    yield request.param
+    mm2chain.tune("ring_class", 3)
+
+
 @pytest.mark.parametrize("is_cdna,n_segs", [(0, 2), (1, 1), (1, 2), (0, 3)])
-def test_general_variant_segments_and_cdna(is_cdna, n_segs):
+def test_general_variant_segments_and_cdna(is_cdna, n_segs, general_kernel):
     """chain.c:206,211-217: multi-segment (sr) and cDNA branches, non-uniform spans"""
     from mm2chain import params
     rng = np.random.default_rng(7 + is_cdna * 10 + n_segs)
@@ -170,7 +179,7 @@ def test_general_variant_segments_and_cdna(is_cdna, n_segs):
     assert_same(f, p, f_ref, p_ref, off, "general")
 
 
-def test_simple_variant_detects_foreign_segment_ids():
+def test_simple_variant_detects_foreign_segment_ids(general_kernel):
     """n_segs == 1 but anchors carry different segment ids: the simple kernel flags the task, the general one redoes it"""
     from mm2chain import params
     rng = np.random.default_rng(3)
@@ -737,7 +746,7 @@ def _random_task(rng, n, n_refs, n_segs, dense):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_randomised_parameters_and_adversarial_anchors(seed):
+def test_randomised_parameters_and_adversarial_anchors(seed, general_kernel):
     """every scalar of mm_chain_dp drawn at random (incl. degenerate values) on adversarial anchor lists"""
     from mm2chain import params
     rng = np.random.default_rng(1000 + seed)
