@@ -147,6 +147,7 @@ constexpr int K = 4, W = 64 * K;
 constexpr int FUSE_S = 5120, FUSE_L = 7680;        // 52.9 KB of LDS -> three tasks per CU; 78.8 KB -> two
 constexpr int NONE16 = 0xffff;
 constexpr int FNT = 512;                           // epi_fused: threads per task
+constexpr int RANK_MAX = 768;                       // epi_fused: up to this many keys are ordered by counting (quadratic, but barrier-free and on all threads)
 constexpr int NOT_MINE = 1 << 30;                   // rk2kk flag: the chain kept only its peak, which belongs to an earlier chain (chain.c:381-383)
 
 // ---- kernel A: v[], child marks, chain ends -> unsorted keys (chain.c:106-111, 349-367) -------------------------------
@@ -468,9 +469,17 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	int32_t *ctop = A.ctop + base, *rk2kk = A.rk2kk + base, *val0 = A.val0 + base;
 	uint64_t *us = A.key1 + base;
 	uint64_t *u2 = A.u2 + base, *rkey = A.key0 + base;
-	if (wave0) {
-		if (lane == 0) A.seg_end1[task] = (uint32_t)(base + nu);
-		// chain.c:368-372: best peak first.  In LDS while both buffers fit beside each other, else through global memory
+	if (tid == 0) A.seg_end1[task] = (uint32_t)(base + nu);
+	// chain.c:368-372: best peak first.  Up to RANK_MAX keys: every thread counts the keys that come before its own (all threads read the same
+	// key at a time: a broadcast) -- no passes, no barriers; more keys: the radix sort of the first wave, in LDS while both buffers fit
+	if (nu <= RANK_MAX) {
+		for (int r = tid; r < nu; r += FNT) {
+			const uint64_t key = s_a[r];
+			int before = 0;
+			for (int j = 0; j < nu; ++j) { const uint64_t kj = s_a[j]; before += (kj > key) | ((kj == key) & (j < r)); }
+			s_a[CAP / 2 + before] = key;
+		}
+	} else if (wave0) {
 		if (nu <= CAP / 2) wave_sort64<true, true>(s_a, s_a + CAP / 2, nullptr, nullptr, nu, lane, s_cnt);
 		else {
 			for (int r = lane; r < nu; r += 64) rkey[r] = s_a[r];
@@ -580,8 +589,17 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	}
 	// chain.c:406-411: chains by the x of their first anchor (stable here; kernel T replays the reference's sort where that matters)
 	__syncthreads();                                  // the cells are free again
-	if (wave0) {
-		const int nk = s_n;
+	const int nk = s_n;
+	if (nk <= RANK_MAX) {                             // stable: equal first x keep rank order
+		for (int i = tid; i < nk; i += FNT) s_a[i] = rkey[i];
+		__syncthreads();
+		for (int i = tid; i < nk; i += FNT) {
+			const uint64_t key = s_a[i];
+			int before = 0;
+			for (int j = 0; j < nk; ++j) { const uint64_t kj = s_a[j]; before += (kj < key) | ((kj == key) & (j < i)); }
+			A.rkey1[base + before] = key; A.val1[base + before] = i;
+		}
+	} else if (wave0) {
 		if (nk <= CAP / 3) {                            // keys and values of both buffers fit the cells' space
 			uint64_t *k0 = s_a, *k1 = s_a + CAP / 3;
 			int32_t *v0 = (int32_t *)(s_a + 2 * (CAP / 3)), *v1 = v0 + CAP / 3;
