@@ -15,15 +15,21 @@
 //     then tiles T-1, T-2, ... from an LDS ring that is written once per 64 anchors: x / q of NX tiles (all the filters need), f / p of
 //     the NF nearest; deeper f / p and anything beyond NX tiles come from L2 (the task's own earlier stores), for nonempty chunks only.
 //     No per-lane ring arithmetic, no window shifting, no cross-lane data movement per anchor.
-//   * the filters chain.c:202-205 of a chunk cost 6 plain VALU + one v_cmp: dr-1, dq-1, |dr-dq| (v_sad_u32), two saturating
-//     subtractions against max_dq-1 and bw, v_or, compare with zero; dr == 0 (equal x, chain.c:202) never reaches the vector unit:
-//     equal x are neighbours in the sorted array, so the lanes to drop are a run that one ballot per TILE locates.
-//   * chain.c's t[] stamps: 16-bit stamp ring in LDS covering every anchor the ring reaches, exec-masked ds_write_b16 by p, ds_read_u16 by j.
-//   * the whole scan of an anchor -- chunk loop, f / p fetch, stamps, score, the order-dependent fold (strict running max, max_skip
-//     counter as a max-plus prefix scan) -- is ONE hand-written instruction sequence (scan_anchor_asm below) for the variant that
-//     matters (max_skip on, one segment, gap_scale 1, window inside the ring): the compiler's code for wave-uniform control flow
-//     (64-bit boolean masks, s_mov phi chains) needs 2.5x the scalar instructions.  Everything else (segments / cDNA, gap_scale != 1,
-//     windows beyond the ring, equal-x runs longer than a tile) goes through the C++ restatement of the same scan (scan_anchor).
+//   * the filters chain.c:202-205 of a chunk cost 5 plain VALU + one v_cmp: dr-1, dq-1, |dr-dq| (v_sad_u32), one saturating subtraction
+//     against max_dq-1-bw, v_max_u32, compare with bw (valid when max_dq-1 >= bw >= 0: every preset); dr == 0 (equal x, chain.c:202) never
+//     reaches the vector unit: equal x are neighbours in the sorted array, so the lanes to drop are a run that one ballot per TILE locates
+//     and that only moves the start of the own-tile lane mask.
+//   * chain.c's t[] stamps: 16-bit stamp ring in LDS covering every anchor the ring reaches (value 1 + i mod 1024), ds_write_b16 by p,
+//     ds_read_u16 by j; lanes that must not stamp write the slot of anchor lo - 1, so the store needs no exec mask.
+//   * the whole scan of the anchors of a tile -- per-anchor scalars, chunk loop, f / p fetch, stamps, score, the order-dependent fold (running
+//     max; max_skip counter in closed form where the first surviving lane is the only new maximum, else prefix max by DPP and, if needed, a
+//     max-plus prefix scan) -- is ONE hand-written instruction sequence (MM2C_SCAN_TILE_ASM below) for the variants that matter (max_skip
+//     on, one segment, gap_scale 1 or the gap-cost table): the compiler's code for wave-uniform control flow (64-bit boolean masks, s_mov
+//     phi chains) needs 2.5x the scalar instructions.  Two instantiations: `lean` for tiles in which no window reaches beyond the ring,
+//     `far` for the others (stamps beyond the ring in global scratch, x / q requests one tile ahead).  Everything else (segments / cDNA,
+//     gap_scale != 1 without the table, max_skip off, an equal-x run that reaches back into the tile before) goes through the C++
+//     restatement of the same scan (scan_anchor); the segment / cDNA variant is by default run by the first-generation kernel
+//     (chain_kernel.hip), which is faster for it.
 #ifndef MM2C_CHAIN_DP_TILE_H
 #define MM2C_CHAIN_DP_TILE_H
 #include "chain_wave.h"
@@ -453,7 +459,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int tb16, int &own_f, int &own_p, \
-                                    int addr1, int ownst, int own2s, int rl4, int rl, int mdqbw_v, int bw_v, int sent_v) \
+                                    int addr1, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
 { \
 	typedef Lds<NX, NF, false, TABV> LY; \
 	typedef Lds<NX, NF, false, true> LYT; \
@@ -704,7 +710,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), [tb16] "s"(tb16), \
-		  [addr1] "v"(addr1), [ownst] "v"(ownst), [own2s] "v"(own2s), [rl4] "v"(rl4), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
+		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc"); \
@@ -777,8 +783,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	AnchorCtx X;
 	X.avg = avg; X.rl = rl; X.seg_i = 0; X.far_mode = 0;
 	X.mdq1_v = P.max_dq - 1; X.bw_v = P.bw;
-	int own2s = LY::ST + 2 * rl, rl4 = rl << 2, sent_v = SENT, mdqbw_v = P.max_dq - 1 - P.bw;   // stamp slot / ring dword of this lane's anchor of a tile at 0 mod SN                // stamp slot of this lane's anchor of a tile whose base is 0 mod SN; the score of a dead lane
-	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(own2s), "+v"(rl4), "+v"(sent_v), "+v"(mdqbw_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
+	int sent_v = SENT, mdqbw_v = P.max_dq - 1 - P.bw;        // the score of a dead lane; the bound of the one-compare filter
+	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
 	TileMem M;
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
 
@@ -854,7 +860,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 lo_l, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, own2s, rl4, rl, mdqbw_v, X.bw_v, sent_v)
+                                 lo_l, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
 				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far) : MM2C_CALL(scan_tile_asm_cmp_far);
 				else k = TAB ? MM2C_CALL(scan_tile_asm_tab) : MM2C_CALL(scan_tile_asm_cmp);
 #undef MM2C_CALL

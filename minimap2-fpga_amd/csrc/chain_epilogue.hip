@@ -20,8 +20,11 @@
 //                so a task with more than 64 chains AND two equal first-x values replays that sort's passes on one lane;
 //                everywhere else the order is unique (stable wave_sort64 of (x, chain)).
 //
-// One 64-lane wave per task in each kernel; tasks are independent.  Outputs are compact: chains of task k are
-// u[u_off[k] .. u_off[k+1]), their anchors b[b_off[k] .. b_off[k+1]).
+// Two forms.  Kernels A / B / C (epi_ends, epi_claim, epi_emit): one 64-lane wave per task, per-anchor state (marks, v, peaks, owners, depths)
+// in HBM scratch arrays, chunks of 256 anchors with pointer jumping inside a chunk -- any task size.  epi_fused + epi_emit_cd (round 2, the
+// default for tasks of up to 7 680 anchors): one workgroup of 512 threads per task with that state in LDS, pointer jumping over the whole task
+// (see epi_fused).  Tasks are independent.  Outputs are compact: chains of task k are u[u_off[k] .. u_off[k+1]), their anchors
+// b[b_off[k] .. b_off[k+1]).
 
 #include <hip/hip_runtime.h>
 #include <climits>
