@@ -416,12 +416,23 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	if (A.debug_phases && tid == 0) { A.seg_end1[task] = (uint32_t)base; A.seg_end2[task] = (uint32_t)base; A.cnt_u[task] = 0; A.cnt_b[task] = 0; }   // development aid: cut after phase N
 	for (int w = tid; w < (n + 31) / 32; w += FNT) s_mark[w] = 0;
 	__syncthreads();
-	for (int i = tid; i < n; i += FNT) {
-		const int pi = p[i];
-		const int q = pi < 0 ? NONE16 : pi;
-		s_p[i] = (uint16_t)q;
-		if (pi >= 0) atomicOr(&s_mark[pi >> 5], 1u << (pi & 31));
-		s_a[i] = (uint64_t)(uint32_t)(i << 16 | q) << 32 | (uint32_t)f[i];
+	constexpr int KE = CAP / FNT;                   // anchors per thread: anchor tid + FNT k for k < KE.  Every loop over them is written so that
+	                                                // the KE memory accesses of a step are independent and in flight together
+	uint64_t e[KE];                                 // the thread's own cells (only their owner writes them: they stay in registers over the rounds)
+	{
+		int pv[KE], fv[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; pv[k] = i < n ? p[i] : -1; fv[k] = i < n ? f[i] : 0; }
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const int i = tid + FNT * k, q = pv[k] < 0 ? NONE16 : pv[k];
+			e[k] = (uint64_t)(uint32_t)(i << 16 | q) << 32 | (uint32_t)fv[k];
+			if (i < n) {
+				s_p[i] = (uint16_t)q;
+				if (pv[k] >= 0) atomicOr(&s_mark[pv[k] >> 5], 1u << (pv[k] & 31));
+				s_a[i] = e[k];
+			}
+		}
 	}
 	__syncthreads();
 	if (A.debug_phases == 1) return;
@@ -430,16 +441,21 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	// own v; there f = v): a running (maximum, nearest position of it), which composes over path segments.  A cell always describes the path
 	// from its anchor up to (excluding) `next`; cells are read and written in one piece, so whatever state another cell is in, appending it is valid.
 	for (;;) {
+		uint64_t q[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const int nxt = (int)(e[k] >> 32) & 0xffff;
+			q[k] = nxt != NONE16 ? __hip_atomic_load(&s_a[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;   // another thread's cell, in one piece
+		}
 		bool again = false;
-		for (int i = tid; i < n; i += FNT) {
-			const uint64_t e = s_a[i];
-			const int nxt = (int)(e >> 32) & 0xffff;
-			if (nxt == NONE16) continue;
-			const uint64_t q = __hip_atomic_load(&s_a[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // another thread's cell, in one piece
-			int v = (int32_t)e, pk = (int)(e >> 48);
-			if ((int32_t)q > v) { v = (int32_t)q; pk = (int)(q >> 48); }
-			const int nn = (int)(q >> 32) & 0xffff;
-			__hip_atomic_store(&s_a[i], (uint64_t)(uint32_t)(pk << 16 | nn) << 32 | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			if (((int)(e[k] >> 32) & 0xffff) == NONE16) continue;
+			int v = (int32_t)e[k], pk = (int)(e[k] >> 48);
+			if ((int32_t)q[k] > v) { v = (int32_t)q[k]; pk = (int)(q[k] >> 48); }
+			const int nn = (int)(q[k] >> 32) & 0xffff;
+			e[k] = (uint64_t)(uint32_t)(pk << 16 | nn) << 32 | (uint32_t)v;
+			__hip_atomic_store(&s_a[tid + FNT * k], e[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			again |= nn != NONE16;
 		}
 		if (!again) break;
@@ -448,13 +464,12 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	if (A.debug_phases == 2) return;
 	// ---- chain ends -> keys f[peak] << 32 | peak with f[peak] = v (any order: they are sorted next), collected in the cells' place
 	{
-		constexpr int KE = CAP / FNT;
 		uint64_t key[KE]; bool is_end[KE];
 #pragma unroll
 		for (int k = 0; k < KE; ++k) {
 			const int i = tid + FNT * k;
-			is_end[k] = i < n && !((s_mark[i >> 5] >> (i & 31)) & 1) && (int32_t)s_a[i < n ? i : 0] >= A.min_sc;   // chain.c:352
-			key[k] = is_end[k] ? (s_a[i] << 32 | s_a[i] >> 48) : 0;
+			is_end[k] = i < n && !((s_mark[i >> 5] >> (i & 31)) & 1) && (int32_t)e[k] >= A.min_sc;   // chain.c:352 (the cell is final: v, peak)
+			key[k] = is_end[k] ? (e[k] << 32 | e[k] >> 48) : 0;
 		}
 		__syncthreads();
 #pragma unroll
@@ -501,7 +516,6 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	{
 		// round t: every anchor pushes what has reached it to its 2^t-th ancestor, then its jump pointer doubles.  A value that arrives early
 		// (a push of the same round that lands before the anchor reads its own cell) is still the rank of a peak below it: harmless
-		constexpr int KE = CAP / FNT;
 		int up[KE];
 #pragma unroll
 		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; up[k] = i < n ? s_w[2 * i + 1] : -1; }
@@ -525,20 +539,39 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	__syncthreads();
 	if (A.debug_phases == 5) return;
 	// ---- depth inside the owner path (links to the path's top) and the top of every path: pulled, like v
-	for (int i = tid; i < n; i += FNT) {
-		const int o = s_w[2 * i], pi = s_p[i];
-		const bool claimed = o != NONE, link = claimed && pi != NONE16 && s_w[2 * pi] == o;
-		if (claimed && !link) ctop[o] = i;
-		s_w[2 * i + 1] = link ? (1 << 16 | pi) : NONE16;
+	int dn[KE];                                       // links counted so far << 16 | next ancestor to visit
+	{
+		int o[KE], pi[KE], op[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; o[k] = i < n ? s_w[2 * i] : NONE; pi[k] = i < n ? (int)s_p[i] : NONE16; }
+#pragma unroll
+		for (int k = 0; k < KE; ++k) op[k] = (o[k] != NONE && pi[k] != NONE16) ? s_w[2 * pi[k]] : NONE;
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const int i = tid + FNT * k;
+			const bool claimed = o[k] != NONE, link = claimed && pi[k] != NONE16 && op[k] == o[k];
+			if (claimed && !link) ctop[o[k]] = i;
+			dn[k] = link ? (1 << 16 | pi[k]) : NONE16;
+		}
 	}
+	__syncthreads();                                  // every owner has been read: the high words can be overwritten
+#pragma unroll
+	for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; if (i < n) s_w[2 * i + 1] = dn[k]; }
 	__syncthreads();
 	for (;;) {
+		int q[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			const int nxt = dn[k] & 0xffff;
+			q[k] = nxt != NONE16 ? __hip_atomic_load(&s_w[2 * nxt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : NONE16;
+		}
 		bool again = false;
-		for (int i = tid; i < n; i += FNT) {
-			const int e = s_w[2 * i + 1], nxt = e & 0xffff;
-			if (nxt == NONE16) continue;
-			const int q = __hip_atomic_load(&s_w[2 * nxt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), nn = q & 0xffff;
-			__hip_atomic_store(&s_w[2 * i + 1], (int)(((unsigned)e >> 16) + ((unsigned)q >> 16)) << 16 | nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+		for (int k = 0; k < KE; ++k) {
+			if ((dn[k] & 0xffff) == NONE16) continue;
+			const int nn = q[k] & 0xffff;
+			dn[k] = (int)(((unsigned)dn[k] >> 16) + ((unsigned)q[k] >> 16)) << 16 | nn;
+			__hip_atomic_store(&s_w[2 * (tid + FNT * k) + 1], dn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			again |= nn != NONE16;
 		}
 		if (!again) break;
@@ -585,10 +618,14 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	if (A.debug_phases == 7) return;
 	// what kernel C needs per anchor: the kept chain that takes it and its position inside that chain
 	int32_t *cd = A.own + base;
-	for (int i = tid; i < n; i += FNT) {
-		const int o = s_w[2 * i];
-		const int kk = o != NONE ? rk2kk[o] : -1;        // the owner of an anchor is always `mine` for it: no flag
-		cd[i] = kk >= 0 ? (kk << 16 | (int)((unsigned)s_w[2 * i + 1] >> 16)) : -1;
+	{
+		int o[KE], kk[KE];
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; o[k] = i < n ? s_w[2 * i] : NONE; }
+#pragma unroll
+		for (int k = 0; k < KE; ++k) kk[k] = o[k] != NONE ? rk2kk[o[k]] : -1;   // the owner of an anchor is always `mine` for it: no flag
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; if (i < n) cd[i] = kk[k] >= 0 ? (kk[k] << 16 | (int)((unsigned)dn[k] >> 16)) : -1; }
 	}
 	// chain.c:406-411: chains by the x of their first anchor (stable here; kernel T replays the reference's sort where that matters)
 	__syncthreads();                                  // the cells are free again
