@@ -10,8 +10,8 @@
  * (chain.c -> chain_hardware.h:6 -> xcl2.hpp:34 includes <CL/cl_ext_xilinx.h>, a Xilinx XRT vendor header that is absent;
  * no stand-in header is written).  The restatement is pinned
  *  (a) ELEMENT BY ELEMENT AGAINST f[]/p[] PRODUCED BY THE REFERENCE'S OWN DEVICE KERNEL: device/minimap2_opencl.cl compiles, unmodified,
- *      for the host CPU with the image's clang OpenCL front end (oracle/ref_host/Makefile, libref_cl_chain.so); its outputs for 18 tasks
- *      (30 996 anchors) are committed as tests/golden/ref_cl_kernel_fp.npz and reproduced by mm2o_chain_fpv under V2 parameters, by
+ *      for the host CPU with the image's clang OpenCL front end (oracle/ref_host/Makefile, libref_cl_chain.so); its outputs for 23 tasks
+ *      (71 396 anchors) are committed as tests/golden/ref_cl_kernel_fp.npz and reproduced by mm2o_chain_fpv under V2 parameters, by
  *      mm2o_chain_hw_literal and by the HIP kernel.  This pins the window, the filters, the score and gap cost, ties and the strict `>`.
  *      The branches only the V1 loop has (max_skip, max_iter other than 1024, per-anchor spans, segments, gap_scale) are pinned by (b)-(d);
  *  (b) END TO END AGAINST THE REFERENCE'S RECORDED OUTPUT: oracle/ref_host links the reference's own non-path host objects

@@ -65,6 +65,21 @@ for n, xr, qr in [(600, 300, 300), (900, 2000, 1500), (64, 10, 10), (1, 5, 5), (
     y = (np.uint64(15) << np.uint64(32)) | rng.integers(15, 15 + qr, n).astype(np.uint64)
     cases.append((f"random:n={n}:x<{xr}:q<{qr}", np.stack([x, y], 1), 5000, 5000, 500))
 
+# (5) longer tasks (the HIP tile kernel leaves its LDS rings: look-back of 1024 > 448 anchors), k = 19 spans (asm20, options.c:113-122), and a task
+#     that crosses reference sequences and strands (the high word of x changes inside the task: the window test is a 64-bit compare)
+for prof, n, locus, seed, span in [("dense", 12000, 30000, 31, 15), ("mixed", 15000, None, 32, 15), ("mixed", 6000, None, 33, 19), ("colinear", 5000, None, 34, 19)]:
+    off, a = synth.make_stream(prof, 1, n, seed=seed, locus=locus, q_span=span)
+    cases.append((f"synth:{prof}:n={n}:locus={locus}:seed={seed}:span={span}", a.numpy().view(np.uint64), 5000, 5000, 500))
+parts = []
+for rid, strand, n, seed in [(0, 0, 700, 41), (0, 1, 500, 42), (1, 0, 900, 43), (3, 1, 300, 44)]:
+    off, a = synth.make_stream("dense", 1, n, seed=seed, locus=4000)
+    a = a.numpy().view(np.uint64).copy()
+    a[:, 0] = (a[:, 0] & np.uint64(0xffffffff)) | (np.uint64(rid) << np.uint64(33)) | (np.uint64(strand) << np.uint64(32))   # rid << 33 | strand << 32 | pos (map.c:232-241)
+    parts.append(a)
+multi = np.concatenate(parts)
+multi = multi[np.argsort(multi[:, 0], kind="stable")]
+cases.append(("synth:dense:4 reference/strand groups in one task", multi, 5000, 5000, 500))
+
 out = {"n_cases": np.array(len(cases))}
 tot = 0
 for k, (name, a, mdx, mdy, bw) in enumerate(cases):
