@@ -520,12 +520,13 @@ def test_device_epilogue_equal_first_x_replays_the_reference_sort(epi_path):
     from mm2chain import params
     P = params.map_ont()
     tasks = [_tandem_task(60, [3, 2, 1, 4], 1), _tandem_task(12, [3, 2], 2), _tandem_task(90, [1], 3), _tandem_task(150, [2, 5, 1], 4),
-             _tandem_task(300, [2, 3], 5), _tandem_task(1800, [2, 3], 6)]      # the last one has more chains than the LDS variant of the replay holds
+             _tandem_task(300, [2, 3], 5), _tandem_task(1800, [2, 3], 6),      # the last one has more chains than the LDS variant of the replay holds
+             _tandem_task(480, [2, 3], 7)]                                     # fits the LDS epilogue (4 800 anchors) with more chains than its counting sort takes
     off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tasks])]).astype(np.int64)
     a = np.concatenate(tasks)
     res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a, epilogue_threads=0)
     _assert_chains(res, P, 3, 40, off, a, "tandem")
-    assert res[0][0].size > 64 and res[3][0].size > 64 and res[4][0].size > 512 and res[5][0].size > 4096
+    assert res[0][0].size > 64 and res[3][0].size > 64 and res[4][0].size > 512 and res[5][0].size > 4096 and res[6][0].size > 768 and tasks[6].shape[0] <= 5120
     x_first = [int(res[0][1][i, 0]) for i in np.concatenate([[0], np.cumsum(res[0][0] & np.uint64(0xffffffff))[:-1]]).astype(np.int64)]
     assert len(set(x_first)) < len(x_first), "the test must contain chains that start at equal x"
 
@@ -562,12 +563,16 @@ def test_device_epilogue_on_arbitrary_forests(seed, epi_path):
             par = idx - 1 - rng.integers(0, 4, n)
         else:               # mixture with far parents
             par = np.where(rng.random(n) < 0.5, idx - 1, idx - 1 - rng.integers(0, 200, n))
+        if n == 3000 and seed == 3:   # roots only: every anchor is a chain end (more keys than the sorts of the LDS epilogue take in LDS)
+            par = np.full(n, -1)
         par = np.where(par < 0, -1, par)
         p[o:o + n] = par
         ff = np.zeros(n, np.int64)
         gain = rng.integers(-30, 25 if seed % 3 else 16, n)
         for i in range(n):
             ff[i] = max(15, (ff[par[i]] if par[i] >= 0 else 0) + 15 + gain[i]) if seed % 3 != 2 else int(rng.integers(0, 60))
+        if n == 3000 and seed == 3:
+            ff = rng.integers(30, 90, n)          # ... all of them above min_sc
         f[o:o + n] = ff
     ref = [ob.backtrack(2, 30, a[off[k]:off[k + 1]], f[off[k]:off[k + 1]], p[off[k]:off[k + 1]]) for k in range(len(sizes))]
     host = mm2chain.chain_epilogue_host(2, 30, off, a, f, p, n_threads=4)
