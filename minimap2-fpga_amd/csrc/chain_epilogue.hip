@@ -391,7 +391,8 @@ __global__ __launch_bounds__(64) void epi_claim(EpiArgs A)
 // is then f and p once, the chain records (per chain, not per anchor) and one word per anchor for kernel C: (chain << 16 | depth), or -1.
 
 template <int CAP>
-__global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
+__global__ __launch_bounds__(FNT, CAP <= 5120 ? 6 : 4)   // waves per SIMD: three (two) workgroups per CU, as many as the LDS takes
+void epi_fused(EpiArgs A, int n_above)
 {
 	static_assert(CAP % 64 == 0 && CAP < NONE16, "indices and NONE16 in 16 bits");
 	// one 8-byte cell per anchor, read and written whole (so that another wave sees a consistent pair), used three times:
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	__syncthreads();
 	if (A.debug_phases == 2) return;
 	// ---- chain ends -> keys f[peak] << 32 | peak with f[peak] = v (any order: they are sorted next), collected in the cells' place
+	bool wide = false;                                // a score that does not fit 19 bits beside a 13-bit peak, or is not positive
 	{
 		uint64_t key[KE]; bool is_end[KE];
 #pragma unroll
@@ -470,8 +472,9 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 			const int i = tid + FNT * k;
 			is_end[k] = i < n && !((s_mark[i >> 5] >> (i & 31)) & 1) && (int32_t)e[k] >= A.min_sc;   // chain.c:352 (the cell is final: v, peak)
 			key[k] = is_end[k] ? (e[k] << 32 | e[k] >> 48) : 0;
+			wide |= is_end[k] && ((int32_t)e[k] < 1 || (int32_t)e[k] >= (1 << 19));
 		}
-		__syncthreads();
+		wide = __syncthreads_or(wide);
 #pragma unroll
 		for (int k = 0; k < KE; ++k) {
 			const uint64_t m = __ballot(is_end[k]);
@@ -488,6 +491,177 @@ __global__ __launch_bounds__(FNT) void epi_fused(EpiArgs A, int n_above)
 	uint64_t *us = A.key1 + base;
 	uint64_t *u2 = A.u2 + base, *rkey = A.key0 + base;
 	if (tid == 0) A.seg_end1[task] = (uint32_t)(base + nu);
+	const bool by_key = !wide && nu <= 2 * FNT && CAP <= 8192 && A.debug_phases == 0;
+	if (tid == 0) A.seg_begin[task] = by_key ? 1u : 0u;   // tells kernel C which of the two forms of its input this task has
+	if (by_key) {
+		// ---- Owners WITHOUT sorting the chain ends first.  The owner of an anchor is the BEST peak in its subtree; "best" is the order of the
+		// keys f[peak] << 32 | peak, and with scores below 2^19 and tasks of at most 8 192 anchors the key fits one word, f[peak] << 13 | peak, that
+		// an LDS atomic maximum can carry.  Only the chains that survive the filter (a sixth of the chain ends on the headline stream) need their
+		// rank, and a handful of keys is ranked by counting.  A chain is then known by its peak: `ctop`, `rk2kk` are indexed by peaks here.
+		int32_t *end2kk = A.v + base;                  // per chain end: its number among the kept chains (| NOT_MINE), or -1
+		uint16_t *const s_map = (uint16_t *)(s_a + CAP / 2 + 512);   // peak -> number of its chain among the kept ones (behind the kept keys and their flags)
+		static_assert(CAP / 2 + 512 + CAP / 4 <= CAP && 2 * FNT <= CAP / 2, "kept keys, their flags and the peak -> chain map share the cells' space");
+		uint64_t mk[2];
+#pragma unroll
+		for (int m = 0; m < 2; ++m) { const int en = tid + FNT * m; mk[m] = en < nu ? s_a[en] : 0; if (en < nu) us[en] = mk[m]; }
+		for (int w = tid; w < (n + 31) / 32; w += FNT) s_mark[w] = 0;   // from here on: this peak has been listed
+		__syncthreads();
+		for (int i = tid; i < n; i += FNT) s_a[i] = (uint64_t)(uint32_t)(s_p[i] == NONE16 ? -1 : (int)s_p[i]) << 32;   // owner 0: none (keys are >= 8 192)
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+			if (tid + FNT * m < nu) atomicMax((unsigned *)&s_w[2 * (int32_t)(mk[m] & 0xffff)], (uint32_t)(mk[m] >> 32) << 13 | (uint32_t)(mk[m] & 0x1fff));
+		__syncthreads();
+		{
+			int up[KE];
+#pragma unroll
+			for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; up[k] = i < n ? s_w[2 * i + 1] : -1; }
+			for (;;) {
+				bool open = false;
+#pragma unroll
+				for (int k = 0; k < KE; ++k) open |= up[k] >= 0;
+				if (!__syncthreads_or(open)) break;
+#pragma unroll
+				for (int k = 0; k < KE; ++k)
+					if (up[k] >= 0) {
+						const int acc = __hip_atomic_load(&s_w[2 * (tid + FNT * k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (acc != 0) atomicMax((unsigned *)&s_w[2 * up[k]], (unsigned)acc);
+						up[k] = s_w[2 * up[k] + 1];
+					}
+				__syncthreads();
+#pragma unroll
+				for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; if (i < n) s_w[2 * i + 1] = up[k]; }
+			}
+		}
+		__syncthreads();
+		// depths and tops, as below
+		int dn[KE], ow[KE];
+		{
+			int pi[KE], op[KE];
+#pragma unroll
+			for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; ow[k] = i < n ? s_w[2 * i] : 0; pi[k] = i < n ? (int)s_p[i] : NONE16; }
+#pragma unroll
+			for (int k = 0; k < KE; ++k) op[k] = (ow[k] != 0 && pi[k] != NONE16) ? s_w[2 * pi[k]] : 0;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) {
+				const bool claimed = ow[k] != 0, link = claimed && pi[k] != NONE16 && op[k] == ow[k];
+				if (claimed && !link) ctop[ow[k] & 0x1fff] = tid + FNT * k;
+				dn[k] = link ? (1 << 16 | pi[k]) : NONE16;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < KE; ++k) { const int i = tid + FNT * k; if (i < n) s_w[2 * i + 1] = dn[k]; }
+		__syncthreads();
+		for (;;) {
+			int q[KE];
+#pragma unroll
+			for (int k = 0; k < KE; ++k) {
+				const int nxt = dn[k] & 0xffff;
+				q[k] = nxt != NONE16 ? __hip_atomic_load(&s_w[2 * nxt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : NONE16;
+			}
+			bool again = false;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) {
+				if ((dn[k] & 0xffff) == NONE16) continue;
+				const int nn = q[k] & 0xffff;
+				dn[k] = (int)(((unsigned)dn[k] >> 16) + ((unsigned)q[k] >> 16)) << 16 | nn;
+				__hip_atomic_store(&s_w[2 * (tid + FNT * k) + 1], dn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				again |= nn != NONE16;
+			}
+			if (!again) break;
+		}
+		__syncthreads();
+		// ---- one thread per chain end (chain.c:377-389)
+		bool keep[2], mine[2]; int len[2], sc[2], top[2];
+#pragma unroll
+		for (int m = 0; m < 2; ++m) {
+			keep[m] = mine[m] = false; len[m] = sc[m] = top[m] = 0;
+			if (tid + FNT * m < nu) {
+				const int j = (int)(mk[m] & 0xffff), peak = (int32_t)(mk[m] >> 32);
+				const bool first = !((atomicOr(&s_mark[j >> 5], 1u << (j & 31)) >> (j & 31)) & 1);   // a peak listed twice belongs to one listing
+				mine[m] = first && s_w[2 * j] == (int)((uint32_t)peak << 13 | (uint32_t)j);
+				len[m] = mine[m] ? (int)((unsigned)s_w[2 * j + 1] >> 16) + 1 : 1;
+			}
+		}
+		__syncthreads();                               // the tops are in memory (ctop), the cells have been read
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+			if (tid + FNT * m < nu) {
+				const int j = (int)(mk[m] & 0xffff), peak = (int32_t)(mk[m] >> 32);
+				top[m] = mine[m] ? ctop[j] : j;
+				const int stop = s_p[top[m]] == NONE16 ? -1 : (int)s_p[top[m]];
+				sc[m] = stop < 0 ? peak : peak - f[stop];
+				keep[m] = (stop < 0 || sc[m] >= A.min_sc) && len[m] >= A.min_cnt;
+			}
+		// the kept chains in the order of their keys (best first; of two listings of one peak the one that took the anchors first)
+		if (tid == 0) s_n = 0;
+		__syncthreads();
+		int at[2];
+#pragma unroll
+		for (int m = 0; m < 2; ++m) {
+			at[m] = -1;
+			if (keep[m]) { at[m] = atomicAdd(&s_n, 1); s_a[at[m]] = mk[m]; s_w[2 * (CAP / 2) + at[m]] = mine[m]; }
+		}
+		__syncthreads();
+		const int nk = s_n;
+		int n_b = 0;
+#pragma unroll
+		for (int m = 0; m < 2; ++m) {
+			const int en = tid + FNT * m;
+			if (en >= nu) continue;
+			const int j = (int)(mk[m] & 0xffff);
+			int kk = -1;
+			if (keep[m]) {
+				kk = 0;
+				for (int t = 0; t < nk; ++t) {
+					const uint64_t kt = s_a[t];
+					const int mt = s_w[2 * (CAP / 2) + t];
+					kk += (kt > mk[m]) | ((kt == mk[m]) & ((mt > (int)mine[m]) | ((mt == (int)mine[m]) & (t < at[m]))));
+				}
+				u2[kk] = (uint64_t)(uint32_t)sc[m] << 32 | (uint32_t)len[m];
+				rkey[kk] = A.d_a[base + top[m]].x;
+				n_b += len[m];
+			}
+			end2kk[en] = kk < 0 ? -1 : (mine[m] ? kk : kk | NOT_MINE);
+			if (mine[m]) s_map[j] = (uint16_t)kk;        // anchors of a dropped chain find 0xffff here
+		}
+		n_b = wave_sum(n_b);
+		__syncthreads();                               // the keys have been read, the chain numbers are in place
+		// what kernel C needs per anchor: the kept chain that takes it and its position inside that chain
+		{
+			int32_t *cd = A.own + base;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) {
+				const int i = tid + FNT * k;
+				const int kk = ow[k] != 0 ? (int)s_map[ow[k] & 0x1fff] : 0xffff;
+				if (i < n) cd[i] = kk != 0xffff ? (kk << 16 | (int)((unsigned)dn[k] >> 16)) : -1;
+			}
+		}
+		__syncthreads();                               // ... and read: the first-x keys may take their place
+		if (tid == 0) s_n = 0;
+		__syncthreads();
+		if (lane == 0 && n_b) atomicAdd(&s_n, n_b);
+		__syncthreads();
+		if (tid == 0) { A.seg_end2[task] = (uint32_t)(base + nk); A.cnt_u[task] = nk; A.cnt_b[task] = s_n; }
+		// chain.c:406-411: chains by the x of their first anchor, stable (kernel T replays the reference's sort where that matters)
+		if (nk <= RANK_MAX) {
+			for (int i = tid; i < nk; i += FNT) s_a[i] = rkey[i];
+			__syncthreads();
+			for (int i = tid; i < nk; i += FNT) {
+				const uint64_t key = s_a[i];
+				int before = 0;
+				for (int j = 0; j < nk; ++j) { const uint64_t kj = s_a[j]; before += (kj < key) | ((kj == key) & (j < i)); }
+				A.rkey1[base + before] = key; A.val1[base + before] = i;
+			}
+		} else {
+			for (int i = tid; i < nk; i += FNT) val0[i] = i;
+			__syncthreads();
+			if (wave0) wave_sort64<false, true>(rkey, A.rkey1 + base, val0, A.val1 + base, nk, lane, s_cnt);
+		}
+		return;
+	}
+	// ---- the general form: the chain ends are sorted first and an owner is the RANK of its chain
 	// chain.c:368-372: best peak first.  Up to RANK_MAX keys: every thread counts the keys that come before its own (all threads read the same
 	// key at a time: a broadcast) -- no passes, no barriers; more keys: the radix sort of the first wave, in LDS while both buffers fit
 	if (nu <= RANK_MAX) {
@@ -776,7 +950,8 @@ __global__ __launch_bounds__(64) void epi_emit_cd(EpiArgs A)
 	const int lane = (int)threadIdx.x;
 	const int nu = (int)(A.seg_end1[task] - (uint32_t)base), nk = (int)(A.seg_end2[task] - (uint32_t)base);
 	if (nk == 0) return;
-	const int32_t *cd = A.own + base, *rk2kk = A.rk2kk + base;
+	const int32_t *cd = A.own + base, *rk2kk = A.rk2kk + base, *end2kk = A.v + base;
+	const bool by_key = A.seg_begin[task] == 1;                                  // the chain ends are listed unsorted, with their chain numbers in end2kk
 	int32_t *dest = A.dest + base;
 	const int32_t *ord = A.val1 + base;
 	const uint64_t *u2 = A.u2 + base, *us = A.key1 + base;
@@ -808,7 +983,7 @@ __global__ __launch_bounds__(64) void epi_emit_cd(EpiArgs A)
 			if (at[k] >= 0 && at[k] < n_b) b_out[at[k]] = A.d_a[base + i0 + lane + 64 * k];
 	}
 	for (int r = lane; r < nu; r += 64) {                                        // chains that kept only their (already taken) peak
-		const int kk = rk2kk[r];
+		const int kk = by_key ? end2kk[r] : rk2kk[r];
 		if (kk < 0 || !(kk & NOT_MINE)) continue;
 		const int at = dest[kk & ~NOT_MINE];
 		if (at >= 0 && at < n_b) b_out[at] = A.d_a[base + (int32_t)us[r]];
