@@ -827,21 +827,29 @@ void epi_fused(EpiArgs A, int n_above)
 // ---- exclusive scans of the per-task chain / anchor counts -> compact output offsets ---------------------------------------
 __global__ __launch_bounds__(1024) void epi_offsets(EpiArgs A)
 {
-	__shared__ int64_t s_u[1024], s_b[1024];
-	const int64_t nt = A.n_tasks, per = (nt + 1023) / 1024;
-	const int64_t t0 = min(nt, (int64_t)threadIdx.x * per), t1 = min(nt, t0 + per);
-	int64_t su = 0, sb = 0;
-	for (int64_t t = t0; t < t1; ++t) { su += A.cnt_u[t]; sb += A.cnt_b[t]; }
-	s_u[threadIdx.x] = su; s_b[threadIdx.x] = sb;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int64_t au = 0, ab = 0;
-		for (int k = 0; k < 1024; ++k) { const int64_t xu = s_u[k], xb = s_b[k]; s_u[k] = au; s_b[k] = ab; au += xu; ab += xb; }
-		A.u_off[nt] = au; A.b_off[nt] = ab;
+	// one workgroup: 1 024 tasks at a time, coalesced; scan inside the waves by shuffles, the sixteen wave totals through LDS, a running carry
+	// (eight times as many tasks per step, with all loads in flight together, took the same 0.2 ms)
+	__shared__ int64_t s_u[16], s_b[16];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t nt = A.n_tasks;
+	int64_t carry_u = 0, carry_b = 0;
+	for (int64_t t0 = 0; t0 < nt; t0 += 1024) {
+		const int64_t t = t0 + tid;
+		const int64_t cu = t < nt ? A.cnt_u[t] : 0, cb = t < nt ? A.cnt_b[t] : 0;
+		int64_t iu = cu, ib = cb;                                                 // inclusive scan inside the wave
+		for (int o = 1; o < 64; o <<= 1) {
+			const int64_t yu = __shfl_up(iu, o), yb = __shfl_up(ib, o);
+			if (lane >= o) { iu += yu; ib += yb; }
+		}
+		if (lane == 63) { s_u[wave] = iu; s_b[wave] = ib; }
+		__syncthreads();
+		int64_t wu = 0, wb = 0, tot_u = 0, tot_b = 0;
+		for (int w = 0; w < 16; ++w) { const int64_t xu = s_u[w], xb = s_b[w]; if (w < wave) { wu += xu; wb += xb; } tot_u += xu; tot_b += xb; }
+		if (t < nt) { A.u_off[t] = carry_u + wu + iu - cu; A.b_off[t] = carry_b + wb + ib - cb; }
+		carry_u += tot_u; carry_b += tot_b;
+		__syncthreads();
 	}
-	__syncthreads();
-	su = s_u[threadIdx.x]; sb = s_b[threadIdx.x];
-	for (int64_t t = t0; t < t1; ++t) { A.u_off[t] = su; A.b_off[t] = sb; su += A.cnt_u[t]; sb += A.cnt_b[t]; }
+	if (tid == 0) { A.u_off[nt] = carry_u; A.b_off[nt] = carry_b; }
 }
 
 // ---- kernel T: tasks with more than 64 chains and equal first-x values: the order radix_sort_128x leaves (chain.c:411) ----
