@@ -81,6 +81,8 @@ struct Lds {
 	static constexpr int FMASK = NF * 256 - 1;   // slot of a tile in the f / p rings = its x / q slot mod NF (NF a power of two dividing NX)
 };
 
+constexpr int FBIAS = 14;   // min(dq, dr, span) - gap cost = min3(dq - 1, dr - 1, span - 1) - linear part + (clz(dd | 1) >> 1) - 14 (chain.c:207-209,218)
+
 // what the chunks of one anchor share (wave-uniform unless noted)
 struct AnchorCtx {
 	int xi1, qi1;            // x_i - 1, q_i - 1 (so that dr - 1 and dq - 1 come out of one subtraction each)
@@ -160,8 +162,8 @@ __device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, i
 {
 	if (depth <= NF) {
 		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 4
-		fj = *(const int *)(M.lds + LY::F + o);
-		pj = *(const int *)(M.lds + LY::Pp + o);                  // the ring holds p relative to the piece, as the scan uses it
+		fj = *(const int *)(M.lds + LY::F + o) + FBIAS;           // the ring holds f - FBIAS and 2 p (piece-relative), see the end of the tile loop
+		pj = *(const int *)(M.lds + LY::Pp + o) >> 1;
 	} else {
 		const int j = max(base + rl, 0);                          // lanes before the window of a partly covered tile may point before the task
 		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -318,12 +320,11 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_FAR_REQ "v_add_u32 %[u2], %[fb], %[rl]\n\t" "v_max_i32 %[u2], 0, %[u2]\n\t" "v_lshlrev_b32 %[u2], 4, %[u2]\n\t" \
 	"global_load_dword %[fx], %[u2], %[aptr]\n\t" "global_load_dword %[fq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
 #define MM2C_SCORE_CMP "v_or_b32 %[va], 1, %[dd]\n\t" "v_ffbh_u32 %[va], %[va]\n\t" "v_lshrrev_b32 %[va], 1, %[va]\n\t" "v_cvt_f32_u32 %[vc], %[dd]\n\t" \
-	"v_mul_f32 %[vc], %[avg], %[vc]\n\t" "v_cvt_i32_f32 %[vc], %[vc]\n\t" "v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t" "v_sub_u32 %[sc], %[sc], %[vc]\n\t" \
-	"v_add3_u32 %[sc], %[sc], %[va], -14\n\t"
-#define MM2C_ADDF_CMP "v_add_u32 %[sc], %[sc], %[vf]\n\t"
+	"v_mul_f32 %[vc], %[avg], %[vc]\n\t" "v_cvt_i32_f32 %[vc], %[vc]\n\t" "v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t" "v_sub_u32 %[sc], %[sc], %[vc]\n\t"
+#define MM2C_ADDF_CMP "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t"   /* vf = f[j] - 14 */
 #define MM2C_SCORE_TAB "v_min_u32 %[va], 0x1ff, %[dd]\n\t" "v_lshlrev_b32 %[va], 1, %[va]\n\t" "ds_read_i16 %[va], %[va] offset:%[GAPOFF]\n\t" \
 	"v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t"
-#define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t"
+#define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t" "v_add_u32 %[sc], 14, %[sc]\n\t"   /* vf = f[j] - 14; the table holds 1 - cost */
 
 // ---- the segments in which the two instantiations of the loop differ.  `far`: the tile holds an anchor whose window reaches beyond the LDS ring
 // (bit 30 of its tw word): stamps with a target before the ring go to the global scratch, and a scan that runs through the whole ring without
@@ -346,10 +347,10 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	MM2C_FAR_REQ \
 	"Lnf_%=:\n\t"
 #define MM2C_LK_LEAN \
-	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
-	"s_add_i32 %[lo0], %[lo], -1\n\t" \
+	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
 	"v_mov_b32 %[lom1v], %[lo0]\n\t"
 #define MM2C_HF_FAR \
+	"v_ashrrev_i32 %[vp], 1, %[vp]\n\t" \
 	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
 	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
@@ -372,10 +373,9 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
 	"s_mov_b64 exec, -1\n"
 #define MM2C_HF_LEAN \
-	"v_cndmask_b32_e64 %[u2], -1, %[vp], %[valid]\n\t" \
+	"v_cndmask_b32_e64 %[u2], -2, %[vp], %[valid]\n\t" \
 	"v_max_i32 %[u2], %[u2], %[lom1v]\n\t" \
-	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
-	"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
+	"v_and_b32 %[u2], %[SNM2], %[u2]\n\t" \
 	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"ds_read_u16 %[vb], %[vb] offset:%[STOFF]\n"
 #define MM2C_TAIL_FAR \
@@ -440,6 +440,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
 	SCORE \
 	"s_waitcnt vmcnt(0)\n\t" \
+	"v_add_u32 %[vf], -14, %[vf]\n\t" \
 	"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
 	"v_max_i32 %[vp], -1, %[vp]\n\t" \
 	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
@@ -455,7 +456,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_END_LEAN(SCORE) \
 	"Lend_%=:\n"
 
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE) \
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int tb16, int &own_f, int &own_p, \
@@ -497,8 +498,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_mov_b32 %[d], 0\n\t" \
-		"v_mov_b32 %[vf], %[own_f]\n\t" \
-		"v_mov_b32 %[vp], %[own_p]\n\t" \
+		"v_add_u32 %[vf], -14, %[own_f]\n\t" \
+		"v_lshlrev_b32 %[vp], 1, %[own_p]\n\t" \
 		"v_mov_b32 %[vb], %[ownst]\n\t" \
 		SCORE \
 		"s_branch Lhf_%=\n" \
@@ -543,6 +544,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_waitcnt vmcnt(0)\n\t" \
 		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
 		"v_max_i32 %[vp], -1, %[vp]\n\t" \
+		"v_lshlrev_b32 %[vp], 1, %[vp]\n\t" \
+		"v_add_u32 %[vf], -14, %[vf]\n\t" \
 		"s_branch Lhf_%=\n" \
 		"Lpart_%=:\n\t" \
 		"s_mov_b32 %[n], 0\n\t" \
@@ -575,11 +578,11 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
 		"s_bitset0_b64 %[marked], %[t0]\n\t" \
 		"s_bcnt1_i32_b64 %[t1], %[marked]\n\t" \
-		"s_cbranch_scc0 Lret_%=\n\t" \
+		"s_cbranch_scc0 " LNEXT "\n\t" \
 		"s_add_i32 %[nskip], %[nskip], %[t1]\n\t" \
 		"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
-		"s_branch Lret_%=\n" \
+		"s_branch " LNEXT "\n" \
 		"Lslow2_%=:\n\t" \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n" \
 		"Lslow_%=:\n\t" \
@@ -712,17 +715,17 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), [tb16] "s"(tb16), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
-		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		  [SNM1] "n"(LY::SN - 1), [SNM2] "n"(2 * LY::SN - 2), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc"); \
 	return 63 - L; \
 }
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR)
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR)
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
@@ -855,14 +858,14 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
 		const int ownst = (idx & (SN - 1)) << 1;              // byte offset of the anchor's slot in the stamp ring
-		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
+		const int tx1_l = own_x - 1, tq1_l = own_q - 1, lo2_l = 2 * (lo_c - 1);
 
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
-#define MM2C_CALL(FN) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 lo_l, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
-				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far) : MM2C_CALL(scan_tile_asm_cmp_far);
-				else k = TAB ? MM2C_CALL(scan_tile_asm_tab) : MM2C_CALL(scan_tile_asm_cmp);
+#define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
+                                 LO0, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
+				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo2_l) : MM2C_CALL(scan_tile_asm_cmp, lo2_l);   // lean: twice (window start - 1), the stamp offset of the sink slot
 #undef MM2C_CALL
 				k = __builtin_amdgcn_readfirstlane(k);
 				if (k >= cnt) break;
@@ -895,8 +898,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 		{
 			const int o = (idx << 2) & LY::FMASK;    // ... and enters the f / p rings
-			*(int *)(lds + LY::F + o) = own_f;
-			*(int *)(lds + LY::Pp + o) = own_p;
+			*(int *)(lds + LY::F + o) = own_f - FBIAS;        // what the hand-written score adds: f[j] and its constant term in one
+			*(int *)(lds + LY::Pp + o) = own_p * 2;           // a stamp slot is 2 (p mod SN) bytes into the stamp ring (-1 -> -2: below every window)
 		}
 		cur = nxt; cur_st = nxt_st;
 	}
