@@ -244,57 +244,53 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	const ulonglong2 *a = a_all + base;
 	int32_t *st = st_all + base;
 	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
-	// st[] is monotone: the answers of a tile of 256 anchors start at the answer of the tile before.  When that range of x values fits
-	// the LDS it is staged there with coalesced loads (every x read about twice) and searched there; probing global memory costs a
-	// cache line per lane and step.
-	constexpr int STAGE = 2048;
-	__shared__ uint64_t s_x[STAGE];
+	// st[] is monotone: the answers of a tile of 256 anchors start at the answer of the tile before.  The x values live in an LDS ring indexed
+	// by the anchor (RING of them): a tile adds its own 256 with one coalesced 16-byte load per lane -- requested while the tile before is
+	// being searched, the tiles depend on each other only through that one answer -- and every search probes LDS.  (Staging tile + window
+	// afresh for every tile read each x two to three times and waited for the loads tile by tile: 2.03 ms on the headline batch.)
+	// A window longer than the ring is searched in global memory.
+	constexpr int RING = 2048;
+	__shared__ uint64_t s_x[RING];
 	__shared__ int s_prev;
 	__shared__ unsigned long long s_sum;
 	if (lane == 0) { s_prev = 0; s_sum = 0; }
-	__syncthreads();
-	if (avg_out && n > 0) {
-		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
-		uint64_t sum = 0;
-		for (int k = lane; k < n; k += 256) sum += (a[k].y >> 32) & 0xff;
-		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-		if ((lane & 63) == 0) atomicAdd(&s_sum, (unsigned long long)sum);
-		__syncthreads();
-		if (lane == 0) avg_out[task] = (float)(__dmul_rn(.01, (double)(float)s_sum) / (double)n);
-	}
+	uint64_t span_sum = 0;                                            // chain.c:48: spans of this lane's anchors
+	ulonglong2 nxt = lane < n ? a[lane] : make_ulonglong2(0, 0);
 	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
 		const int i = i0 + lane, cnt = min(256, n - i0);
+		const ulonglong2 cur = nxt;
+		if (i < n) { s_x[i & (RING - 1)] = cur.x; span_sum += (cur.y >> 32) & 0xff; }
+		__syncthreads();                                            // the tile is in the ring; s_prev of the tile before is visible
+		if (i + 256 < n) nxt = a[i + 256];
 		const int range_lo = max(s_prev, max(i0 - P.max_iter, 0)), len = i0 + cnt - range_lo;
-		__syncthreads();                                            // s_prev read by everyone, s_x of the tile before no longer in use
 		int lo = 0;
-		if (len <= STAGE) {
-			for (int k = lane; k < len; k += 256) s_x[k] = a[range_lo + k].x;
-			__syncthreads();
-			if (i < n) {
-				const uint64_t xi = s_x[i - range_lo];
-				int hi = i - range_lo;
-				lo = max(i - P.max_iter, range_lo) - range_lo;          // answer in [lo, hi]; x_i <= x_i + D always holds
+		if (i < n) {
+			const uint64_t xi = cur.x;
+			int hi = i;
+			lo = max(i - P.max_iter, range_lo);                       // answer in [lo, hi]; x_i <= x_i + D always holds
+			if (len <= RING) {
 				while (lo < hi) {
 					const int mid = (lo + hi) >> 1;
-					if (xi > s_x[mid] + D) lo = mid + 1; else hi = mid;   // chain.c:192 condition for "++st"
+					if (xi > s_x[mid & (RING - 1)] + D) lo = mid + 1; else hi = mid;   // chain.c:192 condition for "++st"
 				}
-				lo += range_lo;
+			} else {
+				while (lo < hi) {
+					const int mid = (lo + hi) >> 1;
+					if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;
+				}
 			}
-		} else if (i < n) {
-			const uint64_t xi = a[i].x;
-			int hi = i;
-			lo = max(i - P.max_iter, range_lo);
-			while (lo < hi) {
-				const int mid = (lo + hi) >> 1;
-				if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;
-			}
-		}
-		if (i < n) {
 			st[i] = lo;
 			if (has_cut && lo == i && i > 0) has_cut[task] = 1;      // an empty window: the task can be cut here (chain_cut)
-			if (lane == cnt - 1) s_prev = lo;
 		}
+		__syncthreads();                                            // everybody has read s_prev and is done with the ring slots the next tile overwrites
+		if (i < n && lane == cnt - 1) s_prev = lo;
+	}
+	if (avg_out && n > 0) {
+		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
+		for (int o = 32; o > 0; o >>= 1) span_sum += __shfl_xor(span_sum, o);
+		if ((lane & 63) == 0) atomicAdd(&s_sum, (unsigned long long)span_sum);
 		__syncthreads();
+		if (lane == 0) avg_out[task] = (float)(__dmul_rn(.01, (double)(float)s_sum) / (double)n);
 	}
 }
 
