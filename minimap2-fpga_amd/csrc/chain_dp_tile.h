@@ -19,8 +19,9 @@
 //     against max_dq-1-bw, v_max_u32, compare with bw (valid when max_dq-1 >= bw >= 0: every preset); dr == 0 (equal x, chain.c:202) never
 //     reaches the vector unit: equal x are neighbours in the sorted array, so the lanes to drop are a run that one ballot per TILE locates
 //     and that only moves the start of the own-tile lane mask.
-//   * chain.c's t[] stamps: 16-bit stamp ring in LDS covering every anchor the ring reaches (value 1 + i mod 1024), ds_write_b16 by p,
-//     ds_read_u16 by j; lanes that must not stamp write the slot of anchor lo - 1, so the store needs no exec mask.
+//   * chain.c's t[] stamps: one byte per anchor the ring reaches, value 1 + position in the tile (they only mean something during the scan of
+//     the anchor that wrote them: the ring is wiped per tile), ds_write_b8 by p, ds_read_u8 by j; lanes that must not stamp write the slot of
+//     anchor lo - 1, so the store needs no exec mask.
 //   * the whole scan of the anchors of a tile -- per-anchor scalars, chunk loop, f / p fetch, stamps, score, the order-dependent fold (running
 //     max; max_skip counter in closed form where the first surviving lane is the only new maximum, else prefix max by DPP and, if needed, a
 //     max-plus prefix scan) -- is ONE hand-written instruction sequence (MM2C_SCAN_TILE_ASM below) for the variants that matter (max_skip
@@ -58,7 +59,7 @@ __device__ __forceinline__ int add3i(int a, int b, int c)
 // 16-bit LDS store for the lanes of mask m only (exec is all ones everywhere in this kernel: control flow is wave-uniform)
 __device__ __forceinline__ void lds_store_b16_masked(mask_t m, int byte_addr, int value)
 {
-	asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, -1" : : "s"(m), "v"(byte_addr), "v"(value) : "memory");
+	asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2\n\ts_mov_b64 exec, -1" : : "s"(m), "v"(byte_addr), "v"(value) : "memory");
 }
 // put two wave-uniform values into lane `l` (wave-uniform) of two registers; the lane select goes through M0 because a VALU
 // instruction of gfx9 reads at most one SGPR
@@ -75,7 +76,7 @@ __device__ __forceinline__ void write_lane2(int &v0, int &v1, int a0, int a1, in
 template <int NX, int NF, bool GEN, bool TAB>
 struct Lds {
 	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q rings
-	static constexpr int X = 0, Q = NX * 256, F = 2 * NX * 256, Pp = F + NF * 256, ST = Pp + NF * 256, GAP = ST + 2 * SN,
+	static constexpr int X = 0, Q = NX * 256, F = 2 * NX * 256, Pp = F + NF * 256, ST = Pp + NF * 256, GAP = ST + SN,
 	                     G = GAP + (TAB ? 1024 : 0), BYTES = G + (GEN ? NX * 64 : 0);
 	static constexpr int RB = NX * 256;          // bytes of one x / q ring array
 	static constexpr int FMASK = NF * 256 - 1;   // slot of a tile in the f / p rings = its x / q slot mod NF (NF a power of two dividing NX)
@@ -142,8 +143,8 @@ __device__ __forceinline__ bool chunk_finish(const KParams &P, const AnchorCtx &
 				mk &= ~fm;
 			}
 		}
-		lds_store_b16_masked(mk, LY::ST + ((pj & (SN - 1)) << 1), X.s16_v);
-		const int tj = *(const uint16_t *)(M.lds + LY::ST + ((X.rl + (base & (SN - 1))) << 1));   // same wave, LDS is in order: the stores above (asm volatile, "memory") have landed
+		lds_store_b16_masked(mk, LY::ST + (pj & (SN - 1)), X.s16_v);
+		const int tj = *(const uint8_t *)(M.lds + LY::ST + (X.rl + (base & (SN - 1))));   // same wave, LDS is in order: the stores above (asm volatile, "memory") have landed
 		marked = valid & BALLOT(tj == X.s16);
 	}
 	int sc;
@@ -162,8 +163,8 @@ __device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, i
 {
 	if (depth <= NF) {
 		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 4
-		fj = *(const int *)(M.lds + LY::F + o) + FBIAS;           // the ring holds f - FBIAS and 2 p (piece-relative), see the end of the tile loop
-		pj = *(const int *)(M.lds + LY::Pp + o) >> 1;
+		fj = *(const int *)(M.lds + LY::F + o) + FBIAS;           // the ring holds f - FBIAS and p (piece-relative), see the end of the tile loop
+		pj = *(const int *)(M.lds + LY::Pp + o);
 	} else {
 		const int j = max(base + rl, 0);                          // lanes before the window of a partly covered tile may point before the task
 		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -292,7 +293,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // max_skip on, one segment, max_dq - 1 >= bw; gap cost computed (gap_scale 1) or read from the per-task table.  One instruction sequence
 // per TILE: anchors k_start .. of the tile with first anchor i0, one after the other; lane L = 63 - k holds anchor i0 + k in the per-tile
 // registers: tx / tq = x, q; tx1 / tq1 = x - 1, q - 1; tspan = span; tlo = window start, tbef = anchors of older tiles inside the window
-// (both clamped to what the ring holds; tbef travels in bits 15-23 of tw); tb16 - L = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
+// (both clamped to what the ring holds; tbef travels in bits 15-23 of tw); 64 - L = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
 // all, bit 30: window clamped, bit 31: anchor not handled here.  Results go into the anchor's lane of own_f / own_p.  Returns the position
 // of the first anchor it did not process (cnt when the tile is done, else a bit-31 anchor).  A clamped window that the ring part of the scan
 // does not end (no `break` of chain.c:231) goes on tile by tile from L2 / HBM: x, q from the anchor array, f / p from the task's own
@@ -330,7 +331,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // (bit 30 of its tw word): stamps with a target before the ring go to the global scratch, and a scan that runs through the whole ring without
 // the `break` goes on from memory (bit 28 set at run time).  `lean`: no such anchor in the tile, so nothing of that is tested; the stamp store
 // needs no exec mask either: lanes that must not stamp (filtered out, or p before the window) write the slot of anchor lo - 1 instead, which
-// no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (slots are compared with 1 + i mod 1024, a slot lives for 64 NX anchors).
+// no scan of THIS anchor reads and whose content no other anchor can mistake for its own stamp (stamps are unique within a tile and the ring is wiped when a tile starts).
 // Requests for tiles beyond the ring: the one for the first such tile goes out when an anchor with a clamped window starts (it is needed unless
 // the scan of the ring ends with the `break`), the one for each further tile while the tile before it is filtered.  A request that the `break`
 // has made useless is not awaited when the anchor is committed (that wait cost 5 % on colinear streams): loads return in order, so a later
@@ -350,15 +351,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
 	"v_mov_b32 %[lom1v], %[lo0]\n\t"
 #define MM2C_HF_FAR \
-	"v_ashrrev_i32 %[vp], 1, %[vp]\n\t" \
 	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
 	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
-	"v_lshlrev_b32 %[u2], 1, %[u2]\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
-	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
+	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"s_mov_b64 exec, -1\n\t" \
-	"ds_read_u16 %[vb], %[vb] offset:%[STOFF]\n\t" \
+	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
@@ -373,11 +372,11 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
 	"s_mov_b64 exec, -1\n"
 #define MM2C_HF_LEAN \
-	"v_cndmask_b32_e64 %[u2], -2, %[vp], %[valid]\n\t" \
+	"v_cndmask_b32_e64 %[u2], -1, %[vp], %[valid]\n\t" \
 	"v_max_i32 %[u2], %[u2], %[lom1v]\n\t" \
-	"v_and_b32 %[u2], %[SNM2], %[u2]\n\t" \
-	"ds_write_b16 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-	"ds_read_u16 %[vb], %[vb] offset:%[STOFF]\n"
+	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
+	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
+	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n"
 #define MM2C_TAIL_FAR \
 	"s_cbranch_scc0 Lret_%=\n\t" \
 	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
@@ -459,7 +458,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
-                                    int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int tb16, int &own_f, int &own_p, \
+                                    int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
                                     int addr1, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
 { \
 	typedef Lds<NX, NF, false, TABV> LY; \
@@ -481,7 +480,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_bfe_u32 %[nfull], %[pk], 0x9000f\n\t" \
 		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
 		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
-		"s_sub_i32 %[s16], %[tb16], %[L]\n\t" \
+		"s_sub_i32 %[s16], 64, %[L]\n\t" \
 		"v_mov_b32 %[addr], %[addr1]\n\t" \
 		MM2C_NEXT_XQ \
 		"s_add_i32 %[span1], %[best], -1\n\t" \
@@ -499,7 +498,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_mov_b32 %[d], 0\n\t" \
 		"v_add_u32 %[vf], -14, %[own_f]\n\t" \
-		"v_lshlrev_b32 %[vp], 1, %[own_p]\n\t" \
+		"v_mov_b32 %[vp], %[own_p]\n\t" \
 		"v_mov_b32 %[vb], %[ownst]\n\t" \
 		SCORE \
 		"s_branch Lhf_%=\n" \
@@ -513,7 +512,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
 		"v_add_u32 %[vb], 0x200, %[addr]\n\t" \
-		"v_bfe_u32 %[vb], %[vb], 1, %[RBBITS]\n\t" \
+		"v_bfe_u32 %[vb], %[vb], 2, %[RBBITS]\n\t" \
 		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
 		"s_cbranch_scc1 Lfg_%=\n\t" \
 		"v_and_b32 %[u2], %[FMASK], %[addr]\n\t" \
@@ -544,7 +543,6 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_waitcnt vmcnt(0)\n\t" \
 		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
 		"v_max_i32 %[vp], -1, %[vp]\n\t" \
-		"v_lshlrev_b32 %[vp], 1, %[vp]\n\t" \
 		"v_add_u32 %[vf], -14, %[vf]\n\t" \
 		"s_branch Lhf_%=\n" \
 		"Lpart_%=:\n\t" \
@@ -712,10 +710,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
-		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), [tb16] "s"(tb16), \
+		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
-		  [SNM1] "n"(LY::SN - 1), [SNM2] "n"(2 * LY::SN - 2), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 1), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 2), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc"); \
 	return 63 - L; \
 }
@@ -757,8 +755,6 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	int32_t *f = f_all + base0, *p = p_all + base0, *t = FAR ? t_all + base0 : nullptr;
 	if (ASMV && (uint32_t)(uintptr_t)(void *)lds != 0) { if (lane == 0) status[task] = 3; return; }   // cannot happen: one LDS object per kernel
 
-	uint16_t *const s_t = (uint16_t *)(lds + LY::ST);
-	for (int s = lane; s < SN; s += 64) s_t[s] = 0;
 	const int pbase = pbase_in ? pbase_in[task] : 0;
 	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative)
 
@@ -812,7 +808,9 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (i0 == 0) seg0 = rdlane(own_g, 63);
 			if (BALLOT(rl < cnt && own_g != seg0)) { if (lane == 0) status[task] = 1; return; }
 		}
-		s_t[idx & (SN - 1)] = 0;             // stamp slots of the entering anchors (recycled from idx - SN)
+		// stamps are one byte: 1 + the anchor's position in its tile.  They only mean something during the scan of the anchor that wrote them, so
+		// the whole ring is wiped when a tile starts (two dword stores per lane) and a value identifies its anchor within the tile
+		for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 		const int stamp_lo = i0 - 64 * (NX - 1);   // oldest anchor reachable without global memory while this tile is processed
 		{
 			const int o = (idx & (SN - 1)) << 2;   // the tile enters the x / q rings (its slot held the tile NX tiles back)
@@ -857,15 +855,15 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
-		const int ownst = (idx & (SN - 1)) << 1;              // byte offset of the anchor's slot in the stamp ring
-		const int tx1_l = own_x - 1, tq1_l = own_q - 1, lo2_l = 2 * (lo_c - 1);
+		const int ownst = idx & (SN - 1);                     // byte offset of the anchor's slot in the stamp ring
+		const int tx1_l = own_x - 1, tq1_l = own_q - 1, lom1_l = lo_c - 1;
 
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 LO0, tw_l, (i0 & 1023) + 64, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+                                 LO0, tw_l, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
 				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
-				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo2_l) : MM2C_CALL(scan_tile_asm_cmp, lo2_l);   // lean: twice (window start - 1), the stamp offset of the sink slot
+				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lom1_l) : MM2C_CALL(scan_tile_asm_cmp, lom1_l);   // lean: window start - 1, the sink slot of the stamp store
 #undef MM2C_CALL
 				k = __builtin_amdgcn_readfirstlane(k);
 				if (k >= cnt) break;
@@ -886,7 +884,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				}
 				X.xi1 = xi - 1; X.qi1 = qi - 1; X.span_i = span_i; X.span1_v = span_i - 1;
 				if (GEN) X.seg_i = rdlane(own_g, L);                                                 // chain.c:191
-				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + (i & 1023); X.s16_v = X.s16;   // LDS stamps need to be unique over the life of a slot (64 NX anchors) only
+				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + k; X.s16_v = X.s16;             // LDS stamps: unique within the tile (the ring is wiped per tile)
 				X.far_mode = FAR && lo < stamp_lo;
 				if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
 				else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);
@@ -899,7 +897,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		{
 			const int o = (idx << 2) & LY::FMASK;    // ... and enters the f / p rings
 			*(int *)(lds + LY::F + o) = own_f - FBIAS;        // what the hand-written score adds: f[j] and its constant term in one
-			*(int *)(lds + LY::Pp + o) = own_p * 2;           // a stamp slot is 2 (p mod SN) bytes into the stamp ring (-1 -> -2: below every window)
+			*(int *)(lds + LY::Pp + o) = own_p;
 		}
 		cur = nxt; cur_st = nxt_st;
 	}

@@ -48,7 +48,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
         stamp_lo = i0 - 64 * (NX - 1)
         idx = i0 + 63 - lane                                                      # lane L holds anchor i0 + 63 - L
         m = idx < n
-        s_x[idx[m] % SN] = xlo[idx[m]]; s_q[idx[m] % SN] = q[idx[m]]; s_t[idx[m] % SN] = 0
+        s_x[idx[m] % SN] = xlo[idx[m]]; s_q[idx[m] % SN] = q[idx[m]]; s_t[:] = 0   # one-byte stamps: the ring is wiped per tile
         for k in range(cnt):
             i = i0 + k
             sp_i = span_override if span_override >= 0 else int(span[i])
@@ -65,7 +65,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                 e += 1
             if e:
                 S["eq_run_anchors"] += 1
-            s16 = 1 + (i & 1023)
+            s16 = 1 + (i & 63)
             broke = False
             base = i0
             while base + 63 >= lo and not broke:
