@@ -293,7 +293,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // max_skip on, one segment, max_dq - 1 >= bw; gap cost computed (gap_scale 1) or read from the per-task table.  One instruction sequence
 // per TILE: anchors k_start .. of the tile with first anchor i0, one after the other; lane L = 63 - k holds anchor i0 + k in the per-tile
 // registers: tx / tq = x, q; tx1 / tq1 = x - 1, q - 1; tspan = span; tlo = window start, tbef = anchors of older tiles inside the window
-// (both clamped to what the ring holds; tbef travels in bits 15-23 of tw); 64 - L = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
+// (both clamped to what the ring holds; tbef travels in bits 15-24 of tw); 64 - L = LDS stamp; tw = number of own-tile predecessors inside the window, bit 29: no window at
 // all, bit 30: window clamped, bit 31: anchor not handled here.  Results go into the anchor's lane of own_f / own_p.  Returns the position
 // of the first anchor it did not process (cnt when the tile is done, else a bit-31 anchor).  A clamped window that the ring part of the scan
 // does not end (no `break` of chain.c:231) goes on tile by tile from L2 / HBM: x, q from the anchor array, f / p from the task's own
@@ -477,7 +477,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_bitcmp1_b32 %[pk], 29\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
 		SEG_LK \
-		"s_bfe_u32 %[nfull], %[pk], 0x9000f\n\t" \
+		"s_bfe_u32 %[nfull], %[pk], 0xa000f\n\t" \
 		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
 		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
 		"s_sub_i32 %[s16], 64, %[L]\n\t" \
@@ -732,7 +732,8 @@ __global__ void __launch_bounds__(64)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live,
+              const uint8_t *__restrict__ cls, int my_cls)
 {
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
 	static_assert(512 % (NF * 256) == 0, "the hand-written loop takes a tile's f / p ring slot from the x / q ring address two tiles further on");
@@ -747,6 +748,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if (task >= n_tasks) return;
 	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut): the grid is sized for the worst case
 	if (only_flagged && status[task] == 0) return;
+	if (cls && cls[task] != my_cls) return;                   // ring-size classes (chain_window_start): this task belongs to the other instantiation
 	const int64_t base0 = offsets[task];
 	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base0));
 	if (n <= 0) return;
@@ -850,7 +852,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		const int e_l = above ? (int)__builtin_ctzll(above) : 64;
 		const int w_l = min(rl, idx - lo_l);                      // own-tile predecessors inside the window: lanes lane + 1 .. lane + w
 		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);   // the window clamped to what the ring holds; its anchors in older tiles (<= 64 (NX - 1))
-		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);   // bits 0-5: lanes to scan, bits 8-14: the first of them, bits 15-23: bef
+		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);   // bits 0-5: lanes to scan, bits 8-14: the first of them, bits 15-24: bef
 		if (lo_l >= idx) tw_l |= 1 << 29;
 		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
 		if (e_l > rl) tw_l |= (int)0x80000000;

@@ -29,6 +29,7 @@ struct CutArgs {
 	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;
 	int32_t *d_has_cut = nullptr;   // per task (n_tasks entries), zero on entry: set by the prepass where a window is empty
 	float *d_avg = nullptr;
+	uint8_t *d_cls = nullptr;       // per piece: ring-size class of its task (nullptr: no classes)
 };
 
 struct LaunchArgs {
@@ -39,6 +40,8 @@ struct LaunchArgs {
 	const void *d_anchors;      // 16 B per anchor
 	const float *d_avg;         // per task or nullptr (computed on the device, chain.c:48-49)
 	float *d_avg_ws = nullptr;  // n_tasks floats of workspace: when d_avg is nullptr the prepass computes avg_qspan_scaled into it
+	uint8_t *d_cls = nullptr;   // n_tasks bytes of workspace, or nullptr: ring-size class per task, written by the prepass (tile kernel only)
+	int far_ring = 0;           // 0: one ring size; 1: tasks whose scans are expected to leave the 448-anchor ring get the long ring; 2: every task gets it
 	const int32_t *d_pbase;     // per task or nullptr: added to every p >= 0 on output (tasks that are pieces of a caller's task)
 	int32_t *d_f, *d_p;
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor

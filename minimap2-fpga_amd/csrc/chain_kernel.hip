@@ -234,7 +234,7 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
-                   float *__restrict__ avg_out /* per task, or nullptr */)
+                   float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -253,7 +253,10 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	__shared__ uint64_t s_x[RING];
 	__shared__ int s_prev;
 	__shared__ unsigned long long s_sum;
-	if (lane == 0) { s_prev = 0; s_sum = 0; }
+	__shared__ unsigned long long s_far;
+	if (lane == 0) { s_prev = 0; s_sum = 0; s_far = 0; }
+	const int max_dq = min(P.max_dist_x, P.max_dist_y);
+	uint64_t far_sum = 0;                                             // expected tiles beyond the short ring, see below
 	uint64_t span_sum = 0;                                            // chain.c:48: spans of this lane's anchors
 	ulonglong2 nxt = lane < n ? a[lane] : make_ulonglong2(0, 0);
 	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
@@ -282,8 +285,35 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			st[i] = lo;
 			if (has_cut && lo == i && i > 0) has_cut[task] = 1;      // an empty window: the task can be cut here (chain_cut)
 		}
+		if (cls_out && far_ring == 1) {
+			// Ring-size class of the task.  A scan leaves the 64 (NX - 1) anchors of the short ring when the window is longer AND the `break` of
+			// chain.c:231 does not come first; the break needs a chain among the nearest predecessors, so an anchor counts with the tiles of its
+			// window beyond the ring unless one of its three nearest predecessors passes the filters (chain.c:202-205).  Neighbours in other
+			// waves of the block are not looked at (lanes 0-2 of a wave count as "no chain").
+			const int beyond = i < n ? max((i & ~63) - 64 * (MM2C_NX - 1) - lo, 0) : 0;
+			bool chain = false;
+			const int xi = (int)(uint32_t)cur.x, qi = (int)(uint32_t)cur.y;
+#pragma unroll
+			for (int d = 1; d <= 3; ++d) {
+				const int xj = __shfl_up(xi, d), qj = __shfl_up(qi, d);
+				const int dr = xi - xj, dq = qi - qj, dd = dr > dq ? dr - dq : dq - dr;
+				chain |= (lane & 63) >= d && i - d >= lo && dr > 0 && dq > 0 && dq <= max_dq && dd <= P.bw;
+			}
+			if (beyond > 0 && !chain) far_sum += (uint64_t)((beyond + 63) >> 6);
+		}
 		__syncthreads();                                            // everybody has read s_prev and is done with the ring slots the next tile overwrites
 		if (i < n && lane == cnt - 1) s_prev = lo;
+	}
+	if (cls_out && n > 0) {
+		if (far_ring == 1) {
+			for (int o = 32; o > 0; o >>= 1) far_sum += __shfl_xor(far_sum, o);
+			if ((lane & 63) == 0 && far_sum) atomicAdd(&s_far, (unsigned long long)far_sum);
+			__syncthreads();
+			// measured with every task in one class (short / long ring, ms per 3.28e8 anchors): ava-ont mixed (3.3 tiles per anchor by this
+			// count) 118 / 96, dense (0.85) 83.6 / 82.3, asm20 mixed (0.5) 99.7 / 110.6, headline (0.05) 50.1 / 61.5: the long ring, at half the
+			// occupancy, pays only where scans go far beyond the short one
+			if (lane == 0) cls_out[task] = (n >= 1024 && 10 * s_far > 15 * (unsigned long long)n) ? 1 : 0;
+		} else if (lane == 0) cls_out[task] = far_ring == 2 ? 1 : 0;
 	}
 	if (avg_out && n > 0) {
 		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
@@ -336,7 +366,7 @@ chain_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *__restrict__ o
 // (chain.c:48-49): computed here (or taken from the caller) and copied to every piece.
 __global__ void __launch_bounds__(64)
 chain_cut(int seg_min, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order, const uint4 *__restrict__ a_all,
-          const float *__restrict__ avg_in, const int32_t *__restrict__ st_all, CutArgs C)
+          const float *__restrict__ avg_in, const int32_t *__restrict__ st_all, CutArgs C, const uint8_t *__restrict__ cls)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -349,7 +379,7 @@ chain_cut(int seg_min, int64_t n_tasks, const int64_t *__restrict__ offsets, con
 		// a short task, or no empty window inside it (the prepass saw none): one piece; its avg is left to the DP kernel (negative = "not computed")
 		if (lane == 0) {
 			const int k = atomicAdd(C.d_count, 1);
-			C.d_start[k] = base; C.d_end[k] = base + n; C.d_pbase[k] = 0; C.d_avg[k] = avg_in ? avg_in[task] : -1.0f;
+			C.d_start[k] = base; C.d_end[k] = base + n; C.d_pbase[k] = 0; C.d_avg[k] = avg_in ? avg_in[task] : -1.0f; if (C.d_cls) C.d_cls[k] = cls ? cls[task] : 0;
 		}
 		return;
 	}
@@ -375,7 +405,7 @@ chain_cut(int seg_min, int64_t n_tasks, const int64_t *__restrict__ offsets, con
 				const int c = i0 + (int)__builtin_ctzll(m);
 				if (pass == 1 && lane == 0) {
 					const int k = slot0 + cnt;
-					C.d_start[k] = base + s0; C.d_end[k] = base + c; C.d_pbase[k] = s0; C.d_avg[k] = avg;
+					C.d_start[k] = base + s0; C.d_end[k] = base + c; C.d_pbase[k] = s0; C.d_avg[k] = avg; if (C.d_cls) C.d_cls[k] = cls ? cls[task] : 0;
 				}
 				++cnt; s0 = c;
 				m &= m - 1;
@@ -383,7 +413,7 @@ chain_cut(int seg_min, int64_t n_tasks, const int64_t *__restrict__ offsets, con
 		}
 		if (pass == 1 && lane == 0) {
 			const int k = slot0 + cnt;
-			C.d_start[k] = base + s0; C.d_end[k] = base + n; C.d_pbase[k] = s0; C.d_avg[k] = avg;
+			C.d_start[k] = base + s0; C.d_end[k] = base + n; C.d_pbase[k] = s0; C.d_avg[k] = avg; if (C.d_cls) C.d_cls[k] = cls ? cls[task] : 0;
 		}
 		++cnt;                                                    // the last piece
 		if (pass == 0) {
@@ -534,20 +564,32 @@ static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagg
 }
 
 // ---- second-generation kernel (chain_dp_tile.h): x / q rings of NX tiles, f / p rings of NF tiles
-template <bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
-static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged)
+template <int NX, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, bool classes, int my_cls)
 {
-	constexpr int NX = MM2C_NX, NF = MM2C_NF;
+	constexpr int NF = MM2C_NF;
 	if (L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
 		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,
-		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count);
+		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count, classes ? (const uint8_t *)L.cut.d_cls : (const uint8_t *)nullptr, my_cls);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
 	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t,
-	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr);
+	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, classes ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr, my_cls);
 	return hipGetLastError();
+}
+
+// the short ring (MM2C_NX tiles) for every task, or -- ring-size classes, variants with the hand-written loop only -- the short ring for class 0
+// and a ring of twice the length (half the occupancy) for class 1
+template <bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged)
+{
+	const bool classes = !GEN && SKIP && L.far_ring != 0 && L.d_cls != nullptr && (L.cut.max_pieces == 0 || L.cut.d_cls != nullptr);
+	hipError_t e = launch_tile_nx<MM2C_NX, SKIP, GEN, GS1, FAR, TAB>(L, d_avg, st, only_flagged, classes, 0);
+	if (e != hipSuccess || !classes) return e;
+	if constexpr (!GEN && SKIP) return launch_tile_nx<2 * MM2C_NX, SKIP, GEN, GS1, FAR, TAB>(L, d_avg, st, only_flagged, true, 1);
+	return e;
 }
 
 template <bool SKIP, bool FAR>
@@ -613,12 +655,13 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
-	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out);
+	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
+	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
 	if (e == hipSuccess && L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL(chain_cut, dim3((unsigned)L.n_tasks), dim3(64), 0, st, L.cut.seg_min, L.n_tasks, L.d_offsets, L.d_order,
-		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut);
+		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut, tile && L.far_ring != 0 ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr);
 		e = hipGetLastError();
 		if (n_launches) ++*n_launches;
 	}

@@ -279,7 +279,7 @@ struct mm2c_plan {
 	int device = 0;                         // the device the plan's workspace lives on
 	const int64_t *d_off_user = nullptr;    // mm2c_plan_set_device_offsets: task sizes that only the device knows
 	int64_t n_tasks = 0, total = 0;
-	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr;
+	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr; uint8_t *d_cls = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
 	bool ran = false, epi_ran = false;
 	std::vector<int32_t> sizes_desc;        // task sizes, longest first (host copy: bounds the number of pieces of the device-side cut)
@@ -334,6 +334,8 @@ int mm2c_init(int device_ordinal)
 	G.ring_class = rc ? std::max(0, std::min(4, atoi(rc))) : 3;
 	const char *ef = getenv("MM2C_EPI_FUSED");           // 0: the device epilogue works in HBM for every task (kernels A, B, C)
 	if (ef) G.epi_fused = atoi(ef) != 0;
+	const char *fr = getenv("MM2C_FAR_RING");            // 0: one LDS ring size for every task; 2: the long ring for every task (tests)
+	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
 	G.ready = true;
 	return 0;
 }
@@ -414,6 +416,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "ring_class") == 0) {
 		if (value < 0 || value > 4) return fail(MM2C_E_ARG, "ring_class must be 0 .. 4");
 		G.ring_class = value;
+		return 0;
+	}
+	if (strcmp(key, "far_ring") == 0) {
+		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "far_ring must be 0, 1 or 2");
+		G.far_ring = value;
 		return 0;
 	}
 	if (strcmp(key, "epi_fused") == 0) {
@@ -509,6 +516,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, nt);
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -532,7 +540,7 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 	if (!pl) return;
 	(void)hipSetDevice(pl->device);
 	if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // as hipFree would: the blocks go back to the cache and may be reused at once
-	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st); dev_free(pl->d_avg_ws);
+	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st); dev_free(pl->d_avg_ws); dev_free(pl->d_cls);
 	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
@@ -563,6 +571,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off_user ? pl->d_off_user : pl->d_off; L.d_order = pl->d_order;
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.d_avg_ws = pl->d_avg_ws;
+	L.d_cls = pl->d_cls; L.far_ring = G.far_ring;
 	L.ring_class = G.ring_class;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
@@ -578,13 +587,13 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 				size_t at = 0;
 				auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 				const size_t o_cnt = take(4), o_stat = take(mp * 4), o_hc = take((size_t)pl->n_tasks * 4), o_start = take(mp * 8), o_end = take(mp * 8),
-				             o_pb = take(mp * 4), o_avg = take(mp * 4);
+				             o_pb = take(mp * 4), o_avg = take(mp * 4), o_cls = take(mp);
 				HIP_TRY(dev_alloc((void **)&pl->d_cut, at));
 				char *b = pl->d_cut;
 				pl->cut.max_pieces = max_pieces; pl->cut.seg_min = G.seg_min;
 				pl->cut.d_count = (int32_t *)(b + o_cnt); pl->cut.d_status = (int32_t *)(b + o_stat); pl->cut.d_has_cut = (int32_t *)(b + o_hc);
 				pl->cut.d_start = (int64_t *)(b + o_start); pl->cut.d_end = (int64_t *)(b + o_end);
-				pl->cut.d_pbase = (int32_t *)(b + o_pb); pl->cut.d_avg = (float *)(b + o_avg);
+				pl->cut.d_pbase = (int32_t *)(b + o_pb); pl->cut.d_avg = (float *)(b + o_avg); pl->cut.d_cls = (uint8_t *)(b + o_cls);
 			}
 			pl->cut.min_anchors = G.plan_cut_min;
 			HIP_TRY(hipMemsetAsync(pl->d_cut, 0, 256 + (((size_t)max_pieces * 4 + 255) & ~(size_t)255) + (((size_t)pl->n_tasks * 4 + 255) & ~(size_t)255), st));   // count + status + has_cut

@@ -136,6 +136,29 @@ def test_tile_kernel_paths(max_skip, gap_scale, bw):
     assert bw <= 0 or int((p_ref >= 0).sum()) > a.shape[0] // 3   # (a negative max_skip: the first skip event ends a scan; bw < 0: nothing chains)
 
 
+@pytest.mark.parametrize("far_ring", [1, 2, 0])
+def test_ring_size_classes_in_one_batch(far_ring):
+    """plans give tasks whose scans are expected to go far beyond the 448-anchor LDS ring an instantiation with a ring twice as long (chosen per task
+    by the prepass; far_ring 2: every task, 0: none): a batch under ava-ont scalars with tasks of both kinds, long ones that are cut into pieces
+    on the device included, must come out the same whichever instantiation ran"""
+    import mm2chain
+    from mm2chain import params, synth
+    P = params.ava_ont()
+    parts = []
+    for prof, n, locus, seed in [("mixed", 12000, 400000, 1), ("colinear", 9000, 400000, 2), ("mixed", 700, None, 3), ("dense", 5000, 30000, 4),
+                                 ("mixed", 20000, 400000, 5), ("sparse", 3000, None, 6), ("mixed", 1023, 400000, 7)]:
+        parts.append(synth.make_stream(prof, 1, n, seed=400 + seed, locus=locus)[1].numpy().view(np.uint64))
+    a = np.concatenate(parts)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in parts]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    mm2chain.tune("far_ring", far_ring)
+    try:
+        f, p = gpu_batch(P, off, a)
+    finally:
+        mm2chain.tune("far_ring", 1)
+    assert_same(f, p, f_ref, p_ref, off, f"far_ring={far_ring}")
+
+
 def test_ava_ont_and_asm20_shapes():
     from mm2chain import params
     for P, span in ((params.ava_ont(), 15), (params.asm20(), 19)):

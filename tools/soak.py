@@ -24,6 +24,7 @@ for r in range(rounds):
                            max_iter=int(rng.choice([-3, 0, 1, 63, 64, 65, 200, 1024, 5000, 5000, INT32_MAX])),
                            gap_scale=float(rng.choice([1.0, 1.0, 0.5, 0.8, 2.25, 0.0])), is_cdna=int(rng.integers(0, 2)) if n_segs > 1 or rng.random() < .2 else 0,
                            n_segs=n_segs)
+    mm2chain.tune("far_ring", int(rng.choice([1, 1, 2, 0])))   # ring-size classes of the tile kernel: chosen per task, all long, all short
     mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 4, 4, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
@@ -46,5 +47,5 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 3)
+mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
