@@ -291,15 +291,17 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			// window beyond the ring unless one of its three nearest predecessors passes the filters (chain.c:202-205).  Neighbours in other
 			// waves of the block are not looked at (lanes 0-2 of a wave count as "no chain").
 			const int beyond = i < n ? max((i & ~63) - 64 * (MM2C_NX - 1) - lo, 0) : 0;
-			bool chain = false;
-			const int xi = (int)(uint32_t)cur.x, qi = (int)(uint32_t)cur.y;
+			if (__ballot(beyond > 0) != 0) {                          // (a wave whose windows all fit the short ring has nothing to count)
+				bool chain = false;
+				const int xi = (int)(uint32_t)cur.x, qi = (int)(uint32_t)cur.y;
 #pragma unroll
-			for (int d = 1; d <= 3; ++d) {
-				const int xj = __shfl_up(xi, d), qj = __shfl_up(qi, d);
-				const int dr = xi - xj, dq = qi - qj, dd = dr > dq ? dr - dq : dq - dr;
-				chain |= (lane & 63) >= d && i - d >= lo && dr > 0 && dq > 0 && dq <= max_dq && dd <= P.bw;
+				for (int d = 1; d <= 3; ++d) {
+					const int xj = __shfl_up(xi, d), qj = __shfl_up(qi, d);
+					const int dr = xi - xj, dq = qi - qj, dd = dr > dq ? dr - dq : dq - dr;
+					chain |= (lane & 63) >= d && i - d >= lo && dr > 0 && dq > 0 && dq <= max_dq && dd <= P.bw;
+				}
+				if (beyond > 0 && !chain) far_sum += (uint64_t)((beyond + 63) >> 6);
 			}
-			if (beyond > 0 && !chain) far_sum += (uint64_t)((beyond + 63) >> 6);
 		}
 		__syncthreads();                                            // everybody has read s_prev and is done with the ring slots the next tile overwrites
 		if (i < n && lane == cnt - 1) s_prev = lo;
