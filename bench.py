@@ -3,7 +3,9 @@
 
 One "step" = one pass of the chaining DP (f[], p[] for every anchor) over one CSR batch of synthetic reads that is
 already resident in HBM.  N GPUs = N processes (torch.distributed / RCCL), reads sharded with no data-path
-collective (weak scaling: the per-GPU batch is fixed); one all-reduce of counters at the end.
+collective (weak scaling: the per-GPU batch is fixed); one all-reduce of counters at the end.  The N ranks come from a launcher
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` sets RANK / WORLD_SIZE) or, for the bare
+`python bench.py --gpus N`, from this script itself (launch_ranks: N child processes started before any GPU call).
 
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` prices the dominant kernel against HBM with
 24 algorithmic bytes per anchor (16 B mm128_t read + 4 B f + 4 B p written); `cpu_baseline` times the
@@ -79,6 +81,39 @@ def plan_predict_totals(mm2chain, P, off1, a1):
     return r
 
 
+def launch_ranks(n):
+    """What `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py ...` would do, for the bare `python bench.py --gpus n`:
+    n child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1.  Rank 0's JSON line goes to
+    this process's stdout (inherited).  Returns the exit code: 0 only when every rank ended with 0; when one fails the others are ended."""
+    import socket
+    import subprocess
+    if os.environ.get("MM2C_BENCH_ONE_DEVICE") != "1" and os.environ.get("MM2C_BENCH_REHEARSE_NO_GPU") != "1":
+        have = torch.cuda.device_count()                        # counting devices does not initialise the GPU
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} ended with code {code}; ending the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()                         # exactly the processes started above
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +139,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, BEFORE this process makes any GPU call
+        # (fresh children, never an exec of a process that has touched the GPU); this process only waits for them
+        sys.exit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,6 +151,21 @@ def main():
     # one GPU on a 1-GPU box to exercise the multi-process flow; the real runs use nccl (= RCCL) with one GPU per rank
     backend = os.environ.get("MM2C_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("MM2C_BENCH_ONE_DEVICE") == "1" else local_rank
+    if os.environ.get("MM2C_BENCH_REHEARSE_NO_GPU") == "1":
+        # launcher rehearsal on a box without a GPU (tests/test_cpu_sharding.py): rendezvous, the counter all-reduce and the per-rank gather
+        # with NO chaining work at all -- it exercises launch_ranks() and the rank plumbing, and its line says so (value null)
+        from mm2chain import sharding
+        if world > 1:
+            dist.init_process_group("gloo")
+        tot, _, mx = sharding.allreduce_counters(1000 * (rank + 1), 0, 1000 + rank)
+        per = sharding.gather_elapsed_ns(1000 + rank)
+        if rank == 0:
+            print(json.dumps({"metric": "anchors/sec chained", "value": None, "unit": "anchors/s", "n_gpus": world, "world_size_seen": world,
+                              "rehearsal": "launcher and rank plumbing only: no GPU, no chaining work", "counters_sum": tot, "max_ns": mx,
+                              "per_rank_ns": per, "requested_gpus": args.gpus}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
@@ -215,6 +270,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot_anchors, _, max_ns = sharding.allreduce_counters(total * args.steps, 0, int(elapsed * 1e9))
+    per_rank_ns = sharding.gather_elapsed_ns(int(elapsed * 1e9))
     wall = max_ns / 1e9
 
     # ---- correctness of what was just timed: a sample of tasks against the oracle (outside the timed region)
@@ -240,7 +296,8 @@ def main():
     achieved = total * ALGO_BYTES_PER_ANCHOR / (k_avg_ms * 1e-3) / 1e9
     out = {
         "metric": "anchors/sec chained", "value": tot_anchors / wall, "unit": "anchors/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "n_gpus": world, "world_size_seen": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
+        "per_rank_ms_per_step": [ns / 1e6 / args.steps for ns in per_rank_ns], "slowest_rank": int(np.argmax(per_rank_ns)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"synthetic ONT anchor stream ({args.profile}), {args.anchors_per_read} anchors/read, "
                                f"{args.preset} chaining params (max_dist={P.max_dist_x}, bw={P.bw}, max_iter={P.max_iter}, max_skip={P.max_skip}), "

@@ -76,7 +76,8 @@ int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_by
  * 256/512/1024 anchors of LDS ring per task; "far_ring" 1 = plans give tasks whose scans are expected to go far beyond the 448-anchor
  * LDS ring of the tile kernel an instantiation with a ring twice as long (chosen per task by the prepass; default; env MM2C_FAR_RING), 0 = never,
  * 2 = every task; "epi_fused" 1 = the device epilogue keeps the per-anchor state of tasks of up to
- * 7 680 anchors in LDS (default; env MM2C_EPI_FUSED), 0 = in HBM for every task; "seg_min" = shortest piece (anchors) a task is cut into at
+ * 7 680 anchors in LDS (default; env MM2C_EPI_FUSED), 0 = in HBM for every task; "force_tab" 1 = the tile kernel reads the gap
+ * cost from its LDS table also when gap_scale is 1 (default 0: computed; tests); "seg_min" = shortest piece (anchors) a task is cut into at
  * empty-window positions (default 256, 0 = never cut); "plan_cut" 0/1 = plans cut their tasks of at least "plan_cut_min" anchors (default
  * 8192) into such pieces on the device before the DP (default 1); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for
  * host batches of at least twice that size (default 20 Mi anchors); "multi_min_anchors" = smallest host batch that is split across the
@@ -132,6 +133,10 @@ int mm2c_plan_run_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_a
  * recent mm2c_plan_run_device; synchronises on the end event.  _prepass_ms: the same for the window-start kernel
  * (chain_window_start) that runs just before it. */
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
+/* Which kernel instantiation the most recent mm2c_plan_run_device launched for the tasks' first pass, as text, e.g.
+ * "chain_dp_tile<NX=8,NF=2,SKIP=1,GEN=0,GS1=1,FAR=1,TAB=0> loop=asm classes=1 cut=0" (loop=asm: the hand-written per-tile loop, loop=c++: its
+ * C++ restatement; chain_dp_wave<...>: the first-generation kernel).  For tests and logs: results never depend on the instantiation. */
+int mm2c_plan_last_variant(mm2c_plan_t *plan, char *buf, size_t len);
 int mm2c_plan_last_prepass_ms(mm2c_plan_t *plan, float *ms);
 
 /*

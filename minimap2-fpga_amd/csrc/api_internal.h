@@ -37,6 +37,7 @@ struct Global {
 	std::atomic<int64_t> multi_min_anchors{1 << 20};   // host batches of at least this many anchors are split across the devices
 	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
 	std::atomic<int> ring_class{3};
+	std::atomic<int> force_tab{0};                      // tile kernel: gap cost from the LDS table also when gap_scale == 1 (tests; slower)
 	std::atomic<int> far_ring{1};                       // plans: tasks whose scans are expected to leave the short LDS ring run with a ring twice as long (0: never, 2: all)
 	std::atomic<int> epi_fused{1};                      // device epilogue: tasks that fit the LDS take the fused kernel (0: kernels A, B, C for every task)
 	std::atomic<size_t> combine_max_anchors{1u << 17};   // host paths: calls up to this many anchors are combined with concurrent callers' calls
@@ -108,8 +109,32 @@ int check_offsets(int64_t n_tasks, const int64_t *off);
 int build_order(int64_t n_tasks, const int64_t *off, std::vector<int32_t> &order);
 size_t layout_epilogue(mm2c::EpiArgs &E, char *base, size_t tot, size_t nt, size_t sort_tmp);
 int epilogue_debug_phases();
-hipError_t dev_alloc(void **out, size_t bytes);   // cached device memory for plans and one-shot calls
-void dev_free(void *p);
+hipError_t dev_alloc(void **out, size_t bytes);   // cached device memory for plans and one-shot calls (of the calling thread's current device)
+void dev_free(void *p);                           // waits for the block's device first (as hipFree would), then parks the block in that device's cache
+void dev_free_synced(void *p);                    // the caller has already made sure nothing is in flight on the block (one wait for many blocks)
+
+// makes `dev` the calling thread's current device for the lifetime of the object and puts the caller's device back afterwards: an entry point
+// must not change the current device of a host thread that also drives other GPUs (a torch caller, a worker of another library)
+struct DeviceScope {
+	int prev = -1; bool changed = false; hipError_t err = hipSuccess;
+	explicit DeviceScope(int dev)
+	{
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != dev) { err = hipSetDevice(dev); changed = err == hipSuccess; }
+	}
+	~DeviceScope() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+	DeviceScope(const DeviceScope &) = delete;
+	DeviceScope &operator=(const DeviceScope &) = delete;
+};
+// the stream a stream argument of the C ABI stands for; MM2C_STREAM_LIBRARY is the library's stream, which lives on the primary device
+inline int resolve_stream(void *stream, int device, hipStream_t *out)
+{
+	if (stream == MM2C_STREAM_LIBRARY) {
+		if (device != G.device) return fail(MM2C_E_ARG, "MM2C_STREAM_LIBRARY belongs to the primary device %d; this plan lives on device %d: pass a stream of that device", G.device, device);
+		*out = G.stream;
+	} else *out = (hipStream_t)stream;             // NULL = the HIP null stream (what a default-stream caller such as PyTorch works on)
+	return 0;
+}
 void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
 

@@ -308,6 +308,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // else the max-plus scan n <- max(n + d, 0) over the lanes.
 // Wait states the assembler does not insert for inline asm (gfx940): VALU write -> DPP read of that VGPR: 2 (s_nop 1); VALU write ->
 // v_readlane of it: s_nop 0 kept for safety; LDS results: s_waitcnt lgkmcnt(0); global results: s_waitcnt vmcnt(0).
+// Registers the block touches beyond its operands: VCC and SCC (declared clobbers); M0 (the lane select of v_writelane) and EXEC (the masked
+// stamp stores of the `far` instantiation).  clang refuses both on a clobber list ("reserved registers"): M0 is safe because the compiler loads it
+// right before each of its own uses and never keeps a value in it across a statement; EXEC is saved on entry and that value -- not a literal
+// -1 -- is what the block puts back after every masked store, so the block leaves EXEC exactly as it found it.
+// LDS: the block addresses the kernel's LDS from 0 with immediate offsets (Lds<>): the kernel must own exactly ONE LDS object.  Checked three
+// times: when the library is built (Makefile: the group segment size of every chain_dp_tile kernel in the code object equals Lds<>::BYTES of its
+// template arguments -- a second object would add to it), by tests/test_cpu_abi.py on the shipped library, and at run time (status 3).
 #define MM2C_DPP_STEP(R, CTRL) "s_nop 1\n\t" "v_max_i32_dpp " R ", " R ", " R " " CTRL "\n\t"
 #define MM2C_DPP_PREFIX_MAX(R) MM2C_DPP_STEP(R, "row_shr:1 row_mask:0xf bank_mask:0xf") MM2C_DPP_STEP(R, "row_shr:2 row_mask:0xf bank_mask:0xf") \
 	MM2C_DPP_STEP(R, "row_shr:4 row_mask:0xf bank_mask:0xf") MM2C_DPP_STEP(R, "row_shr:8 row_mask:0xf bank_mask:0xf") \
@@ -356,7 +363,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-	"s_mov_b64 exec, -1\n\t" \
+	"s_mov_b64 exec, %[ex]\n\t" \
 	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
@@ -370,7 +377,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
 	"s_mov_b64 exec, %[mask]\n\t" \
 	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
-	"s_mov_b64 exec, -1\n"
+	"s_mov_b64 exec, %[ex]\n"
 #define MM2C_HF_LEAN \
 	"v_cndmask_b32_e64 %[u2], -1, %[vp], %[valid]\n\t" \
 	"v_max_i32 %[u2], %[u2], %[lom1v]\n\t" \
@@ -447,7 +454,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
-	"s_mov_b64 exec, -1\n\t" \
+	"s_mov_b64 exec, %[ex]\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
 	"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
@@ -464,9 +471,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	typedef Lds<NX, NF, false, TABV> LY; \
 	typedef Lds<NX, NF, false, true> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
-	mask_t mask, valid, mk, marked, nm, se; \
+	mask_t mask, valid, mk, marked, nm, se, ex; \
 	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
+		"s_mov_b64 %[ex], exec\n\t" \
 		"s_sub_i32 %[L], 63, %[kstart]\n" \
 		"Lk_%=:\n\t" \
 		"v_readlane_b32 %[pk], %[tw], %[L]\n\t" \
@@ -705,7 +713,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
 		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [L] "=&s"(L), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
-		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), \
+		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), \
 		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \

@@ -47,8 +47,20 @@ struct LaunchArgs {
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
+	int force_tab = 0;          // 1: the gap-cost table of the tile kernel also for gap_scale == 1 (mm2c_tune("force_tab"); slower, kept for the parity tests)
 	int ring_class;             // 3: tile kernel (general variant: first-generation kernel); 4: tile kernel for every variant; 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
 	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
+};
+
+// which instantiation launch_chain_dp chose for the tasks' first pass (mm2c_plan_last_variant; the parity tests assert it, so that a vector set
+// is known to have gone through the hand-written loop and not through the C++ restatement beside it)
+struct LaunchInfo {
+	int tile;        // 1: chain_dp_tile (second generation), 0: chain_dp_wave
+	int nx, nf, r;   // tile kernel: tiles in the x / q and f / p rings of class 0; wave kernel: anchors in the LDS ring
+	int skip, gen, gs1, far_, tab;
+	int asm_loop;    // the hand-written per-tile loop (scan_tile_asm_*) runs, not scan_anchor<>
+	int classes;     // ring-size classes: class-1 tasks run the instantiation with 2 * nx tiles
+	int cut;         // tasks are cut into pieces on the device first
 };
 
 int chain_ring_anchors(int ring_class);
@@ -56,7 +68,7 @@ int chain_ring_anchors(int ring_class);
 hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_offsets, const int32_t *d_order, const void *d_anchors,
                           uint8_t *d_num_subparts, int64_t *d_total_subparts, int64_t *d_total_trip, hipStream_t st);
 // ev_dp_begin (optional) is recorded between the window-start prepass and the DP kernel
-hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin);
+hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin, LaunchInfo *info = nullptr);
 
 } // namespace mm2c
 

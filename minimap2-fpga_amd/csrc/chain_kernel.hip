@@ -633,7 +633,7 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 
 int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }   // 3, 4: the tile kernel
 
-hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin)
+hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin, LaunchInfo *info)
 {
 	const KParams &P = L.P;
 	if (L.n_tasks <= 0) return hipSuccess;
@@ -651,8 +651,17 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	// the gap-cost table of the tile kernel: dd <= bw <= 511 entries of int16 (cost <= 2.55 * 511 + 4, times gap_scale)
 	// used when gap_scale != 1 (it takes the f64 path of chain.c:219 out of the loop); with gap_scale 1 computing the cost is as fast and the
 	// kernel's LDS stays at 6 KB (measured: 62.8 vs 66.3 ms on the headline batch)
-	static const bool force_tab = getenv("MM2C_FORCE_TAB") != nullptr;   // experiment switch: the table also for gap_scale == 1
+	static const bool force_tab_env = getenv("MM2C_FORCE_TAB") != nullptr;   // experiment switch: the table also for gap_scale == 1
+	const bool force_tab = force_tab_env || L.force_tab != 0;
 	const bool tab = tile && (!gs1 || force_tab) && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
+	if (info) {
+		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
+		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
+		info->skip = skip; info->gen = want_gen; info->gs1 = gs1; info->far_ = t0 ? far_ : (tile ? far_old : far_); info->tab = t0 && tab && !want_gen;
+		info->asm_loop = t0 && skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // = ASM of chain_dp_tile
+		info->classes = t0 && !want_gen && skip && L.far_ring != 0 && L.d_cls != nullptr && (L.cut.max_pieces == 0 || L.cut.d_cls != nullptr);
+		info->cut = L.cut.max_pieces > 0;
+	}
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;

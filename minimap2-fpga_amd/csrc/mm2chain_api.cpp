@@ -80,22 +80,49 @@ hipError_t dev_alloc(void **out, size_t bytes)
 	return hipSuccess;
 }
 
+// the cache that handed out p (blocks are parked in the cache of the device they were allocated on, whatever device is current now)
+static int owner_of(void *p, DevCache::Block *b)
+{
+	for (int d = 0; d < 64; ++d) {
+		DevCache &c = g_caches[d];
+		std::lock_guard<std::mutex> lk(c.mu);
+		for (size_t i = 0; i < c.live.size(); ++i)
+			if (c.live[i].p == p) { *b = c.live[i]; c.live.erase(c.live.begin() + (long)i); return d; }
+	}
+	return -1;
+}
+
+static void park_or_release(int d, DevCache::Block b)
+{
+	bool park = false;
+	if (d >= 0) {
+		DevCache &c = g_caches[d];
+		std::lock_guard<std::mutex> lk(c.mu);
+		if (b.size != 0 && c.cached_bytes + b.size <= DevCache::MAX_CACHED && c.free_blocks.size() < 64) {
+			c.free_blocks.push_back(b); c.cached_bytes += b.size; park = true;
+		}
+	}
+	if (!park) (void)hipFree(b.p);
+}
+
+void dev_free_synced(void *p)
+{
+	if (!p) return;
+	DevCache::Block b{p, 0};
+	park_or_release(owner_of(p, &b), b);
+}
+
 void dev_free(void *p)
 {
 	if (!p) return;
-	// like hipFree, this waits for the device: a parked block is handed to the next caller at once, so nothing may still be in flight on it
-	(void)hipDeviceSynchronize();
 	DevCache::Block b{p, 0};
-	bool park = false;
+	const int d = owner_of(p, &b);
 	{
-		std::lock_guard<std::mutex> lk(DC.mu);
-		for (size_t i = 0; i < DC.live.size(); ++i)
-			if (DC.live[i].p == p) { b = DC.live[i]; DC.live.erase(DC.live.begin() + (long)i); break; }
-		if (b.size != 0 && DC.cached_bytes + b.size <= DevCache::MAX_CACHED && DC.free_blocks.size() < 64) {
-			DC.free_blocks.push_back(b); DC.cached_bytes += b.size; park = true;
-		}
+		// like hipFree, this waits for the block's device: a parked block is handed to the next caller at once, so nothing may still be in flight on it
+		DeviceScope on(d >= 0 ? d : cur_device());
+		(void)hipDeviceSynchronize();
 	}
-	if (!park) (void)hipFree(p);
+	park_or_release(d, b);
 }
 
 void dev_cache_release()
@@ -130,17 +157,25 @@ int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int
 	std::vector<int> rcs((size_t)nd, 0);
 	std::vector<std::string> errs((size_t)nd);
 	std::vector<std::thread> th;
-	for (int s = 0; s < nd; ++s) {
-		if (bounds[(size_t)s] == bounds[(size_t)s + 1]) continue;
-		th.emplace_back([&, s]() {
-			std::lock_guard<std::mutex> hold(g_slot_mu[s]);            // one split batch at a time per device context
-			tl_slot = s;
-			rcs[(size_t)s] = fn(s, bounds[(size_t)s], bounds[(size_t)s + 1]);
-			if (rcs[(size_t)s] != 0) errs[(size_t)s] = g_err;
-			tl_slot = -1;
-		});
+	bool spawn_failed = false;
+	try {
+		th.reserve((size_t)nd);
+		for (int s = 0; s < nd; ++s) {
+			if (bounds[(size_t)s] == bounds[(size_t)s + 1]) continue;
+			th.emplace_back([&, s]() {
+				std::lock_guard<std::mutex> hold(g_slot_mu[s]);            // one split batch at a time per device context
+				tl_slot = s;
+				try { rcs[(size_t)s] = fn(s, bounds[(size_t)s], bounds[(size_t)s + 1]); }
+				catch (...) { rcs[(size_t)s] = fail(MM2C_E_ARG, "out of host memory in the worker of a split batch"); }
+				if (rcs[(size_t)s] != 0) errs[(size_t)s] = g_err;
+				tl_slot = -1;
+			});
+		}
+	} catch (...) {
+		spawn_failed = true;                                           // std::system_error from thread creation: the workers already started are joined below
 	}
 	for (auto &t : th) t.join();
+	if (spawn_failed) return fail(MM2C_E_ARG, "could not start the worker threads of a split batch");
 	for (int s = 0; s < nd; ++s) if (rcs[(size_t)s] != 0) return fail(rcs[(size_t)s], "device %d: %s", G.devices[(size_t)s], errs[(size_t)s].c_str());
 	return 0;
 }
@@ -282,6 +317,7 @@ struct mm2c_plan {
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr; uint8_t *d_cls = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
 	bool ran = false, epi_ran = false;
+	mm2c::LaunchInfo info = {};             // what the last run launched (mm2c_plan_last_variant)
 	std::vector<int32_t> sizes_desc;        // task sizes, longest first (host copy: bounds the number of pieces of the device-side cut)
 	char *d_cut = nullptr;                  // piece arrays of the device-side cut (chain_cut), allocated by the first run that cuts
 	mm2c::CutArgs cut;
@@ -423,6 +459,11 @@ int mm2c_tune(const char *key, int value)
 		G.far_ring = value;
 		return 0;
 	}
+	if (strcmp(key, "force_tab") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "force_tab must be 0 or 1");
+		G.force_tab = value;
+		return 0;
+	}
 	if (strcmp(key, "epi_fused") == 0) {
 		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "epi_fused must be 0 or 1");
 		G.epi_fused = value;
@@ -508,7 +549,8 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	pl->sizes_desc.resize((size_t)n_tasks);
 	for (int64_t k = 0; k < n_tasks; ++k) pl->sizes_desc[(size_t)k] = (int32_t)(h_offsets[order[(size_t)k] + 1] - h_offsets[order[(size_t)k]]);
 	pl->device = cur_device();
-	hipError_t e = hipSetDevice(pl->device);
+	DeviceScope on(pl->device);
+	hipError_t e = on.err;
 	const size_t nt = (size_t)std::max<int64_t>(n_tasks, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_off, (nt + 1) * 8);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_order, nt * 4);
@@ -538,14 +580,15 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 void mm2c_plan_destroy(mm2c_plan_t *pl)
 {
 	if (!pl) return;
-	(void)hipSetDevice(pl->device);
-	if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // as hipFree would: the blocks go back to the cache and may be reused at once
-	dev_free(pl->d_off); dev_free(pl->d_order); dev_free(pl->d_status); dev_free(pl->d_t); dev_free(pl->d_st); dev_free(pl->d_avg_ws); dev_free(pl->d_cls);
-	if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
-	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
-	if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
-	dev_free(pl->d_epi);
-	dev_free(pl->d_cut);
+	{
+		DeviceScope on(pl->device);
+		if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // ONE wait, as hipFree would: the blocks go back to the cache and may be reused at once
+		dev_free_synced(pl->d_off); dev_free_synced(pl->d_order); dev_free_synced(pl->d_status); dev_free_synced(pl->d_t); dev_free_synced(pl->d_st);
+		dev_free_synced(pl->d_avg_ws); dev_free_synced(pl->d_cls); dev_free_synced(pl->d_epi); dev_free_synced(pl->d_cut);
+		if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
+		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+		if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
+	}
 	delete pl;
 }
 
@@ -564,15 +607,17 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (pl->n_tasks == 0 || pl->total == 0) return 0;
 	if (!d_anchors || !d_f || !d_p) return fail(MM2C_E_ARG, "device pointer is NULL");
-	HIP_TRY(hipSetDevice(pl->device));
-	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
+	hipStream_t st;
+	if (const int rc = resolve_stream(stream, pl->device, &st)) return rc;
 	mm2c::LaunchArgs L;
 	L.P = to_kparams(&pl->par);
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off_user ? pl->d_off_user : pl->d_off; L.d_order = pl->d_order;
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.d_avg_ws = pl->d_avg_ws;
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring;
-	L.ring_class = G.ring_class;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
@@ -602,7 +647,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	}
 	HIP_TRY(hipEventRecord(pl->ev_pre, st));
 	int nl = 0;
-	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, pl->ev0));
+	HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, pl->ev0, &pl->info));
 	HIP_TRY(hipEventRecord(pl->ev1, st));
 	pl->ran = true;
 	G.tasks += (uint64_t)pl->n_tasks; G.anchors += (uint64_t)pl->total; G.launches += (uint64_t)nl;
@@ -616,7 +661,10 @@ int mm2c_plan_predict_device(mm2c_plan_t *pl, const void *d_anchors, uint8_t *d_
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (pl->n_tasks == 0) return 0;
 	if (!d_anchors && pl->total > 0) return fail(MM2C_E_ARG, "device pointer is NULL");
-	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
+	hipStream_t st;
+	if (const int rc = resolve_stream(stream, pl->device, &st)) return rc;
 	HIP_TRY(mm2c::launch_predict(pl->par.max_dist_x, pl->n_tasks, pl->d_off_user ? pl->d_off_user : pl->d_off, pl->d_order, d_anchors, d_num_subparts,
 	                             d_total_subparts, d_total_trip_count, st));
 	G.launches += 1;
@@ -643,6 +691,17 @@ int mm2c_plan_run_device_n(mm2c_plan_t *pl, const void *d_anchors, int64_t n_anc
 	return mm2c_plan_run_device(pl, d_anchors, d_avg_qspan, d_f, d_p, stream);
 }
 
+int mm2c_plan_last_variant(mm2c_plan_t *pl, char *buf, size_t len)
+{
+	if (!pl || !buf || len == 0) return fail(MM2C_E_ARG, "NULL argument");
+	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
+	const mm2c::LaunchInfo &I = pl->info;
+	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
+	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut);
+	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
+	return 0;
+}
+
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 {
 	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");
@@ -659,7 +718,10 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 	if (!d_u_off || !d_b_off) return fail(MM2C_E_ARG, "device pointer is NULL");
-	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
+	hipStream_t st;
+	if (const int rc = resolve_stream(stream, pl->device, &st)) return rc;
 	if (pl->n_tasks == 0 || pl->total == 0) {
 		HIP_TRY(hipMemsetAsync(d_u_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));
 		HIP_TRY(hipMemsetAsync(d_b_off, 0, ((size_t)pl->n_tasks + 1) * 8, st));
@@ -669,7 +731,6 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
 	if (pl->total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "the device epilogue takes batches of fewer than 2^31 anchors (got %lld)", (long long)pl->total);
 	mm2c::EpiArgs &E = pl->E;
 	if (!pl->d_epi) {
-		HIP_TRY(hipSetDevice(pl->device));
 		const size_t tmp = mm2c::epilogue_sort_temp_bytes(pl->total, pl->n_tasks);
 		const size_t bytes = layout_epilogue(E, nullptr, (size_t)pl->total, (size_t)pl->n_tasks, tmp);
 		HIP_TRY(dev_alloc((void **)&pl->d_epi, bytes));

@@ -23,6 +23,7 @@ struct HostReq {
 //  * avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
 //  * one upload arena [anchors | piece offsets | launch order | p base | avg | status(0)] and one download arena [f | p],
 //    mirrored in pinned memory for small passes: one H2D copy, the kernels, one D2H copy, one sync.
+static ThreadCtx *combiner_ctx();
 int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 {
 	int rc;
@@ -67,7 +68,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	seg_off.push_back(total);
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
-	HIP_TRY(hipSetDevice(cur_device()));
+	HIP_TRY(hipSetDevice(c == combiner_ctx() ? G.device : cur_device()));   // the context's stream and arenas belong to that device
 	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
 	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
@@ -117,7 +118,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_pbase = (const int32_t *)(c->d_in + o_pb) + s0; L.d_status = (int32_t *)(c->d_in + o_stat) + s0;
 			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-			L.ring_class = G.ring_class;
+			L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
 			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
@@ -144,7 +145,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_status = (int32_t *)(c->d_in + o_stat);
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-	L.ring_class = G.ring_class;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
 	if (staged) {
@@ -186,6 +187,8 @@ struct Combiner {
 	ThreadCtx ctx;                      // stream + arenas of the pass in flight (leader-exclusive)
 	uint64_t epoch = ~0ull;
 } CB;
+
+static ThreadCtx *combiner_ctx() { return &CB.ctx; }
 
 void release_combiner()
 {
@@ -234,7 +237,7 @@ int submit_combined(HostReq *me)
 			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
 			else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
 				CB.ctx = ThreadCtx();
-				hipError_t e = hipSetDevice(cur_device());
+				hipError_t e = hipSetDevice(G.device);                       // the combiner belongs to the primary device, whoever leads first
 				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
 				if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
 				else CB.epoch = G.epoch;
@@ -276,7 +279,9 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	HostReq req;
 	req.par = par; req.n_tasks = n_tasks; req.off = h_offsets; req.a = h_anchors; req.avg = h_avg_qspan; req.f = h_f; req.p = h_p;
 	req.err[0] = 0;
-	if ((size_t)total <= G.combine_max_anchors) {
+	// the combiner's context (stream, arenas) lives on the primary device: the worker of a split batch drives another one and runs on the
+	// context of its own device slot, however small its range is
+	if (!in_split_worker() && (size_t)total <= G.combine_max_anchors) {
 		rc = submit_combined(&req);
 		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
 	} else {
@@ -388,7 +393,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
 		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
-		L.ring_class = G.ring_class;
+		L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 		if (mp > 0 && mp <= (size_t)INT32_MAX) {
 			char *b = w.d_work;
 			L.cut.max_pieces = (int64_t)mp; L.cut.seg_min = G.seg_min; L.cut.min_anchors = G.plan_cut_min;

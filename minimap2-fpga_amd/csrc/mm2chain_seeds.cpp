@@ -43,7 +43,8 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	             o_stack = take(4 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
 	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
 	pl->device = cur_device();
-	hipError_t e = hipSetDevice(pl->device);
+	DeviceScope on(pl->device);
+	hipError_t e = on.err;
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_mem, at);
 	if (e == hipSuccess && n_reads > 0) {
 		std::vector<int64_t> off((size_t)n_reads + 1);
@@ -78,12 +79,14 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
 {
 	if (!pl) return;
-	(void)hipSetDevice(pl->device);
-	if (pl->ran) (void)hipDeviceSynchronize();
-	dev_free(pl->d_mem);
-	if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
-	for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
-	for (int i = 0; i < 4; ++i) if (pl->fork[i]) (void)hipEventDestroy(pl->fork[i]);
+	{
+		DeviceScope on(pl->device);
+		if (pl->ran) (void)hipDeviceSynchronize();
+		dev_free_synced(pl->d_mem);
+		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+		for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
+		for (int i = 0; i < 4; ++i) if (pl->fork[i]) (void)hipEventDestroy(pl->fork[i]);
+	}
 	delete pl;
 }
 
@@ -95,7 +98,10 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	if (pl->n_reads == 0) return 0;
 	if (!d_qlen || (pl->n_matches > 0 && !d_matches) || (pl->total > 0 && (!d_hits || !d_anchors))) return fail(MM2C_E_ARG, "device pointer is NULL");
 	static_assert(sizeof(mm2c_match_t) == sizeof(mm2c::Match), "mm2c_match_t layout");
-	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
+	hipStream_t st;
+	if (const int rc = resolve_stream(stream, pl->device, &st)) return rc;
 	mm2c::SeedArgs &S = pl->S;
 	S.d_matches = (const mm2c::Match *)d_matches; S.d_hits = d_hits; S.d_qlen = d_qlen; S.d_anchors = (ulonglong2 *)d_anchors;
 	S.n_hits = pl->n_hits_declared; pl->n_hits_declared = 0;
@@ -139,7 +145,10 @@ int mm2c_seedplan_run_device_skip(mm2c_seedplan_t *pl, const mm2c_match_t *d_mat
 	int rc = mm2c_seedplan_run_device_n(pl, d_matches, n_matches, d_hits, n_hits, d_qlen, n_qlen, d_anchors, n_anchors, stream);
 	pl->skip = nullptr;
 	if (rc != 0 || pl->n_reads == 0) return rc;
-	hipStream_t st = stream == MM2C_STREAM_LIBRARY ? G.stream : (hipStream_t)stream;
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
+	hipStream_t st;
+	if (const int rc2 = resolve_stream(stream, pl->device, &st)) return rc2;
 	HIP_TRY(hipMemcpyAsync(d_anchor_off_out, pl->d_oo, ((size_t)pl->n_reads + 1) * 8, hipMemcpyDeviceToDevice, st));
 	return 0;
 }
@@ -149,6 +158,8 @@ int mm2c_seedplan_check(mm2c_seedplan_t *pl, int64_t *n_reads_with_ties)
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
 	if (n_reads_with_ties) *n_reads_with_ties = 0;
 	if (!pl->ran || pl->n_reads == 0) return 0;
+	DeviceScope on(pl->device);
+	HIP_TRY(on.err);
 	HIP_TRY(hipEventSynchronize(pl->ev1));
 	std::vector<int32_t> st((size_t)pl->n_reads), ti((size_t)pl->n_reads);
 	HIP_TRY(hipMemcpy(st.data(), pl->S.status, st.size() * 4, hipMemcpyDeviceToHost));

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 		}
 		hits_seen += total;
 	}
+	// the hits of the read's matches must add up to its anchor range in both modes (with skip_seed the range is a capacity and `run` may be smaller)
+	if (hits_seen != na) { if (lane == 0) { A.status[read] = 1; if (A.d_count) A.d_count[read] = 0; } return; }
 	if (A.d_count) { if (lane == 0) A.d_count[read] = run; }
 	else if (run != na && lane == 0) A.status[read] = 1;
 	x_or = wave_or(x_or); x_and = ~wave_or(~x_and);

@@ -151,6 +151,12 @@ class ChainPlan:
         N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")
         return ms.value
 
+    def last_variant(self):
+        """text naming the kernel instantiation the last run launched (mm2c_plan_last_variant)"""
+        buf = C.create_string_buffer(192)
+        N.check(self.lib.mm2c_plan_last_variant(self.handle, buf, len(buf)), "mm2c_plan_last_variant")
+        return buf.value.decode()
+
     def last_prepass_ms(self):
         ms = C.c_float(0)
         N.check(self.lib.mm2c_plan_last_prepass_ms(self.handle, C.byref(ms)), "mm2c_plan_last_prepass_ms")

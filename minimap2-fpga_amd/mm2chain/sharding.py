@@ -44,3 +44,14 @@ def allreduce_counters(anchors, pairs, elapsed_ns, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return int(t[0]), int(t[1]), int(m[0])
+
+
+def gather_elapsed_ns(elapsed_ns, device=None):
+    """every rank's elapsed ns, in rank order, on every rank (the bench line names the slowest rank)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(elapsed_ns)]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    mine = torch.tensor([int(elapsed_ns)], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(t[0]) for t in out]

@@ -80,6 +80,25 @@ multi = np.concatenate(parts)
 multi = multi[np.argsort(multi[:, 0], kind="stable")]
 cases.append(("synth:dense:4 reference/strand groups in one task", multi, 5000, 5000, 500))
 
+# (6) the shapes bench.py times (BASELINE configs 2, 4, 5): the FIRST reads of its own streams (same generator, same seed 20240, so these
+#     are tasks of the benchmarked batches) under the scalars of each preset -- map-ont (options.c:24-31), asm20 (span 19, 7 500 anchors per
+#     read, options.c:113-122), ava-ont (bw 2000, max_gap 10000, 20 000 anchors per read in a 400 kb locus, options.c:83-86) -- and the ragged
+#     variant of SURVEY 8d
+BENCH_SEED = 20240
+for prof, n_reads in [("mixed", 2), ("dense", 1), ("colinear", 1), ("sparse", 1)]:
+    off, a = synth.make_stream(prof, n_reads, 5000, seed=BENCH_SEED)
+    for r in range(n_reads):
+        cases.append((f"bench:map-ont:{prof}:read {r}", a.numpy().view(np.uint64)[int(off[r]):int(off[r + 1])], 5000, 5000, 500))
+for prof in ("mixed", "dense"):
+    off, a = synth.make_stream(prof, 1, 7500, seed=BENCH_SEED, q_span=19)
+    cases.append((f"bench:asm20:{prof}:read 0", a.numpy().view(np.uint64), 5000, 5000, 500))
+for prof in ("mixed", "colinear"):
+    off, a = synth.make_stream(prof, 1, 20000, seed=BENCH_SEED, locus=400000)
+    cases.append((f"bench:ava-ont:{prof}:read 0", a.numpy().view(np.uint64), 10000, 10000, 2000))
+off, a = synth.make_stream("mixed", 3, (1000, 9000), seed=BENCH_SEED)
+for r in range(3):
+    cases.append((f"bench:map-ont:mixed ragged:read {r}", a.numpy().view(np.uint64)[int(off[r]):int(off[r + 1])], 5000, 5000, 500))
+
 out = {"n_cases": np.array(len(cases))}
 tot = 0
 for k, (name, a, mdx, mdy, bw) in enumerate(cases):

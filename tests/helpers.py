@@ -24,8 +24,9 @@ def oracle_batch(par, offsets, anchors):
     return f, p
 
 
-def gpu_batch(par, offsets, anchors, avg=None):
-    """run the HIP path through the C ABI (plan, device-resident) and return f, p as numpy"""
+def gpu_batch(par, offsets, anchors, avg=None, variant=None):
+    """run the HIP path through the C ABI (plan, device-resident) and return f, p as numpy; `variant`: a list that receives the text of
+    mm2c_plan_last_variant (which kernel instantiation ran)"""
     import mm2chain
     a_np = np.ascontiguousarray(anchors).view(np.int64).reshape(-1, 2)
     d_a = torch.from_numpy(a_np).cuda()
@@ -36,6 +37,8 @@ def gpu_batch(par, offsets, anchors, avg=None):
     plan = mm2chain.ChainPlan(par, offsets)
     plan.run(d_a, d_f, d_p, d_avg)
     torch.cuda.synchronize()
+    if variant is not None:
+        variant.append(plan.last_variant())
     plan.close()
     return d_f.cpu().numpy(), d_p.cpu().numpy()
 

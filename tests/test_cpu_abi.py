@@ -3,6 +3,7 @@ the reference's three C++ symbols, and fails loudly (no CPU fallback) when there
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -100,6 +101,16 @@ def test_header_is_self_contained_c99_and_cxx11(tmp_path):
     inc = os.path.join(root, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "cxx.o")])
+
+
+def test_hand_written_loop_owns_the_kernels_only_lds_object():
+    """the assembly of chain_dp_tile addresses LDS from 0: every instantiation's group segment in the shipped code objects must be exactly
+    its Lds<> object (tools/check_lds_layout.py, also run by the Makefile after linking)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lds_layout
+    seen, bad = check_lds_layout.check(os.path.join(ROOT, "minimap2-fpga_amd", "libmm2chain_hip.so"))
+    assert seen >= 20 and not bad, bad
+    assert check_lds_layout.lds_bytes(8, 2, 0, 0) == 5632      # 5.5 KB per wave: 28 waves per CU (DESIGN 3.2)
 
 
 def test_split_model_getter_returns_the_header_constants():

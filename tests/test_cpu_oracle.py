@@ -242,8 +242,15 @@ def test_oracle_equals_the_references_own_device_kernel():
         par = P(max_dist_x=mdx, max_dist_y=mdy, bw=bw, max_skip=2**31 - 1, max_iter=1024)
         f, p, _ = ob.chain_fpv(par, a, avg)
         assert np.array_equal(f, z[f"c{k}_f"]) and np.array_equal(p, z[f"c{k}_p"]), f"chain.c loop with V2 scalars, case {k} {z[f'c{k}_name']}"
+        # the same loop with the max-skip machinery of chain.c:226-233 switched ON but unable to fire: inside 1024 candidates the counter
+        # reaches at most 1023 (the nearest candidate i-1 is never stamped), so max_skip = 1023 must give the reference's values too.
+        # The GPU test runs these scalars through the hand-written loop (SKIP = true instantiation); this pins the oracle it is compared with.
+        par = P(max_dist_x=mdx, max_dist_y=mdy, bw=bw, max_skip=1023, max_iter=1024)
+        f, p, _ = ob.chain_fpv(par, a, avg)
+        assert np.array_equal(f, z[f"c{k}_f"]) and np.array_equal(p, z[f"c{k}_p"]), f"chain.c loop, max_skip 1023 / max_iter 1024, case {k} {z[f'c{k}_name']}"
         n_anch += a.shape[0]; n_deep += int((ns == 8).sum())
-    assert n_anch > 30000 and n_deep > 3000     # anchors whose window fills all 8 sub-parts (look-back of 1024)
+    assert n_anch > 150000 and n_deep > 3000     # anchors whose window fills all 8 sub-parts (look-back of 1024)
+    assert n_cases >= 35                         # incl. the first reads of bench.py's own streams under map-ont / asm20 / ava-ont scalars
 
 
 def test_host_epilogue_of_the_library_equals_the_oracle_mm_chain_dp():

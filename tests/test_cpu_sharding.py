@@ -72,6 +72,24 @@ def test_two_rank_gloo_shards_cover_the_batch():
     assert res[0][4] == res[1][4] > 0
 
 
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must become two ranks (launch_ranks: fresh child processes, RANK / WORLD_SIZE /
+    MASTER_* set, rendezvous on 127.0.0.1) and print n_gpus 2.  No GPU here: MM2C_BENCH_REHEARSE_NO_GPU makes each rank do the rendezvous, the
+    counter all-reduce and the per-rank gather only; the same flow with real work runs on the GPU box (test_gpu_parity.py)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MM2C_BENCH_REHEARSE_NO_GPU"] = "1"
+    for n in (2, 1):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["world_size_seen"] == n and out["requested_gpus"] == n
+        assert out["counters_sum"] == 1000 * n * (n + 1) // 2 and out["per_rank_ns"] == [1000 + k for k in range(n)] and out["max_ns"] == 1000 + n - 1
+
+
 def test_in_process_device_split_covers_and_balances():
     """mm2c_split_tasks (the split the host-batch entries use when mm2c_init_devices configured several devices; cf. the reference's
     per-kernel queue scaffolding chain_hardware.cpp:9-23): with a fake device count, every task lands in exactly one contiguous range, in

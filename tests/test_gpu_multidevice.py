@@ -68,6 +68,35 @@ def test_host_batches_split_across_device_contexts(n_ctx):
         assert np.array_equal(out[k][0], res1[k][0]), k          # seeds -> chains == anchors -> chains (scores and counts; the order among equal x is the sort's)
 
 
+def test_small_ranges_of_a_split_batch_stay_on_their_own_device_context():
+    """ranges of at most combine_max_anchors (2^17) anchors used to go through the call combiner, whose stream and arenas belong to the primary
+    device, from worker threads bound to other devices; a worker now always runs on the context of its own device slot.  Small batch, three
+    contexts, per-read calls (which do use the combiner) before and after, passes counted."""
+    import mm2chain
+    from mm2chain import params, _native as N
+    P = params.map_ont()
+    off, a = _stream("mixed", 60, (200, 3000), seed=5)
+    assert int(off[-1]) < 3 * (1 << 17)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    mm2chain.shutdown()
+    mm2chain.init_devices([0, 0, 0])
+    try:
+        mm2chain.tune("multi_min_anchors", 1000)
+        k = 7
+        f1, p1 = mm2chain.chain_task(P, a[off[k]:off[k + 1]], ob.avg_qspan(a[off[k]:off[k + 1]]))       # creates the combiner's context
+        assert_same(f1, p1, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, "per-read call before the split batch")
+        st0 = N.Stats(); N.load().mm2c_get_stats(st0)
+        f, p = mm2chain.chain_batch_host(P, off, a)
+        st1 = N.Stats(); N.load().mm2c_get_stats(st1)
+        assert_same(f, p, f_ref, p_ref, off, "split batch with ranges below combine_max_anchors")
+        assert st1.passes - st0.passes == 3                      # one pass per device context, none through the combiner
+        f1, p1 = mm2chain.chain_task(P, a[off[k]:off[k + 1]], ob.avg_qspan(a[off[k]:off[k + 1]]))
+        assert_same(f1, p1, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, "per-read call after the split batch")
+    finally:
+        mm2chain.shutdown()
+        mm2chain.init(0)
+
+
 def test_devices_named_in_the_environment_for_hosts_whose_init_hook_carries_no_ordinals(monkeypatch):
     """hardware_init(long, char *) (chain_hardware.h:69) -> mm2c_init(-1): MM2C_DEVICES names the devices"""
     import mm2chain
@@ -95,3 +124,20 @@ def test_devices_named_in_the_environment_for_hosts_whose_init_hook_carries_no_o
         monkeypatch.delenv("MM2C_DEVICES", raising=False)
         mm2chain.shutdown()
         mm2chain.init(0)
+
+
+def test_bench_gpus_2_starts_two_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` (no launcher): two rank processes, here sharing the box's one MI355X (MM2C_BENCH_ONE_DEVICE) and talking gloo
+    (RCCL needs one GPU per rank); each runs the real timed loop on its own batch, the line reports n_gpus 2 and both ranks' checks"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MM2C_BENCH_BACKEND="gloo", MM2C_BENCH_ONE_DEVICE="1")
+    for extra in ([], ["--strong", "--ragged"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "512", "--distinct", "256",
+                            "--anchors-per-read", "2000", "--cpu-seconds", "0"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+        assert out["verified_vs_oracle"] is True and out["value"] > 0
+        assert out["scaling"] == ("strong" if extra else "weak")

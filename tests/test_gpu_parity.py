@@ -136,6 +136,26 @@ def test_tile_kernel_paths(max_skip, gap_scale, bw):
     assert bw <= 0 or int((p_ref >= 0).sum()) > a.shape[0] // 3   # (a negative max_skip: the first skip event ends a scan; bw < 0: nothing chains)
 
 
+@pytest.mark.parametrize("max_skip,far_ring", [(25, 1), (1000, 1), (1000, 0), (25, 2), (INT32_MAX, 1)])
+def test_far_lookback_in_partial_tail_tiles(max_skip, far_ring, knobs):
+    """the last tile of a task holds cnt < 64 anchors; when their windows reach beyond the LDS ring the `far` instantiation of the hand-written
+    loop runs with lanes that hold no anchor, prefetches of x / q beyond the ring in flight at the tile's (and the task's) end, and far stamps
+    for a partial tile (the memory fault of round 2 came from that corner: loads still in flight when the block ended).  Tasks of every
+    residue class of interest, every anchor inside one window, so that scans really go beyond the ring unless the break comes first."""
+    from mm2chain import params, synth
+    knobs("far_ring", far_ring)
+    sizes = [449, 450, 511, 513, 575, 577, 640 + 1, 960 + 63, 1024 + 1, 1024 + 31, 1087, 1500 + 37, 2048 + 2, 3000 + 5, 64 * 40 + 33, 7 * 64 + 62]
+    parts = [synth.make_stream("dense", 1, n, seed=900 + k, locus=3000 if k % 2 else 4500)[1].numpy().view(np.uint64) for k, n in enumerate(sizes)]
+    a = np.concatenate(parts)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    P = params.make_params(max_skip=max_skip)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    v = []
+    f, p = gpu_batch(P, off, a, variant=v)
+    assert_same(f, p, f_ref, p_ref, off, f"partial tail tiles, max_skip={max_skip}, far_ring={far_ring}: {v[0]}")
+    assert "FAR=1" in v[0] and ("loop=asm" in v[0]) == (max_skip < 5000), v
+
+
 @pytest.mark.parametrize("far_ring", [1, 2, 0])
 def test_ring_size_classes_in_one_batch(far_ring):
     """plans give tasks whose scans are expected to go far beyond the 448-anchor LDS ring an instantiation with a ring twice as long (chosen per task
@@ -166,6 +186,28 @@ def test_ava_ont_and_asm20_shapes():
         f_ref, p_ref = oracle_batch(P, off, a)
         f, p = gpu_batch(P, off, a)
         assert_same(f, p, f_ref, p_ref, off, f"span {span}")
+
+
+@pytest.mark.parametrize("preset,profile", [("asm20", "mixed"), ("asm20", "dense"), ("ava-ont", "mixed"), ("ava-ont", "colinear"), ("map-ont", "ragged")])
+def test_configs_4_and_5_at_their_bench_shapes(preset, profile):
+    """BASELINE configs 4 and 5 (stand-ins of SURVEY 8d) at the shapes `bench.py --preset asm20 / ava-ont` times, and the ragged variant of
+    config 2: 256 reads of 7 500 anchors with span 19 (asm20: options.c:113-122), 256 reads of 20 000 anchors in a 400 kb locus under
+    bw 2000 / max_gap 10000 (ava-ont: options.c:83-86), 256 reads of U[1000, 9000] anchors; the same generator and seed as bench.py, so these
+    are the first reads of the benchmarked batches.  HIP against the oracle, element by element."""
+    from mm2chain import params, synth
+    n_reads = 256
+    if preset == "asm20":
+        P, (off, a) = params.asm20(), synth.make_stream(profile, n_reads, 7500, seed=20240, q_span=19)
+    elif preset == "ava-ont":
+        P, (off, a) = params.ava_ont(), synth.make_stream(profile, n_reads, 20000, seed=20240, locus=400000)
+    else:
+        P, (off, a) = params.map_ont(), synth.make_stream("mixed", n_reads, (1000, 9000), seed=20240)
+    off, a = off.numpy(), a.numpy().view(np.uint64)
+    f_ref, p_ref, _ = ob.chain_batch(P, off, a, n_threads=min(16, os.cpu_count() or 4))
+    v = []
+    f, p = gpu_batch(P, off, a, variant=v)
+    assert_same(f, p, f_ref, p_ref, off, f"{preset} {profile}: {v[0]}")
+    assert "loop=asm" in v[0] and "SKIP=1" in v[0] and "FAR=1" in v[0], v
 
 
 def _multiseg_task(rng, n, n_segs):
@@ -618,28 +660,84 @@ def test_device_epilogue_on_arbitrary_forests(seed, epi_path):
     assert n_chains > 10
 
 
+def _ref_cl_groups():
+    """tests/golden/ref_cl_kernel_fp.npz grouped by scalar set: {(mdx, mdy, bw): (offsets, anchors, f, p)}; every task has one q_span"""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cl_kernel_fp.npz"))
+    groups = {}
+    for k in range(int(z["n_cases"])):
+        key = tuple(int(v) for v in z[f"c{k}_scalars"][:3])
+        groups.setdefault(key, []).append(k)
+    out = {}
+    for key, ks in groups.items():
+        off = np.concatenate([[0], np.cumsum([z[f"c{k}_anchors"].shape[0] for k in ks])]).astype(np.int64)
+        out[key] = (off, np.concatenate([z[f"c{k}_anchors"] for k in ks]), np.concatenate([z[f"c{k}_f"] for k in ks]), np.concatenate([z[f"c{k}_p"] for k in ks]))
+    return z, out
+
+
 def test_hip_equals_the_references_own_device_kernel():
     """f[] / p[] the REFERENCE'S OWN device kernel produced (device/minimap2_opencl.cl compiled for the host and called like
     run_chaining_on_hw does; tests/golden/ref_cl_kernel_fp.npz, generator beside it) against the HIP path, element by element:
     through the reference's C++ symbol run_chaining_on_hw (chain_hardware.h:68) and through a device-resident plan with the V2 scalars"""
     import mm2chain
     from mm2chain import params
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cl_kernel_fp.npz"))
-    tasks, fs, ps = [], [], []
+    z, groups = _ref_cl_groups()
     for k in range(int(z["n_cases"])):
         a, (mdx, mdy, bw, q_span), avg = z[f"c{k}_anchors"], [int(v) for v in z[f"c{k}_scalars"]], float(z[f"c{k}_avg"])
         ns = z[f"c{k}_num_subparts"]
         ret, f, p = mm2chain.run_chaining_on_hw(a.shape[0], mdx, mdy, bw, q_span, avg, a, ns, int(ns.sum()), tid=k)
         assert ret == 0
         assert_same(f, p, z[f"c{k}_f"], z[f"c{k}_p"], None, f"run_chaining_on_hw, case {k} {z[f'c{k}_name']}")
-        if (mdx, mdy, bw) == (5000, 5000, 500) and q_span == 15:
-            tasks.append(a); fs.append(z[f"c{k}_f"]); ps.append(z[f"c{k}_p"])
-    off = np.concatenate([[0], np.cumsum([t.shape[0] for t in tasks])]).astype(np.int64)
-    f, p = gpu_batch(params.fpga_v2(5000, 5000, 500, 15), off, np.concatenate(tasks))
-    assert_same(f, p, np.concatenate(fs), np.concatenate(ps), off, "plan with V2 scalars")
-    # and the stock CPU semantics (V1) restricted to what V2 can express: same vectors
-    f, p = gpu_batch(params.make_params(max_skip=INT32_MAX, max_iter=1024), off, np.concatenate(tasks))
-    assert_same(f, p, np.concatenate(fs), np.concatenate(ps), off, "plan with V1 kernel, max_skip = inf, max_iter = 1024")
+    for (mdx, mdy, bw), (off, a, f_ref, p_ref) in groups.items():
+        v = []
+        f, p = gpu_batch(params.make_params(mdx, mdy, bw, INT32_MAX, 1024, 1.0, 0, 1, -1, mm2chain.MM2C_F_IGNORE_SEG), off, a, variant=v)
+        assert_same(f, p, f_ref, p_ref, off, f"plan with V2 scalars {(mdx, mdy, bw)}")
+        assert "SKIP=0" in v[0] and "loop=c++" in v[0], v
+        # and the stock CPU semantics (V1) restricted to what V2 can express: same vectors
+        f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=INT32_MAX, max_iter=1024), off, a)
+        assert_same(f, p, f_ref, p_ref, off, f"plan with V1 kernel, max_skip = inf, max_iter = 1024, {(mdx, mdy, bw)}")
+
+
+@pytest.fixture
+def knobs():
+    """tuning knobs a test changes, put back afterwards (results never depend on them; the instantiation that runs does)"""
+    import mm2chain
+    yield mm2chain.tune
+    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0),
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256)):
+        mm2chain.tune(key, val)
+
+
+@pytest.mark.parametrize("route", ["asm", "asm-tab", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024"])
+def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs):
+    """The reference-produced vectors through the instantiations that carry the throughput.  With max_skip = 1023 and max_iter = 1024 the
+    max-skip machinery of chain.c:226-233 is compiled in and runs (stamps, skip counter, the folds) but cannot fire: among at most 1024
+    candidates the counter reaches at most 1023, because the nearest candidate i-1 is never stamped.  The result must therefore be the
+    reference kernel's own f[] / p[] (.cl:116-154), and the launcher picks SKIP = true -> the hand-written per-tile loop
+    scan_tile_asm_cmp[_far] (look-back 1024 > 448: the `far` instantiation too).  Routes: the gap-cost table (scan_tile_asm_tab[_far]),
+    ring-size classes off / forced, tasks cut into pieces on the device, and the first-generation kernel with each of its ring sizes.
+    Which instantiation ran is asserted from mm2c_plan_last_variant."""
+    from mm2chain import params
+    if route == "asm-tab": knobs("force_tab", 1)
+    if route == "asm-short-ring-only": knobs("far_ring", 0)
+    if route == "asm-long-ring-only": knobs("far_ring", 2)
+    if route == "asm-device-cut": knobs("plan_cut_min", 1000); knobs("seg_min", 64)
+    if route.startswith("wave-"): knobs("ring_class", {"256": 0, "512": 1, "1024": 2}[route[5:]])
+    z, groups = _ref_cl_groups()
+    assert (5000, 5000, 500) in groups and (10000, 10000, 2000) in groups
+    n = 0
+    for (mdx, mdy, bw), (off, a, f_ref, p_ref) in groups.items():
+        v = []
+        f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=1023, max_iter=1024), off, a, variant=v)
+        assert_same(f, p, f_ref, p_ref, off, f"{route}, scalars {(mdx, mdy, bw)}: {v[0]}")
+        if route.startswith("wave-"):
+            assert v[0].startswith(f"chain_dp_wave<R={route[5:]},SKIP=1"), v
+        else:
+            assert v[0].startswith("chain_dp_tile<") and "SKIP=1" in v[0] and "GEN=0" in v[0] and "FAR=1" in v[0] and "loop=asm" in v[0], v
+            assert ("TAB=1" in v[0]) == (route == "asm-tab" and bw <= 511), v
+            assert ("classes=1" in v[0]) == (route != "asm-short-ring-only"), v
+            assert ("cut=1" in v[0]) == (route == "asm-device-cut" and int(np.diff(off).max()) >= 1000), v
+        n += a.shape[0]
+    assert n > 150000
 
 
 def test_hip_on_every_committed_golden_vector():
