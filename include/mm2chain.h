@@ -252,11 +252,25 @@ int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
 int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const mm2c_match_t *h_matches, const uint64_t *h_hits,
                               int64_t n_hits, const int32_t *h_qlen, int64_t *anchor_off, mm2c_anchor_t *anchors);
 
+/* The index's position arrays resident in HBM (the arrays mm_idx_get, index.c, hands out pointers into: rid<<32 | pos<<1 | strand): uploaded
+ * once per index, shared by every later call -- a 288 GB device holds the positions of a human genome index (about 10 GB) beside the batches.
+ * With a resident pool a match's cr_off is an offset into THAT pool and no hit crosses PCIe per read any more. */
+typedef struct mm2c_hitpool mm2c_hitpool_t;
+mm2c_hitpool_t *mm2c_hitpool_create(const uint64_t *h_hits, int64_t n_hits);   /* NULL on failure */
+int64_t mm2c_hitpool_size(const mm2c_hitpool_t *pool);
+void mm2c_hitpool_destroy(mm2c_hitpool_t *pool);                                 /* not while a call that uses it is running */
+
 /* matches in, chains out: collect_seed_hits + mm_chain_dp for a batch of reads (map.c:295-316) with the anchors staying on the GPU.
+ * Big batches run in chunks of whole reads ("pipeline_chunk_anchors") on two streams: the upload of one chunk, the kernels of the
+ * one before and the download of the chains of the one before that overlap; every buffer the chunks use is kept for the next call.
  * anchor_off[n_reads+1] is filled with the anchor counts' prefix sums (= the sum of n per read); u / b as mm2c_mm_chain_dp_batch_host
  * (room for one entry per anchor of the batch). */
 int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
                                const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const int32_t *h_qlen,
+                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b);
+/* the same with the hits taken from a resident pool: h_matches[i].cr_off points into `pool` */
+int mm2c_seed_chain_batch_pool(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                               const mm2c_match_t *h_matches, const mm2c_hitpool_t *pool, const int32_t *h_qlen,
                                int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b);
 
 /* ---- anchor streams on disk (csrc/anchor_stream.c documents the layout) ------------------------ */
@@ -279,6 +293,25 @@ typedef struct { uint64_t tasks, anchors, launches, segments, host_call_ns, pass
    paths cut tasks into; host_call_ns: wall time inside the host-buffer entry points, summed over calling threads; passes: GPU
    passes they issued (concurrent small calls are combined into one pass) */
 void mm2c_get_stats(mm2c_stats_t *out);
+
+/* Where the time of the host-batch entries goes (mm2c_seed_chain_batch_host / _pool, mm2c_mm_chain_dp_batch_host, mm2c_chain_batch_host), summed
+ * since mm2c_init or the last mm2c_reset_stage_stats.  Host stages are wall time of the calling thread(s); device stages are HIP-event time on
+ * the stream of each chunk (chunks of one call overlap on two streams, so the device stages may add up to more than total_ns). */
+typedef struct {
+	uint64_t calls, chunks;      /* entries served, and the chunks their batches were pipelined in */
+	uint64_t total_ns;           /* wall time inside the entries */
+	uint64_t alloc_ns, n_alloc;  /* hipMalloc / hipHostMalloc: device-cache misses, arena growth, pinned staging (whole library) */
+	uint64_t free_ns, n_free;    /* hipFree / hipHostFree and the device waits in front of them (whole library) */
+	uint64_t setup_ns;           /* host: checking the offsets, launch orders, plan objects and their small synchronous uploads */
+	uint64_t h2d_ns;             /* device: uploads (matches, hits or anchors, per-read metadata) */
+	uint64_t seed_ns;            /* device: seed hits -> sorted anchors */
+	uint64_t dp_ns;              /* device: window prepass + chaining DP */
+	uint64_t epi_ns;             /* device: v[], backtrack, chain order */
+	uint64_t d2h_ns;             /* device: downloads of offsets and chains (or f / p) */
+	uint64_t wait_ns;            /* host: blocked on a stream or an event */
+} mm2c_stage_stats_t;
+void mm2c_get_stage_stats(mm2c_stage_stats_t *out);
+void mm2c_reset_stage_stats(void);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,18 @@ struct Global {
 };
 extern Global G;
 
+// mm2c_stage_stats_t, as atomics (the entries run on many host threads)
+struct StageStats {
+	std::atomic<uint64_t> calls{0}, chunks{0}, total_ns{0}, alloc_ns{0}, n_alloc{0}, free_ns{0}, n_free{0}, setup_ns{0}, h2d_ns{0}, seed_ns{0}, dp_ns{0},
+	                      epi_ns{0}, d2h_ns{0}, wait_ns{0};
+};
+extern StageStats SS;
+struct ScopedNs {                        // adds the wall time of its scope to a counter
+	std::atomic<uint64_t> &acc; std::chrono::steady_clock::time_point t0;
+	explicit ScopedNs(std::atomic<uint64_t> &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+	~ScopedNs() { acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // one chunk in flight of mm2c_mm_chain_dp_batch_host (anchors up, DP, epilogue, chains down); grow-only arenas
 struct WholeSlot {
 	hipStream_t st = nullptr;
@@ -70,12 +82,32 @@ struct WholeSlot {
 	}
 };
 
+// one chunk in flight of mm2c_seed_chain_batch_host / _pool (matches up, seed hits -> anchors, DP, epilogue, chains down)
+struct SeedSlot {
+	hipStream_t st = nullptr;
+	hipEvent_t ev[6] = {};                    // begin, uploaded, anchors made, DP done, chains made, offsets downloaded
+	char *d_buf = nullptr, *h_meta = nullptr; // grow-only arena [matches | hits | qlen | anchors | f | p | u_off | b_off | u | b]; pinned [u_off | b_off]
+	size_t cap_buf = 0, cap_hmeta = 0;
+	void *seedplan = nullptr, *plan = nullptr;   // the chunk's plans (their workspace comes from the device cache)
+	int64_t k0 = 0, k1 = 0;
+	size_t o_uo = 0, o_bo = 0, o_u = 0, o_b = 0;
+	bool busy = false, timed = false;
+	void release()
+	{
+		if (d_buf) (void)hipFree(d_buf); if (h_meta) (void)hipHostFree(h_meta);
+		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+		if (st) (void)hipStreamDestroy(st);
+		*this = SeedSlot();
+	}
+};
+
 // per host thread: stream + grow-only buffers (the reference keeps one buffer set per FPGA kernel,
 // chain_hardware.cpp:13-16,379-397, and serialises callers on a mutex).  One device arena for everything that is uploaded
 // ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
 // mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
 struct ThreadCtx {
 	WholeSlot whole[2];
+	SeedSlot seed[2];
 	hipStream_t st = nullptr, st2 = nullptr;   // st2: second stream of the pipelined big-batch path
 	hipEvent_t ev = nullptr;
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
@@ -87,11 +119,16 @@ struct ThreadCtx {
 		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
 		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
 		whole[0].release(); whole[1].release();
+		seed[0].release(); seed[1].release();
 		*this = ThreadCtx();
 	}
 };
 
 int get_thread_ctx(ThreadCtx **out);
+// context of the big-batch entries: the worker of a split batch gets the context of its device slot (as get_thread_ctx); every other caller gets
+// ONE shared context, locked for the duration of the call -- a host whose mini-batches arrive on different pipeline threads (kt_pipeline,
+// map.c:529-620) then reuses the same arenas instead of growing a set per thread
+int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold);
 int cur_device();                                    // device of the calling thread: a worker of a split batch drives its own, everyone else the primary
 int n_devices();
 bool in_split_worker();
@@ -137,6 +174,9 @@ inline int resolve_stream(void *stream, int device, hipStream_t *out)
 }
 void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
+// for callers that have already waited for the stream(s) the plan ran on: no device-wide wait (chunks of a pipelined batch overlap)
+void plan_destroy_synced(mm2c_plan_t *pl);          // mm2chain_api.cpp
+void seedplan_destroy_synced(mm2c_seedplan_t *pl);  // mm2chain_seeds.cpp
 
 } // namespace mm2c_api
 #endif

@@ -24,6 +24,7 @@ int fail(int code, const char *fmt, ...)
 }
 
 Global G;
+StageStats SS;
 
 // Device memory of plans and one-shot calls goes through a small cache: a batched caller creates and destroys plans of similar size
 // for every mini-batch, and hipMalloc / hipFree of gigabytes cost milliseconds each (hipFree also waits for the device).  A freed
@@ -65,6 +66,7 @@ hipError_t dev_alloc(void **out, size_t bytes)
 		}
 	}
 	void *p = nullptr;
+	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
 	hipError_t e = hipMalloc(&p, bytes);
 	if (e != hipSuccess) {                                     // out of memory with blocks parked in the cache: release them and retry
 		std::vector<DevCache::Block> drop;
@@ -102,7 +104,7 @@ static void park_or_release(int d, DevCache::Block b)
 			c.free_blocks.push_back(b); c.cached_bytes += b.size; park = true;
 		}
 	}
-	if (!park) (void)hipFree(b.p);
+	if (!park) { ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipFree(b.p); }
 }
 
 void dev_free_synced(void *p)
@@ -120,6 +122,7 @@ void dev_free(void *p)
 	{
 		// like hipFree, this waits for the block's device: a parked block is handed to the next caller at once, so nothing may still be in flight on it
 		DeviceScope on(d >= 0 ? d : cur_device());
+		ScopedNs timed(SS.free_ns);
 		(void)hipDeviceSynchronize();
 	}
 	park_or_release(d, b);
@@ -208,6 +211,28 @@ int get_thread_ctx(ThreadCtx **out)
 	return 0;
 }
 
+static ThreadCtx g_batch_ctx;
+static std::mutex g_batch_mu;
+static uint64_t g_batch_epoch = ~0ull;
+
+int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
+{
+	if (tl_slot >= 0) return get_thread_ctx(out);                   // the slot's lock is held by run_split
+	hold = std::unique_lock<std::mutex>(g_batch_mu);
+	std::lock_guard<std::mutex> lk(G.mu);
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!g_batch_ctx.st || g_batch_epoch != G.epoch) {
+		g_batch_ctx = ThreadCtx();
+		DeviceScope on(G.device);
+		hipError_t e = on.err;
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_batch_ctx.st, hipStreamNonBlocking);
+		if (e != hipSuccess) return fail(MM2C_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+		g_batch_epoch = G.epoch;
+	}
+	*out = &g_batch_ctx;
+	return 0;
+}
+
 // Second stream of a two-stream pipeline.  The runtime spreads streams of equal priority over a few hardware queues (4 by default)
 // in creation order, so two streams of one pipeline can end up on the same queue and then run strictly one after the other
 // (measured: no overlap at all with the default GPU_MAX_HW_QUEUES=4).  Streams of different priority never share a queue.
@@ -223,8 +248,9 @@ int grow_device(char **p, size_t *cap, size_t need)
 {
 	if (need <= *cap) return 0;
 	const size_t want = std::max(need, *cap * 2);
-	if (*p) (void)hipFree(*p);
+	if (*p) { ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipFree(*p); }
 	*p = nullptr; *cap = 0;
+	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
 	HIP_TRY(hipMalloc((void **)p, want));
 	*cap = want;
 	return 0;
@@ -234,8 +260,9 @@ int grow_pinned(char **p, size_t *cap, size_t need)
 {
 	if (need <= *cap) return 0;
 	const size_t want = std::max(need, *cap * 2);
-	if (*p) (void)hipHostFree(*p);
+	if (*p) { ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipHostFree(*p); }
 	*p = nullptr; *cap = 0;
+	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
 	HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
 	*cap = want;
 	return 0;
@@ -423,6 +450,7 @@ void mm2c_shutdown(void)
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
 	for (size_t k = 0; k < G.devices.size() && k < 64; ++k) if (g_slot_ctx[k].st) { (void)hipSetDevice(G.devices[k]); (void)hipDeviceSynchronize(); g_slot_ctx[k].release(); }
 	(void)hipSetDevice(G.device);
+	{ std::lock_guard<std::mutex> bl(g_batch_mu); if (g_batch_ctx.st) g_batch_ctx.release(); g_batch_epoch = ~0ull; }
 	release_combiner();
 	dev_cache_release();
 	G.thread_ctxs.clear();
@@ -536,6 +564,20 @@ void mm2c_get_stats(mm2c_stats_t *out)
 	out->tasks = G.tasks.load(); out->anchors = G.anchors.load(); out->launches = G.launches.load(); out->segments = G.segments.load(); out->host_call_ns = G.host_call_ns.load(); out->passes = G.passes.load();
 }
 
+void mm2c_get_stage_stats(mm2c_stage_stats_t *o)
+{
+	if (!o) return;
+	o->calls = SS.calls; o->chunks = SS.chunks; o->total_ns = SS.total_ns; o->alloc_ns = SS.alloc_ns; o->n_alloc = SS.n_alloc; o->free_ns = SS.free_ns;
+	o->n_free = SS.n_free; o->setup_ns = SS.setup_ns; o->h2d_ns = SS.h2d_ns; o->seed_ns = SS.seed_ns; o->dp_ns = SS.dp_ns; o->epi_ns = SS.epi_ns;
+	o->d2h_ns = SS.d2h_ns; o->wait_ns = SS.wait_ns;
+}
+
+void mm2c_reset_stage_stats(void)
+{
+	SS.calls = 0; SS.chunks = 0; SS.total_ns = 0; SS.alloc_ns = 0; SS.n_alloc = 0; SS.free_ns = 0; SS.n_free = 0; SS.setup_ns = 0; SS.h2d_ns = 0;
+	SS.seed_ns = 0; SS.dp_ns = 0; SS.epi_ns = 0; SS.d2h_ns = 0; SS.wait_ns = 0;
+}
+
 // ------------------------------------------------------------------------------------------------ plans
 mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets)
 {
@@ -577,12 +619,12 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	return pl;
 }
 
-void mm2c_plan_destroy(mm2c_plan_t *pl)
+static void plan_destroy_impl(mm2c_plan_t *pl, bool wait)
 {
 	if (!pl) return;
 	{
 		DeviceScope on(pl->device);
-		if (pl->ran || pl->epi_ran) (void)hipDeviceSynchronize();   // ONE wait, as hipFree would: the blocks go back to the cache and may be reused at once
+		if (wait && (pl->ran || pl->epi_ran)) { ScopedNs timed(SS.free_ns); (void)hipDeviceSynchronize(); }   // ONE wait, as hipFree would: the blocks go back to the cache and may be reused at once
 		dev_free_synced(pl->d_off); dev_free_synced(pl->d_order); dev_free_synced(pl->d_status); dev_free_synced(pl->d_t); dev_free_synced(pl->d_st);
 		dev_free_synced(pl->d_avg_ws); dev_free_synced(pl->d_cls); dev_free_synced(pl->d_epi); dev_free_synced(pl->d_cut);
 		if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
@@ -591,6 +633,8 @@ void mm2c_plan_destroy(mm2c_plan_t *pl)
 	}
 	delete pl;
 }
+
+void mm2c_plan_destroy(mm2c_plan_t *pl) { plan_destroy_impl(pl, true); }
 
 int64_t mm2c_plan_total_anchors(const mm2c_plan_t *pl) { return pl ? pl->total : 0; }
 
@@ -775,13 +819,17 @@ void *mm2c_pinned_alloc(size_t bytes)
 {
 	void *p = nullptr;
 	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
-	if (hipSetDevice(cur_device()) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+	DeviceScope on(cur_device());
+	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
+	if (on.err != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
 		fail(MM2C_E_HIP, "hipHostMalloc(%zu) failed", bytes);
 		return nullptr;
 	}
 	return p;
 }
 
-void mm2c_pinned_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
+void mm2c_pinned_free(void *ptr) { if (ptr) { ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipHostFree(ptr); } }
 
 } // extern "C"
+
+namespace mm2c_api { void plan_destroy_synced(mm2c_plan_t *pl) { plan_destroy_impl(pl, false); } }

@@ -74,6 +74,10 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
 	const size_t meta_bytes = in_bytes - o_off;
 	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
+	// chunk size of the two-stream pipeline: "pipeline_chunk_anchors" (a chunk that fills the GPU on its own) for batches many times that size;
+	// a batch of a few chunks' worth is cut into about eight pieces of at least 4 Mi anchors instead, whose kernels overlap on the two streams --
+	// the upload of a piece then hides behind the kernels of the one before (one pass over 2 * 10^7 anchors: 1.44 G anchors/s, PCIe and kernels in series)
+	const int64_t pipe_chunk = std::max<int64_t>(std::min<int64_t>(G.pipeline_chunk_anchors, total / 8), std::min<int64_t>(G.pipeline_chunk_anchors, 4 << 20));
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
 	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
 	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
@@ -92,7 +96,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			at += nb;
 		}
 		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
-	} else if (n_req == 1 && total >= 2 * G.pipeline_chunk_anchors) {
+	} else if (n_req == 1 && total >= 2 * pipe_chunk) {
 		// big batch: pipeline it in chunks of whole pieces on two streams, so that the upload of chunk k+1, the kernels of chunk k
 		// and the download of chunk k-1 overlap (PCIe is full duplex); with page-locked caller buffers this runs at PCIe rate
 		if (!c->st2) HIP_TRY(create_partner_stream(&c->st2));
@@ -103,7 +107,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		const HostReq &q = *reqs[0];
 		const mm2c_anchor_t *src = q.a + q.off[0];
 		int32_t *dst_f = q.f + q.off[0], *dst_p = q.p + q.off[0];
-		const int64_t chunk_anchors = G.pipeline_chunk_anchors;      // big enough for one chunk to fill the GPU on its own
+		const int64_t chunk_anchors = pipe_chunk;
 		int nl = 0, k = 0;
 		for (int64_t s0 = 0; s0 < n_seg; ++k) {
 			int64_t s1 = s0 + 1;
@@ -285,6 +289,7 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 		rc = submit_combined(&req);
 		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
 	} else {
+		ScopedNs timed_total(SS.total_ns); ++SS.calls;
 		ThreadCtx *c;
 		if ((rc = get_thread_ctx(&c))) return rc;
 		HostReq *one = &req;
@@ -343,9 +348,12 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 	// everything on the GPU: anchors up, DP, epilogue, chains down; big batches in chunks of whole tasks on two streams, so that the
 	// upload of chunk k+1, the kernels of chunk k and the download of chunk k-1 overlap
 	if (total >= (int64_t)INT32_MAX && G.pipeline_chunk_anchors >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch too big for one chunk");
+	ScopedNs timed_total(SS.total_ns); ++SS.calls;
 	ThreadCtx *c;
-	if ((rc = get_thread_ctx(&c))) return rc;
-	HIP_TRY(hipSetDevice(cur_device()));
+	std::unique_lock<std::mutex> hold;                              // batch calls from different host threads take turns on one set of arenas
+	if ((rc = get_batch_ctx(&c, hold))) return rc;
+	DeviceScope on(cur_device());
+	HIP_TRY(on.err);
 	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors.load() : total;
 	const mm2c_anchor_t *a0 = h_anchors + h_offsets[0];
 	int64_t base_u = 0, base_b = 0;

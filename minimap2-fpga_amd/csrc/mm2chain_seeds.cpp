@@ -76,12 +76,12 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	return pl;
 }
 
-void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
+static void seedplan_destroy_impl(mm2c_seedplan_t *pl, bool wait)
 {
 	if (!pl) return;
 	{
 		DeviceScope on(pl->device);
-		if (pl->ran) (void)hipDeviceSynchronize();
+		if (wait && pl->ran) { ScopedNs timed(SS.free_ns); (void)hipDeviceSynchronize(); }
 		dev_free_synced(pl->d_mem);
 		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 		for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
@@ -89,6 +89,8 @@ void mm2c_seedplan_destroy(mm2c_seedplan_t *pl)
 	}
 	delete pl;
 }
+
+void mm2c_seedplan_destroy(mm2c_seedplan_t *pl) { seedplan_destroy_impl(pl, true); }
 
 int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches, const uint64_t *d_hits, const int32_t *d_qlen,
                              void *d_anchors, void *stream)
@@ -228,32 +230,90 @@ int mm2c_seed_hits_batch_host(int64_t n_reads, const int64_t *h_match_off, const
 	return rc;
 }
 
-// matches in, chains out: collect_seed_hits + mm_chain_dp for a batch of reads (map.c:295-316) without the anchors leaving the GPU
-int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
-                               const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const int32_t *h_qlen,
-                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b)
+// ---- the index's position arrays resident on the device(s)
+struct mm2c_hitpool {
+	int64_t n = 0;
+	int n_dev = 0;
+	int dev[64] = {};
+	uint64_t *d[64] = {};                       // one copy per device the library drives (a split batch reads the copy of its own device)
+};
+
+mm2c_hitpool_t *mm2c_hitpool_create(const uint64_t *h_hits, int64_t n_hits)
+{
+	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (n_hits < 0 || (n_hits > 0 && !h_hits)) { fail(MM2C_E_ARG, "bad argument"); return nullptr; }
+	mm2c_hitpool *hp = new mm2c_hitpool();
+	hp->n = n_hits;
+	for (size_t k = 0; k < G.devices.size() && hp->n_dev < 64; ++k) {
+		const int dv = G.devices[k];
+		bool seen = false;
+		for (int j = 0; j < hp->n_dev; ++j) seen = seen || hp->dev[j] == dv;
+		if (seen) continue;
+		DeviceScope on(dv);
+		void *p = nullptr;
+		hipError_t e = on.err;
+		{ ScopedNs timed(SS.alloc_ns); ++SS.n_alloc; if (e == hipSuccess) e = hipMalloc(&p, (size_t)std::max<int64_t>(n_hits, 1) * 8); }
+		if (e == hipSuccess && n_hits > 0) e = hipMemcpy(p, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { if (p) (void)hipFree(p); fail(MM2C_E_HIP, "mm2c_hitpool_create: %s", hipGetErrorString(e)); mm2c_hitpool_destroy(hp); return nullptr; }
+		hp->dev[hp->n_dev] = dv; hp->d[hp->n_dev] = (uint64_t *)p; ++hp->n_dev;
+	}
+	return hp;
+}
+
+int64_t mm2c_hitpool_size(const mm2c_hitpool_t *hp) { return hp ? hp->n : 0; }
+
+void mm2c_hitpool_destroy(mm2c_hitpool_t *hp)
+{
+	if (!hp) return;
+	for (int j = 0; j < hp->n_dev; ++j) { DeviceScope on(hp->dev[j]); ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipDeviceSynchronize(); (void)hipFree(hp->d[j]); }
+	delete hp;
+}
+
+static const uint64_t *pool_on(const mm2c_hitpool_t *hp, int device)
+{
+	for (int j = 0; j < hp->n_dev; ++j) if (hp->dev[j] == device) return hp->d[j];
+	return nullptr;
+}
+
+// matches in, chains out: collect_seed_hits + mm_chain_dp for a batch of reads (map.c:295-316) without the anchors leaving the GPU.
+// Big batches run in chunks of whole reads on two streams of different priority (= two hardware queues): while chunk k computes, chunk k+1
+// uploads and the chains of chunk k-1 download.  Per chunk: a seed plan and a chain plan (workspace from the device cache: chunks are of
+// similar size, so after the first ones nothing is allocated) and one grow-only arena per slot.  hits come from the caller's host pool
+// (only the range the chunk's matches point into is uploaded; a pool that is shared by all chunks is uploaded once) or from a resident pool.
+static int seed_chain_impl(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                           const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const mm2c_hitpool_t *pool, const int32_t *h_qlen,
+                           int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b)
 {
 	int rc;
+	ScopedNs timed_total(SS.total_ns);
 	if ((rc = check_params(par))) return rc;
 	if (n_reads < 0 || !anchor_off || !u_off || !b_off) return fail(MM2C_E_ARG, "bad argument");
 	anchor_off[0] = 0; u_off[0] = b_off[0] = 0;
 	if (n_reads == 0) return 0;
 	if (!h_match_off || !h_qlen) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if (pool) n_hits = pool->n;
 	const int64_t mb = h_match_off[0], n_m = h_match_off[n_reads] - mb;
 	if (n_m > 0 && !h_matches) return fail(MM2C_E_ARG, "matches is NULL");
-	for (int64_t r = 0; r < n_reads; ++r) {
-		int64_t sum = 0;
-		if (h_match_off[r + 1] < h_match_off[r]) return fail(MM2C_E_ARG, "match offsets not monotone at read %lld", (long long)r);
-		for (int64_t i = h_match_off[r]; i < h_match_off[r + 1]; ++i) {
-			if (h_matches[i].cr_off < 0 || h_matches[i].cr_off + (int64_t)h_matches[i].n > n_hits)
-				return fail(MM2C_E_ARG, "match %lld reaches beyond the hit pool", (long long)i);
-			sum += h_matches[i].n;
+	std::vector<int64_t> cr_lo, cr_hi;                      // per read: the range of the hit pool its matches point into
+	{
+		ScopedNs timed(SS.setup_ns);
+		cr_lo.resize((size_t)n_reads); cr_hi.resize((size_t)n_reads);
+		for (int64_t r = 0; r < n_reads; ++r) {
+			int64_t sum = 0, lo = INT64_MAX, hi = 0;
+			if (h_match_off[r + 1] < h_match_off[r]) return fail(MM2C_E_ARG, "match offsets not monotone at read %lld", (long long)r);
+			for (int64_t i = h_match_off[r]; i < h_match_off[r + 1]; ++i) {
+				const int64_t c0 = h_matches[i].cr_off, c1 = c0 + (int64_t)h_matches[i].n;
+				if (c0 < 0 || c1 > n_hits) return fail(MM2C_E_ARG, "match %lld reaches beyond the hit pool", (long long)i);
+				sum += h_matches[i].n;
+				if (h_matches[i].n) { lo = std::min(lo, c0); hi = std::max(hi, c1); }
+			}
+			cr_lo[(size_t)r] = lo; cr_hi[(size_t)r] = hi;
+			anchor_off[r + 1] = anchor_off[r] + sum;
 		}
-		anchor_off[r + 1] = anchor_off[r] + sum;
 	}
 	const int64_t total = anchor_off[n_reads];
 	if (total == 0) { for (int64_t r = 1; r <= n_reads; ++r) u_off[r] = b_off[r] = 0; return 0; }
-	if (!h_hits || !u || !b) return fail(MM2C_E_ARG, "host pointer is NULL");
+	if ((!pool && !h_hits) || !u || !b) return fail(MM2C_E_ARG, "host pointer is NULL");
 	if (should_split(total)) {
 		// several devices: a contiguous range of reads each (about equal anchor counts), results closed up afterwards as in mm2c_mm_chain_dp_batch_host
 		const int nd = n_devices();
@@ -264,8 +324,8 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 			ao[(size_t)part].assign(m, 0); uo[(size_t)part].assign(m, 0); bo[(size_t)part].assign(m, 0);
 			r0[(size_t)part] = k0; r1[(size_t)part] = k1;
 			const int64_t at = anchor_off[k0];
-			return mm2c_seed_chain_batch_host(par, min_cnt, min_sc, k1 - k0, h_match_off + k0, h_matches, h_hits, n_hits, h_qlen + k0,
-			                                  ao[(size_t)part].data(), uo[(size_t)part].data(), u + at, bo[(size_t)part].data(), b + at);
+			return seed_chain_impl(par, min_cnt, min_sc, k1 - k0, h_match_off + k0, h_matches, h_hits, n_hits, pool, h_qlen + k0,
+			                       ao[(size_t)part].data(), uo[(size_t)part].data(), u + at, bo[(size_t)part].data(), b + at);
 		});
 		if (rc != 0) return rc;
 		int64_t U = 0, B = 0;
@@ -280,47 +340,160 @@ int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc
 		}
 		return 0;
 	}
-	if (total >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "batch of %lld anchors; the limit of one call is 2^31-1", (long long)total);
-	mm2c_seedplan_t *sp = mm2c_seedplan_create(n_reads, h_match_off, anchor_off);
-	if (!sp) return MM2C_E_HIP;
-	mm2c_plan_t *pl = mm2c_plan_create(par, n_reads, anchor_off);
-	if (!pl) { mm2c_seedplan_destroy(sp); return MM2C_E_HIP; }
-	char *d = nullptr;
-	size_t at = 0;
-	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
-	const size_t nr = (size_t)n_reads, tot = (size_t)total;
-	const size_t o_m = take((size_t)n_m * sizeof(mm2c_match_t)), o_h = take((size_t)n_hits * 8), o_q = take(nr * 4), o_a = take(tot * 16),
-	             o_f = take(tot * 4), o_p = take(tot * 4), o_uo = take((nr + 1) * 8), o_bo = take((nr + 1) * 8), o_u = take(tot * 8), o_b = take(tot * 16);
-	hipStream_t st = G.stream;
-	if (in_split_worker()) {                       // the worker of a split batch: the stream of its own device
-		ThreadCtx *c;
-		if ((rc = get_thread_ctx(&c))) { mm2c_plan_destroy(pl); mm2c_seedplan_destroy(sp); return rc; }
-		st = c->st;
+	++SS.calls;
+	ThreadCtx *c;
+	std::unique_lock<std::mutex> hold;                              // batch calls from different host threads take turns on one set of arenas
+	if ((rc = get_batch_ctx(&c, hold))) return rc;
+	const int device = cur_device();
+	DeviceScope on(device);
+	HIP_TRY(on.err);
+	const uint64_t *d_pool = nullptr;
+	if (pool && !(d_pool = pool_on(pool, device))) return fail(MM2C_E_ARG, "the hit pool has no copy on device %d (created before mm2c_init_devices?)", device);
+	// chunks of whole reads
+	const int64_t chunk_anchors = total >= 2 * G.pipeline_chunk_anchors ? G.pipeline_chunk_anchors.load() : std::min<int64_t>(total, (int64_t)INT32_MAX - 1);
+	std::vector<int64_t> cuts(1, 0);
+	for (int64_t k0 = 0; k0 < n_reads;) {
+		int64_t k1 = k0 + 1;
+		while (k1 < n_reads && anchor_off[k1 + 1] - anchor_off[k0] <= chunk_anchors) ++k1;
+		if (anchor_off[k1] - anchor_off[k0] >= (int64_t)INT32_MAX) return fail(MM2C_E_TOOBIG, "a read with 2^31 anchors or more");
+		cuts.push_back(k1); k0 = k1;
 	}
-	auto body = [&]() -> int {
-		int r;
-		HIP_TRY(dev_alloc((void **)&d, at));
-		HIP_TRY(hipMemcpyAsync(d + o_m, h_matches + mb, (size_t)n_m * sizeof(mm2c_match_t), hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(d + o_h, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(d + o_q, h_qlen, nr * 4, hipMemcpyHostToDevice, st));
-		if ((r = mm2c_seedplan_run_device(sp, (const mm2c_match_t *)(d + o_m), (const uint64_t *)(d + o_h), (const int32_t *)(d + o_q), d + o_a, st))) return r;
-		if ((r = mm2c_plan_run_device(pl, d + o_a, nullptr, (int32_t *)(d + o_f), (int32_t *)(d + o_p), st))) return r;
-		if ((r = mm2c_plan_chains_device(pl, d + o_a, (int32_t *)(d + o_f), (int32_t *)(d + o_p), min_cnt, min_sc, (int64_t *)(d + o_uo), (uint64_t *)(d + o_u),
-		                                 (int64_t *)(d + o_bo), d + o_b, st))) return r;
-		HIP_TRY(hipMemcpyAsync(u_off, d + o_uo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipMemcpyAsync(b_off, d + o_bo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		if (u_off[nr] > 0) HIP_TRY(hipMemcpyAsync(u, d + o_u, (size_t)u_off[nr] * 8, hipMemcpyDeviceToHost, st));
-		if (b_off[nr] > 0) HIP_TRY(hipMemcpyAsync(b, d + o_b, (size_t)b_off[nr] * 16, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		return mm2c_seedplan_check(sp, nullptr);
+	const int n_chunks = (int)cuts.size() - 1;
+	// hits of a chunk = the range of the host pool its matches point into; when those ranges add up to much more than the pool (matches that
+	// point all over an index-wide pool) the whole pool goes up once instead
+	std::vector<int64_t> h_lo((size_t)n_chunks, 0), h_hi((size_t)n_chunks, 0);
+	bool whole_pool = false;
+	char *d_whole = nullptr;
+	if (!pool) {
+		int64_t span = 0;
+		for (int ck = 0; ck < n_chunks; ++ck) {
+			int64_t lo = INT64_MAX, hi = 0;
+			for (int64_t r = cuts[(size_t)ck]; r < cuts[(size_t)ck + 1]; ++r) { lo = std::min(lo, cr_lo[(size_t)r]); hi = std::max(hi, cr_hi[(size_t)r]); }
+			if (hi <= lo) lo = hi = 0;
+			h_lo[(size_t)ck] = lo; h_hi[(size_t)ck] = hi; span += hi - lo;
+		}
+		whole_pool = n_chunks > 1 && span > n_hits + n_hits / 2;
+	}
+	int64_t base_u = 0, base_b = 0;
+	int nl = 0;
+
+	auto drop_plans = [&](SeedSlot &w, bool waited) {           // the chunk's kernels are done (waited) or the call failed (wait inside)
+		if (w.seedplan) { if (waited) seedplan_destroy_synced((mm2c_seedplan_t *)w.seedplan); else mm2c_seedplan_destroy((mm2c_seedplan_t *)w.seedplan); w.seedplan = nullptr; }
+		if (w.plan) { if (waited) plan_destroy_synced((mm2c_plan_t *)w.plan); else mm2c_plan_destroy((mm2c_plan_t *)w.plan); w.plan = nullptr; }
 	};
-	rc = body();
-	dev_free(d);
-	mm2c_plan_destroy(pl);
-	mm2c_seedplan_destroy(sp);
-	G.passes += 1;
+	auto enqueue = [&](SeedSlot &w, int ck) -> int {
+		int r;
+		const int64_t k0 = cuts[(size_t)ck], k1 = cuts[(size_t)ck + 1];
+		const size_t nr = (size_t)(k1 - k0), tot = (size_t)(anchor_off[k1] - anchor_off[k0]);
+		const int64_t m0 = h_match_off[k0], m1 = h_match_off[k1];
+		const size_t nm = (size_t)(m1 - m0), nh = pool || whole_pool ? 0 : (size_t)(h_hi[(size_t)ck] - h_lo[(size_t)ck]);
+		if (!w.st) {
+			HIP_TRY(&w == &c->seed[1] ? create_partner_stream(&w.st) : hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+			for (auto &e : w.ev) HIP_TRY(hipEventCreate(&e));
+		}
+		w.k0 = k0; w.k1 = k1; w.busy = true; w.timed = tot > 0;
+		if (tot == 0) return 0;
+		{
+			ScopedNs timed(SS.setup_ns);
+			w.seedplan = mm2c_seedplan_create((int64_t)nr, h_match_off + k0, anchor_off + k0);
+			if (!w.seedplan) return MM2C_E_HIP;
+			w.plan = mm2c_plan_create(par, (int64_t)nr, anchor_off + k0);
+			if (!w.plan) return MM2C_E_HIP;
+		}
+		size_t at = 0;
+		auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+		const size_t o_m = take(nm * sizeof(mm2c_match_t)), o_h = take(nh * 8), o_q = take(nr * 4), o_a = take(tot * 16), o_f = take(tot * 4), o_p = take(tot * 4);
+		w.o_uo = take((nr + 1) * 8); w.o_bo = take((nr + 1) * 8); w.o_u = take(tot * 8); w.o_b = take(tot * 16);
+		if (at > w.cap_buf || 2 * (nr + 1) * 8 > w.cap_hmeta) {      // the arena moves: the chains of the slot's last chunk may still be on their way out of it
+			ScopedNs timed(SS.wait_ns);
+			HIP_TRY(hipStreamSynchronize(w.st));
+		}
+		if ((r = grow_device(&w.d_buf, &w.cap_buf, at + at / 8))) return r;   // (some headroom: chunks differ by a read or two)
+		if ((r = grow_pinned(&w.h_meta, &w.cap_hmeta, 2 * (nr + 1) * 8 + 4096))) return r;
+		char *d = w.d_buf;
+		hipStream_t st = w.st;
+		HIP_TRY(hipEventRecord(w.ev[0], st));
+		HIP_TRY(hipMemcpyAsync(d + o_m, h_matches + m0, nm * sizeof(mm2c_match_t), hipMemcpyHostToDevice, st));
+		if (nh) HIP_TRY(hipMemcpyAsync(d + o_h, h_hits + h_lo[(size_t)ck], nh * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d + o_q, h_qlen + k0, nr * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipEventRecord(w.ev[1], st));
+		// the matches keep their pool-relative cr_off: the kernels get the pool's base, i.e. the chunk's range shifted back by its start
+		const uint64_t *d_hits = pool ? d_pool : whole_pool ? (const uint64_t *)d_whole : (const uint64_t *)(d + o_h) - h_lo[(size_t)ck];
+		if ((r = mm2c_seedplan_run_device((mm2c_seedplan_t *)w.seedplan, (const mm2c_match_t *)(d + o_m), d_hits, (const int32_t *)(d + o_q), d + o_a, st))) return r;
+		HIP_TRY(hipEventRecord(w.ev[2], st));
+		if ((r = mm2c_plan_run_device((mm2c_plan_t *)w.plan, d + o_a, nullptr, (int32_t *)(d + o_f), (int32_t *)(d + o_p), st))) return r;
+		HIP_TRY(hipEventRecord(w.ev[3], st));
+		if ((r = mm2c_plan_chains_device((mm2c_plan_t *)w.plan, d + o_a, (int32_t *)(d + o_f), (int32_t *)(d + o_p), min_cnt, min_sc, (int64_t *)(d + w.o_uo),
+		                                 (uint64_t *)(d + w.o_u), (int64_t *)(d + w.o_bo), d + w.o_b, st))) return r;
+		HIP_TRY(hipEventRecord(w.ev[4], st));
+		HIP_TRY(hipMemcpyAsync(w.h_meta, d + w.o_uo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(w.h_meta + (nr + 1) * 8, d + w.o_bo, (nr + 1) * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipEventRecord(w.ev[5], st));
+		++SS.chunks;
+		return 0;
+	};
+	// waits for the chunk's offsets, places them behind the chunks before it and starts the download of its chains
+	auto finalize = [&](SeedSlot &w) -> int {
+		if (!w.busy) return 0;
+		w.busy = false;
+		const size_t nr = (size_t)(w.k1 - w.k0);
+		if (!w.timed) { for (size_t k = 1; k <= nr; ++k) { u_off[w.k0 + (int64_t)k] = base_u; b_off[w.k0 + (int64_t)k] = base_b; } return 0; }
+		{ ScopedNs timed(SS.wait_ns); HIP_TRY(hipEventSynchronize(w.ev[5])); }
+		float ms[5] = {};
+		for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&ms[k], w.ev[k], w.ev[k + 1]);
+		SS.h2d_ns += (uint64_t)(ms[0] * 1e6f); SS.seed_ns += (uint64_t)(ms[1] * 1e6f); SS.dp_ns += (uint64_t)(ms[2] * 1e6f); SS.epi_ns += (uint64_t)(ms[3] * 1e6f);
+		SS.d2h_ns += (uint64_t)(ms[4] * 1e6f);
+		{	// every kernel of the chunk is done: its plans go back to the device cache now (only the chains, in the slot's arena, are still to leave)
+			const int r = mm2c_seedplan_check((mm2c_seedplan_t *)w.seedplan, nullptr);
+			drop_plans(w, true);
+			if (r) return r;
+		}
+		const int64_t *cu = (const int64_t *)w.h_meta, *cb = cu + nr + 1;
+		for (size_t k = 1; k <= nr; ++k) { u_off[w.k0 + (int64_t)k] = base_u + cu[k]; b_off[w.k0 + (int64_t)k] = base_b + cb[k]; }
+		if (cu[nr] > 0) HIP_TRY(hipMemcpyAsync(u + base_u, w.d_buf + w.o_u, (size_t)cu[nr] * 8, hipMemcpyDeviceToHost, w.st));
+		if (cb[nr] > 0) HIP_TRY(hipMemcpyAsync(b + base_b, w.d_buf + w.o_b, (size_t)cb[nr] * 16, hipMemcpyDeviceToHost, w.st));
+		base_u += cu[nr]; base_b += cb[nr];
+		return 0;
+	};
+	rc = 0;
+	if (whole_pool) {
+		hipError_t e = dev_alloc((void **)&d_whole, (size_t)n_hits * 8);
+		if (e == hipSuccess) e = hipMemcpy(d_whole, h_hits, (size_t)n_hits * 8, hipMemcpyHostToDevice);   // before either stream starts
+		if (e != hipSuccess) rc = fail(MM2C_E_HIP, "uploading the hit pool: %s", hipGetErrorString(e));
+	}
+	for (int ck = 0; ck < n_chunks && rc == 0; ++ck) {
+		SeedSlot &w = c->seed[ck & 1];
+		if ((rc = finalize(w))) break;                              // the chunk before the previous one (same slot): in chunk order
+		rc = enqueue(w, ck);
+	}
+	if (rc == 0) rc = finalize(c->seed[n_chunks & 1]);              // in chunk order: the older slot first
+	if (rc == 0) rc = finalize(c->seed[(n_chunks + 1) & 1]);
+	for (int i = 0; i < 2; ++i) {                                   // until the chains have landed in the caller's arrays
+		SeedSlot &w = c->seed[i];
+		if (w.st) { ScopedNs timed(SS.wait_ns); hipError_t e = hipStreamSynchronize(w.st); if (e != hipSuccess && rc == 0) rc = fail(MM2C_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+		drop_plans(w, false);                                       // (only after a failure is anything left here)
+		w.busy = false;
+	}
+	if (d_whole) dev_free(d_whole);
+	G.tasks += (uint64_t)n_reads; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.passes += (uint64_t)n_chunks;
 	return rc;
 }
 
+int mm2c_seed_chain_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                               const mm2c_match_t *h_matches, const uint64_t *h_hits, int64_t n_hits, const int32_t *h_qlen,
+                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b)
+{
+	return seed_chain_impl(par, min_cnt, min_sc, n_reads, h_match_off, h_matches, h_hits, n_hits, nullptr, h_qlen, anchor_off, u_off, u, b_off, b);
+}
+
+int mm2c_seed_chain_batch_pool(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_reads, const int64_t *h_match_off,
+                               const mm2c_match_t *h_matches, const mm2c_hitpool_t *pool, const int32_t *h_qlen,
+                               int64_t *anchor_off, int64_t *u_off, uint64_t *u, int64_t *b_off, mm2c_anchor_t *b)
+{
+	if (!pool) return fail(MM2C_E_ARG, "pool is NULL");
+	return seed_chain_impl(par, min_cnt, min_sc, n_reads, h_match_off, h_matches, nullptr, 0, pool, h_qlen, anchor_off, u_off, u, b_off, b);
+}
+
 } // extern "C"
+
+namespace mm2c_api { void seedplan_destroy_synced(mm2c_seedplan_t *pl) { seedplan_destroy_impl(pl, false); } }

@@ -27,6 +27,12 @@ class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64), ("segments", C.c_uint64), ("host_call_ns", C.c_uint64), ("passes", C.c_uint64)]
 
 
+class StageStats(C.Structure):
+    """mm2c_stage_stats_t"""
+    _fields_ = [(k, C.c_uint64) for k in ("calls", "chunks", "total_ns", "alloc_ns", "n_alloc", "free_ns", "n_free", "setup_ns", "h2d_ns", "seed_ns", "dp_ns",
+                                          "epi_ns", "d2h_ns", "wait_ns")]
+
+
 # every symbol include/mm2chain.h declares with C linkage: name -> (restype, argtypes)
 C_SYMBOLS = {
     "mm2c_init": (C.c_int, [C.c_int]),
@@ -77,7 +83,14 @@ C_SYMBOLS = {
     "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mm2c_seed_chain_batch_host": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_seed_chain_batch_pool": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm2c_hitpool_create": (C.c_void_p, [C.c_void_p, C.c_int64]),
+    "mm2c_hitpool_size": (C.c_int64, [C.c_void_p]),
+    "mm2c_hitpool_destroy": (None, [C.c_void_p]),
     "mm2c_get_stats": (None, [C.POINTER(Stats)]),
+    "mm2c_get_stage_stats": (None, [C.POINTER(StageStats)]),
+    "mm2c_reset_stage_stats": (None, []),
     "mm2c_stream_write": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mm2c_stream_read": (C.c_int, [C.c_char_p, C.POINTER(Stream)]),
     "mm2c_stream_from_seed_dump": (C.c_int, [C.c_char_p, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Stream)]),

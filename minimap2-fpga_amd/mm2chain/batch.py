@@ -383,6 +383,56 @@ def seed_chain_batch(params: Params, min_cnt, min_sc, match_off, matches, hits, 
     return _split_chains(n_reads, u_off, u, b_off, b)
 
 
+class HitPool:
+    """mm2c_hitpool_t: the index's position arrays resident in HBM (uploaded once per index)"""
+
+    def __init__(self, hits):
+        self.lib = N.load()
+        h = np.ascontiguousarray(hits, dtype=np.uint64)
+        self.handle = self.lib.mm2c_hitpool_create(_np_ptr(h), h.size)
+        if not self.handle:
+            N.check(-4, "mm2c_hitpool_create")
+        self.size = h.size
+
+    def close(self):
+        if self.handle:
+            self.lib.mm2c_hitpool_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def seed_chain_batch_pool(params: Params, min_cnt, min_sc, match_off, matches, pool: HitPool, qlen):
+    """mm2c_seed_chain_batch_pool: as seed_chain_batch with the hits taken from a resident pool (cr_off points into it)"""
+    lib = N.load()
+    mo = np.ascontiguousarray(np.asarray(match_off, dtype=np.int64))
+    m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+    q = np.ascontiguousarray(qlen, dtype=np.int32)
+    n_reads = mo.size - 1
+    if q.size != n_reads or mo[-1] > m.size or mo[0] < 0:
+        raise ValueError("offsets do not fit the arrays")
+    total = max(int(m["n"][mo[0]:mo[-1]].sum()), 1)
+    ao = np.zeros(n_reads + 1, np.int64); u_off = np.zeros(n_reads + 1, np.int64); b_off = np.zeros(n_reads + 1, np.int64)
+    u = np.zeros(total, np.uint64); b = np.zeros((total, 2), np.uint64)
+    N.check(lib.mm2c_seed_chain_batch_pool(C.byref(params), min_cnt, min_sc, n_reads, _np_ptr(mo), _np_ptr(m), pool.handle, _np_ptr(q),
+                                           _np_ptr(ao), _np_ptr(u_off), _np_ptr(u), _np_ptr(b_off), _np_ptr(b)), "mm2c_seed_chain_batch_pool")
+    return _split_chains(n_reads, u_off, u, b_off, b)
+
+
+def stage_stats(reset=False):
+    """mm2c_get_stage_stats as a dict (ns and counts); reset=True clears the counters afterwards"""
+    lib = N.load()
+    st = N.StageStats()
+    lib.mm2c_get_stage_stats(C.byref(st))
+    if reset:
+        lib.mm2c_reset_stage_stats()
+    return {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+
 def hardware_init(buf_size=0, binary_name=b""):
     """the reference symbol bool hardware_init(long, char*) (chain_hardware.h:70)"""
     return bool(getattr(N.load(), "_Z13hardware_initlPc")(buf_size, binary_name))

@@ -49,6 +49,48 @@ static void defaults(mm_idxopt_t *io, mm_mapopt_t *mo)               /* as drive
 	mo->mini_batch_size = 500000000; mo->pe_ori = 0; mo->pe_bonus = 33;
 }
 
+/* The index's position arrays as ONE pool that lives on the GPU (mm2c_hitpool_create): per bucket its p[] (index.c:24) followed by the value
+ * array of its hash table (a minimizer that occurs once keeps its position in the table itself, index.c:91-94).  mm_idx_get hands out a pointer
+ * into one of the two; pool_offset() turns it into an offset into the pool, which is what a match then carries instead of a copy of the hits.
+ * Both layouts are the reference's own: struct mm_idx_bucket_s is private to index.c (index.c:26-31, restated here field for field), the
+ * table type comes from the reference's khash.h through the macro index.c itself uses (index.c:20). */
+__KHASH_TYPE(idx, uint64_t, uint64_t)
+typedef struct { mm128_v a; int32_t n; uint64_t *p; void *h; } idx_bucket_t;
+typedef struct { int64_t *base_p, *base_v, n; mm2c_hitpool_t *dev; } pool_t;
+
+static int pool_build(const mm_idx_t *mi, pool_t *pl)
+{
+	const idx_bucket_t *B = (const idx_bucket_t *)mi->B;
+	const int nb = 1 << mi->b;
+	uint64_t *host;
+	int i;
+	pl->base_p = (int64_t *)malloc((size_t)nb * 8); pl->base_v = (int64_t *)malloc((size_t)nb * 8); pl->n = 0;
+	for (i = 0; i < nb; ++i) {
+		const kh_idx_t *h = (const kh_idx_t *)B[i].h;
+		pl->base_p[i] = pl->n; pl->n += B[i].n;
+		pl->base_v[i] = pl->n; pl->n += h ? h->n_buckets : 0;
+	}
+	host = (uint64_t *)calloc((size_t)pl->n + 1, 8);
+	for (i = 0; i < nb; ++i) {
+		const kh_idx_t *h = (const kh_idx_t *)B[i].h;
+		if (B[i].n) memcpy(host + pl->base_p[i], B[i].p, (size_t)B[i].n * 8);
+		if (h && h->n_buckets) memcpy(host + pl->base_v[i], h->vals, (size_t)h->n_buckets * 8);
+	}
+	pl->dev = mm2c_hitpool_create(host, pl->n);
+	free(host);
+	return pl->dev ? 0 : -1;
+}
+
+static inline int64_t pool_offset(const mm_idx_t *mi, const pool_t *pl, uint64_t minier, const uint64_t *cr)
+{
+	const int i = (int)(minier & ((1u << mi->b) - 1));
+	const idx_bucket_t *b = &((const idx_bucket_t *)mi->B)[i];
+	if (cr >= b->p && cr < b->p + b->n) return pl->base_p[i] + (cr - b->p);
+	return pl->base_v[i] + (cr - ((const kh_idx_t *)b->h)->vals);
+}
+
+static void pool_free(pool_t *pl) { mm2c_hitpool_destroy(pl->dev); free(pl->base_p); free(pl->base_v); memset(pl, 0, sizeof(*pl)); }
+
 typedef struct {
 	uint32_t hash;
 	int32_t rep_len, n_mini_pos, n_m, n_reg;
@@ -70,6 +112,7 @@ typedef struct {
 
 typedef struct {
 	const mm_idx_t *mi; const mm_mapopt_t *opt; mm_bseq1_t *seq; read_t *rd; int n;
+	const pool_t *pool;           /* resident position arrays, or 0: the hits are copied into the batch (MM2_BATCH_HOSTPOOL=1) */
 	void **km;                    /* per-thread kalloc arenas for mm_sketch, as mm_tbuf_t::km (map.c:22) */
 	bufs_t *bf;
 	/* batch arrays (in bf) */
@@ -96,7 +139,7 @@ static void seed_one(void *data, long i, int tid)
 	mm_sketch(km, t->seq, t->l_seq, mi->w, mi->k, 0, mi->flag & MM_I_HPC, &mv);                  /* map.c:69 */
 	r->mini_pos = (uint64_t *)malloc((mv.n + 1) * 8);
 	r->m = (mm2c_match_t *)malloc((mv.n + 1) * sizeof(mm2c_match_t));
-	r->crs = (const uint64_t **)malloc((mv.n + 1) * sizeof(*r->crs));
+	r->crs = bt->pool ? 0 : (const uint64_t **)malloc((mv.n + 1) * sizeof(*r->crs));
 	for (j = 0; j < mv.n; ++j) {                                                                   /* map.c:95-118 */
 		const mm128_t *p = &mv.a[j];
 		uint32_t q_pos = (uint32_t)p->y, q_span = p->x & 0xff;
@@ -112,8 +155,10 @@ static void seed_one(void *data, long i, int tid)
 			if (j > 0 && p->x >> 8 == mv.a[j - 1].x >> 8) is_tandem = 1;
 			if (j < mv.n - 1 && p->x >> 8 == mv.a[j + 1].x >> 8) is_tandem = 1;
 			if (n > 0) {                                              /* a match without hits makes no anchor: not sent to the GPU */
-				q->cr_off = 0; q->n = (uint32_t)n; q->q_pos = q_pos; q->q_span = q_span; q->seg_tandem = (uint32_t)(p->y >> 32) << 1 | is_tandem;
-				r->crs[r->n_m++] = cr;
+				q->cr_off = bt->pool ? pool_offset(mi, bt->pool, p->x >> 8, cr) : 0;
+				q->n = (uint32_t)n; q->q_pos = q_pos; q->q_span = q_span; q->seg_tandem = (uint32_t)(p->y >> 32) << 1 | is_tandem;
+				if (!bt->pool) r->crs[r->n_m] = cr;
+				++r->n_m;
 				r->n_a += n;
 			}
 			r->mini_pos[r->n_mini_pos++] = (uint64_t)q_span << 32 | q_pos >> 1;
@@ -132,6 +177,12 @@ static void pack_one(void *data, long i, int tid)
 	int64_t h = bt->hit_off[i];
 	int k;
 	(void)tid;
+	if (bt->pool) {                                                /* the matches already point into the resident pool */
+		if (r->n_m) memcpy(&bt->matches[bt->match_off[i]], r->m, (size_t)r->n_m * sizeof(mm2c_match_t));
+		bt->qlen[i] = bt->seq[i].l_seq;
+		free(r->m); r->m = 0;
+		return;
+	}
 	for (k = 0; k < r->n_m; ++k) {
 		mm2c_match_t *q = &bt->matches[bt->match_off[i] + k];
 		*q = r->m[k];
@@ -172,6 +223,7 @@ static void post_one(void *data, long i, int tid)
  * the steps of consecutive mini-batches overlap, so the GPU call of one batch hides behind the seeding of the next */
 typedef struct {
 	const mm_idx_t *mi; const mm_mapopt_t *opt; mm_bseq_file_t *fp; mm2c_params_t par; int n_threads;
+	pool_t ipool; int use_pool;
 	kstring_t str;
 	void **km;
 	bufs_t pool[4];
@@ -197,7 +249,7 @@ static void *pipeline_step(void *shared, int step, void *in)
 		int i;
 		int64_t n_m = 0, n_h = 0;
 		bt->rd = (read_t *)calloc((size_t)bt->n, sizeof(read_t));
-		bt->km = sh->km;
+		bt->km = sh->km; bt->pool = sh->use_pool ? &sh->ipool : 0;
 		kt_for(sh->n_threads, seed_one, bt, bt->n);
 		sh->t_seed += realtime() - tt; tt = realtime();
 		for (i = 0; i < bt->n; ++i) { n_m += bt->rd[i].n_m; n_h += bt->rd[i].n_a; }
@@ -222,7 +274,8 @@ static void *pipeline_step(void *shared, int step, void *in)
 			if (n_h + 1 > bf->cap_hits) {
 				mm2c_pinned_free(bf->hits); mm2c_pinned_free(bf->u); mm2c_pinned_free(bf->b);
 				bf->cap_hits = (n_h + 1) * 5 / 4;
-				bf->hits = (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8); bf->u = (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
+				bf->hits = sh->use_pool ? 0 : (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
+				bf->u = (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
 				bf->b = (mm2c_anchor_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 16);
 			}
 			bt->match_off = bf->match_off; bt->hit_off = bf->hit_off; bt->anchor_off = bf->anchor_off; bt->u_off = bf->u_off; bt->b_off = bf->b_off;
@@ -237,8 +290,10 @@ static void *pipeline_step(void *shared, int step, void *in)
 	} else if (step == 2) {                                                                        /* chain the batch, post all */
 		batch_t *bt = (batch_t *)in;
 		const int64_t n_h = bt->hit_off[bt->n];
-		if (mm2c_seed_chain_batch_host(&sh->par, mo->min_cnt, mo->min_chain_score, bt->n, bt->match_off, bt->matches, bt->hits, n_h, bt->qlen,
-		                               bt->anchor_off, bt->u_off, bt->u, bt->b_off, bt->b) != 0) {
+		if ((sh->use_pool ? mm2c_seed_chain_batch_pool(&sh->par, mo->min_cnt, mo->min_chain_score, bt->n, bt->match_off, bt->matches, sh->ipool.dev, bt->qlen,
+		                                               bt->anchor_off, bt->u_off, bt->u, bt->b_off, bt->b)
+		                  : mm2c_seed_chain_batch_host(&sh->par, mo->min_cnt, mo->min_chain_score, bt->n, bt->match_off, bt->matches, bt->hits, n_h, bt->qlen,
+		                                               bt->anchor_off, bt->u_off, bt->u, bt->b_off, bt->b)) != 0) {
 			fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); exit(1);
 		}
 		sh->t_gpu += realtime() - tt; sh->tot_anchors += n_h; sh->tot_reads += bt->n;
@@ -279,7 +334,7 @@ int main(int argc, char *argv[])
 	mm_idx_t *mi;
 	shared_t sh;
 	int n_threads = 1;
-	double t_idx = 0, tt;
+	double t_idx = 0, t_pool = 0, tt;
 	if (argc >= 5 && strcmp(argv[1], "-t") == 0) { n_threads = atoi(argv[2]); argv += 2; argc -= 2; }
 	if (argc < 3) { fprintf(stderr, "usage: %s [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
@@ -300,11 +355,19 @@ int main(int argc, char *argv[])
 		sh.par.max_skip = mo.max_chain_skip; sh.par.max_iter = mo.max_chain_iter; sh.par.gap_scale = mo.chain_gap_scale;
 		sh.par.is_cdna = 0; sh.par.n_segs = 1; sh.par.q_span_override = -1; sh.par.flags = 0;
 		sh.mi = mi; sh.opt = &mo; sh.n_threads = n_threads;
+		sh.use_pool = !(getenv("MM2_BATCH_HOSTPOOL") && atoi(getenv("MM2_BATCH_HOSTPOOL")));
+		if (sh.use_pool) {
+			double tp = realtime();
+			if (pool_build(mi, &sh.ipool) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
+			t_pool += realtime() - tp;
+			fprintf(stderr, "[mm2_batchhost] position arrays of the index resident on the GPU: %lld entries (%.1f MB), %.2f s\n", (long long)sh.ipool.n, sh.ipool.n * 8e-6, realtime() - tp);
+		}
 		if (!sh.km) { int k; sh.km = (void **)calloc((size_t)n_threads, sizeof(void *)); for (k = 0; k < n_threads; ++k) sh.km[k] = km_init(); }
 		sh.fp = mm_bseq_open(argv[2]);
 		if (!sh.fp) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
 		kt_pipeline(4, pipeline_step, &sh, 4);
 		mm_bseq_close(sh.fp);
+		if (sh.use_pool) pool_free(&sh.ipool);
 		mm_idx_destroy(mi);
 		tt = realtime();
 	}
@@ -314,6 +377,14 @@ int main(int argc, char *argv[])
 	        t_idx, sh.t_read, sh.t_seed, sh.t_pack, sh.t_gpu, sh.t_post, sh.t_out);
 	fprintf(stderr, "[mm2_batchhost] %lld reads, %lld anchors; %.3f s in the batched GPU calls (matches in, chains out, PCIe included) = %.1f M anchors/s\n",
 	        (long long)sh.tot_reads, (long long)sh.tot_anchors, sh.t_gpu, sh.t_gpu > 0 ? sh.tot_anchors / sh.t_gpu / 1e6 : 0.0);
+	{
+		mm2c_stage_stats_t st;
+		mm2c_get_stage_stats(&st);
+		fprintf(stderr, "[mm2_batchhost] inside the library (mm2c_get_stage_stats): %llu calls in %llu chunks, %.3f s wall; host: setup %.3f, alloc %.3f (%llu), free %.3f (%llu), "
+		        "blocked %.3f; device (chunks overlap): upload %.3f, seed hits %.3f, DP %.3f, epilogue %.3f, offsets down %.3f; index pool upload %.2f s\n",
+		        (unsigned long long)st.calls, (unsigned long long)st.chunks, st.total_ns * 1e-9, st.setup_ns * 1e-9, st.alloc_ns * 1e-9, (unsigned long long)st.n_alloc,
+		        st.free_ns * 1e-9, (unsigned long long)st.n_free, st.wait_ns * 1e-9, st.h2d_ns * 1e-9, st.seed_ns * 1e-9, st.dp_ns * 1e-9, st.epi_ns * 1e-9, st.d2h_ns * 1e-9, t_pool);
+	}
 	mm2c_shutdown();
 	return fflush(stdout) == EOF;
 }

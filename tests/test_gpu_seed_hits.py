@@ -184,6 +184,49 @@ def test_matches_in_chains_out_host_entry():
     assert n_chains > 27
 
 
+@pytest.mark.parametrize("mode", ["host-pool-ranges", "host-pool-shared", "resident-pool"])
+def test_matches_in_chains_out_pipelined_in_chunks(mode):
+    """the same entry with a batch big enough (here: a chunk size small enough) to run as a two-stream pipeline of chunks of whole reads:
+    chunk plans from the device cache, hits uploaded per chunk as the range the chunk's matches point into ("host-pool-ranges"), once as a whole
+    when every chunk points all over the pool ("host-pool-shared": the reads are shuffled against the pool), or not at all
+    ("resident-pool": mm2c_hitpool_create + mm2c_seed_chain_batch_pool).  Chains of every read against the oracle; stage statistics populated."""
+    import mm2chain
+    from mm2chain import params
+    d = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz"))
+    base = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"], d[f"r{k}_anchors"]) for k in range(int(d["n_reads"]))]
+    reads = base * 6                                                # 162 reads
+    mo, m, h, ql = _batch([r[:3] for r in reads])
+    if mode == "host-pool-shared":
+        # the same reads in another order than their hit lists lie in the pool: every chunk's matches then span the whole pool
+        order = np.random.default_rng(5).permutation(len(reads))
+        cnt = np.diff(mo)
+        m = np.concatenate([m[mo[k]:mo[k + 1]] for k in order])
+        mo = np.concatenate([[0], np.cumsum(cnt[order])]).astype(np.int64)
+        ql = ql[order]
+        reads = [reads[k] for k in order]
+    P = params.map_ont()
+    total = sum(int(r[1]["n"].sum()) for r in reads)
+    mm2chain.tune("pipeline_chunk_anchors", max(1024, total // 7))
+    mm2chain.stage_stats(reset=True)
+    try:
+        if mode == "resident-pool":
+            pool = mm2chain.HitPool(h)
+            res = mm2chain.seed_chain_batch_pool(P, 3, 40, mo, m, pool, ql)
+            res2 = mm2chain.seed_chain_batch_pool(P, 3, 40, mo, m, pool, ql)        # arenas and cached plan workspace reused
+            pool.close()
+        else:
+            res = mm2chain.seed_chain_batch(P, 3, 40, mo, m, h, ql)
+            res2 = mm2chain.seed_chain_batch(P, 3, 40, mo, m, h, ql)
+    finally:
+        mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
+    st = mm2chain.stage_stats()
+    assert st["calls"] == 2 and st["chunks"] >= 10 and st["seed_ns"] > 0 and st["dp_ns"] > 0 and st["epi_ns"] > 0 and st["total_ns"] > 0, st
+    for k, r in enumerate(reads):
+        u_ref, b_ref = ob.mm_chain_dp(P, 3, 40, r[3])
+        assert np.array_equal(res[k][0], u_ref) and np.array_equal(res[k][1], b_ref), f"{mode}: read {k}: chains differ"
+        assert np.array_equal(res2[k][0], u_ref) and np.array_equal(res2[k][1], b_ref), f"{mode}: second call, read {k}: chains differ"
+
+
 def test_all_vs_all_seed_hits_with_skip_seed_equal_the_reference_and_chain_on_the_device():
     """`-x ava-ont` (BASELINE config 5; options.c:82-86: NO_DIAG | NO_DUAL): the matches of 37 reads mapped against themselves go through
     mm2c_seedplan_run_device_skip -- skip_seed (map.c:122-147) with the name comparison as ranks, MM_SEED_SELF (map.c:241), reads that keep
