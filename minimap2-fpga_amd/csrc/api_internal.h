@@ -43,6 +43,7 @@ struct Global {
 	std::atomic<size_t> combine_max_anchors{1u << 17};   // host paths: calls up to this many anchors are combined with concurrent callers' calls
 	std::atomic<size_t> stage_max_anchors{1u << 21};     // host paths: calls up to this many anchors go through pinned staging buffers
 	std::atomic<int64_t> pipeline_chunk_anchors{20 << 20};  // host paths: batches of at least twice this size are pipelined in chunks of this size
+	std::atomic<int64_t> pipeline_pieces{8}, pipeline_min_chunk{4 << 20};   // host paths: a batch of a few chunks' worth is cut into about `pieces` chunks of at least `min_chunk` anchors
 	std::atomic<int64_t> cut_below_tasks{4096};         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
@@ -174,6 +175,7 @@ inline int resolve_stream(void *stream, int device, hipStream_t *out)
 }
 void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
+void release_seed_aux();                            // mm2chain_seeds.cpp
 // for callers that have already waited for the stream(s) the plan ran on: no device-wide wait (chunks of a pipelined batch overlap)
 void plan_destroy_synced(mm2c_plan_t *pl);          // mm2chain_api.cpp
 void seedplan_destroy_synced(mm2c_seedplan_t *pl);  // mm2chain_seeds.cpp

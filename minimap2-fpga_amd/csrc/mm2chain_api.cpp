@@ -28,7 +28,8 @@ StageStats SS;
 
 // Device memory of plans and one-shot calls goes through a small cache: a batched caller creates and destroys plans of similar size
 // for every mini-batch, and hipMalloc / hipFree of gigabytes cost milliseconds each (hipFree also waits for the device).  A freed
-// block is kept and handed to the next request it fits (size within 1x..1.5x); the cache is bounded and emptied by mm2c_shutdown.
+// block is kept and handed to the next request it fits (the smallest cached block of 1x .. 3x the size: the last chunk of a pipelined batch is
+// smaller than the others and must not cost an allocation); the cache is bounded and emptied by mm2c_shutdown.
 struct DevCache {
 	std::mutex mu;
 	struct Block { void *p; size_t size; };
@@ -54,7 +55,7 @@ hipError_t dev_alloc(void **out, size_t bytes)
 		size_t best = (size_t)-1;
 		for (size_t i = 0; i < DC.free_blocks.size(); ++i) {
 			const size_t sz = DC.free_blocks[i].size;
-			if (sz >= bytes && sz <= bytes + bytes / 2 + 4096 && (best == (size_t)-1 || sz < DC.free_blocks[best].size)) best = i;
+			if (sz >= bytes && sz <= 3 * bytes + (1u << 20) && (best == (size_t)-1 || sz < DC.free_blocks[best].size)) best = i;
 		}
 		if (best != (size_t)-1) {
 			DevCache::Block b = DC.free_blocks[best];
@@ -452,6 +453,7 @@ void mm2c_shutdown(void)
 	(void)hipSetDevice(G.device);
 	{ std::lock_guard<std::mutex> bl(g_batch_mu); if (g_batch_ctx.st) g_batch_ctx.release(); g_batch_epoch = ~0ull; }
 	release_combiner();
+	release_seed_aux();
 	dev_cache_release();
 	G.thread_ctxs.clear();
 	if (G.stream) (void)hipStreamDestroy(G.stream);
@@ -500,6 +502,16 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "pipeline_chunk_anchors") == 0) {
 		if (value < 1024) return fail(MM2C_E_ARG, "pipeline_chunk_anchors must be >= 1024");
 		G.pipeline_chunk_anchors = value;
+		return 0;
+	}
+	if (strcmp(key, "pipeline_pieces") == 0) {
+		if (value < 1) return fail(MM2C_E_ARG, "pipeline_pieces must be >= 1");
+		G.pipeline_pieces = value;
+		return 0;
+	}
+	if (strcmp(key, "pipeline_min_chunk") == 0) {
+		if (value < 1024) return fail(MM2C_E_ARG, "pipeline_min_chunk must be >= 1024");
+		G.pipeline_min_chunk = value;
 		return 0;
 	}
 	if (strcmp(key, "plan_cut") == 0) {

@@ -77,7 +77,8 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	// chunk size of the two-stream pipeline: "pipeline_chunk_anchors" (a chunk that fills the GPU on its own) for batches many times that size;
 	// a batch of a few chunks' worth is cut into about eight pieces of at least 4 Mi anchors instead, whose kernels overlap on the two streams --
 	// the upload of a piece then hides behind the kernels of the one before (one pass over 2 * 10^7 anchors: 1.44 G anchors/s, PCIe and kernels in series)
-	const int64_t pipe_chunk = std::max<int64_t>(std::min<int64_t>(G.pipeline_chunk_anchors, total / 8), std::min<int64_t>(G.pipeline_chunk_anchors, 4 << 20));
+	const int64_t pipe_chunk = std::max<int64_t>(std::min<int64_t>(G.pipeline_chunk_anchors, total / std::max<int64_t>(G.pipeline_pieces, 1)),
+	                                             std::min<int64_t>(G.pipeline_chunk_anchors, G.pipeline_min_chunk));
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
 	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
 	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;

@@ -15,8 +15,62 @@ struct mm2c_seedplan {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipStream_t aux[3] = {};               // helper streams: the size classes of the tie replay run side by side
 	hipEvent_t fork[4] = {};
+	bool has_aux = false;                  // aux / fork come from (and go back to) the pool of helper stream sets
 	bool ran = false;
 };
+
+// helper streams and fork / join events of the seed plans, kept between plans: a pipelined batch makes a plan per chunk, and creating three
+// streams of distinct priority per plan cost milliseconds each
+namespace {
+struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; };
+std::mutex g_aux_mu;
+std::vector<AuxSet> g_aux_free;
+
+hipError_t aux_acquire(int device, AuxSet *out)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_aux_mu);
+		for (size_t i = 0; i < g_aux_free.size(); ++i)
+			if (g_aux_free[i].device == device) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return hipSuccess; }
+	}
+	AuxSet a; a.device = device;
+	hipError_t e = hipSuccess;
+	// helper streams on hardware queues of their own: different priorities never share a queue (see create_partner_stream)
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+	const int prio[3] = { greatest, least, (least + greatest) / 2 };
+	for (int i = 0; i < 3 && e == hipSuccess; ++i)
+		e = least != greatest ? hipStreamCreateWithPriority(&a.aux[i], hipStreamNonBlocking, prio[i]) : hipStreamCreateWithFlags(&a.aux[i], hipStreamNonBlocking);
+	for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&a.fork[i], hipEventDisableTiming);
+	if (e != hipSuccess) {
+		for (auto &st : a.aux) if (st) (void)hipStreamDestroy(st);
+		for (auto &ev : a.fork) if (ev) (void)hipEventDestroy(ev);
+		return e;
+	}
+	*out = a;
+	return hipSuccess;
+}
+
+void aux_release(const AuxSet &a)
+{
+	if (a.device < 0) return;
+	std::lock_guard<std::mutex> lk(g_aux_mu);
+	g_aux_free.push_back(a);
+}
+} // namespace
+
+namespace mm2c_api {
+void release_seed_aux()                       // mm2c_shutdown
+{
+	std::lock_guard<std::mutex> lk(g_aux_mu);
+	for (AuxSet &a : g_aux_free) {
+		DeviceScope on(a.device);
+		for (auto &st : a.aux) if (st) (void)hipStreamDestroy(st);
+		for (auto &ev : a.fork) if (ev) (void)hipEventDestroy(ev);
+	}
+	g_aux_free.clear();
+}
+}
 
 extern "C" {
 
@@ -56,14 +110,11 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	}
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
-	{	// helper streams on hardware queues of their own: different priorities never share a queue (see create_partner_stream)
-		int least = 0, greatest = 0;
-		if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-		const int prio[3] = { greatest, least, (least + greatest) / 2 };
-		for (int i = 0; i < 3 && e == hipSuccess; ++i)
-			e = least != greatest ? hipStreamCreateWithPriority(&pl->aux[i], hipStreamNonBlocking, prio[i]) : hipStreamCreateWithFlags(&pl->aux[i], hipStreamNonBlocking);
+	if (e == hipSuccess) {
+		AuxSet a;
+		e = aux_acquire(pl->device, &a);
+		if (e == hipSuccess) { for (int i = 0; i < 3; ++i) pl->aux[i] = a.aux[i]; for (int i = 0; i < 4; ++i) pl->fork[i] = a.fork[i]; pl->has_aux = true; }
 	}
-	for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pl->fork[i], hipEventDisableTiming);
 	if (e != hipSuccess) { fail(MM2C_E_HIP, "mm2c_seedplan_create: %s", hipGetErrorString(e)); mm2c_seedplan_destroy(pl); return nullptr; }
 	mm2c::SeedArgs &S = pl->S;
 	char *b = pl->d_mem;
@@ -84,8 +135,13 @@ static void seedplan_destroy_impl(mm2c_seedplan_t *pl, bool wait)
 		if (wait && pl->ran) { ScopedNs timed(SS.free_ns); (void)hipDeviceSynchronize(); }
 		dev_free_synced(pl->d_mem);
 		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
-		for (int i = 0; i < 3; ++i) if (pl->aux[i]) (void)hipStreamDestroy(pl->aux[i]);
-		for (int i = 0; i < 4; ++i) if (pl->fork[i]) (void)hipEventDestroy(pl->fork[i]);
+		if (pl->has_aux) {
+			// the helper streams join the plan's stream at the end of every run, so once the caller's stream (or the device) has been waited for they are idle
+			AuxSet a; a.device = pl->device;
+			for (int i = 0; i < 3; ++i) a.aux[i] = pl->aux[i];
+			for (int i = 0; i < 4; ++i) a.fork[i] = pl->fork[i];
+			aux_release(a);
+		}
 	}
 	delete pl;
 }

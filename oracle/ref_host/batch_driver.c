@@ -219,14 +219,14 @@ static void post_one(void *data, long i, int tid)
 	free(r->mini_pos); r->mini_pos = 0;
 }
 
-/* the mini-batch pipeline (cf. worker_pipeline, map.c:529-620): read | seed all + pack | chain the batch on the GPU + post all | print;
+/* the mini-batch pipeline (cf. worker_pipeline, map.c:529-620): read | seed all | pack | chain the batch on the GPU + post all | print;
  * the steps of consecutive mini-batches overlap, so the GPU call of one batch hides behind the seeding of the next */
 typedef struct {
 	const mm_idx_t *mi; const mm_mapopt_t *opt; mm_bseq_file_t *fp; mm2c_params_t par; int n_threads;
 	pool_t ipool; int use_pool;
 	kstring_t str;
 	void **km;
-	bufs_t pool[4];
+	bufs_t pool[6];
 	double t_gpu, t_seed, t_pack, t_post, t_out, t_read;
 	int64_t tot_anchors, tot_reads;
 } shared_t;
@@ -244,19 +244,23 @@ static void *pipeline_step(void *shared, int step, void *in)
 		if (bt->seq) return bt;
 		free(bt);
 		return 0;
-	} else if (step == 1) {                                                                        /* seed all, pack */
+	} else if (step == 1) {                                                                        /* seed all */
 		batch_t *bt = (batch_t *)in;
-		int i;
-		int64_t n_m = 0, n_h = 0;
 		bt->rd = (read_t *)calloc((size_t)bt->n, sizeof(read_t));
 		bt->km = sh->km; bt->pool = sh->use_pool ? &sh->ipool : 0;
 		kt_for(sh->n_threads, seed_one, bt, bt->n);
-		sh->t_seed += realtime() - tt; tt = realtime();
+		sh->t_seed += realtime() - tt;
+		return bt;
+	} else if (step == 2) {                                                                        /* pack: the matches of all reads into one page-locked array */
+		batch_t *bt = (batch_t *)in;
+		int i;
+		int64_t n_m = 0, n_h = 0;
 		for (i = 0; i < bt->n; ++i) { n_m += bt->rd[i].n_m; n_h += bt->rd[i].n_a; }
 		{	/* a free set of page-locked buffers, grown if this mini-batch is bigger than the ones it served before */
 			bufs_t *bf = 0;
 			int k;
-			for (k = 0; k < 4 && !bf; ++k) if (!sh->pool[k].busy) bf = &sh->pool[k];   /* at most 3 mini-batches are between step 1 and step 3 */
+			for (k = 0; k < 6 && !bf; ++k) if (!sh->pool[k].busy) bf = &sh->pool[k];   /* at most 5 mini-batches (one per pipeline thread) hold a set */
+			if (!bf) { fprintf(stderr, "ERROR: no free buffer set\n"); exit(1); }
 			bf->busy = 1; bt->bf = bf;
 			if (bt->n + 1 > bf->cap_reads) {
 				mm2c_pinned_free(bf->match_off); mm2c_pinned_free(bf->hit_off); mm2c_pinned_free(bf->anchor_off); mm2c_pinned_free(bf->u_off);
@@ -287,7 +291,7 @@ static void *pipeline_step(void *shared, int step, void *in)
 		kt_for(sh->n_threads, pack_one, bt, bt->n);
 		sh->t_pack += realtime() - tt;
 		return bt;
-	} else if (step == 2) {                                                                        /* chain the batch, post all */
+	} else if (step == 3) {                                                                        /* chain the batch, post all */
 		batch_t *bt = (batch_t *)in;
 		const int64_t n_h = bt->hit_off[bt->n];
 		if ((sh->use_pool ? mm2c_seed_chain_batch_pool(&sh->par, mo->min_cnt, mo->min_chain_score, bt->n, bt->match_off, bt->matches, sh->ipool.dev, bt->qlen,
@@ -365,7 +369,7 @@ int main(int argc, char *argv[])
 		if (!sh.km) { int k; sh.km = (void **)calloc((size_t)n_threads, sizeof(void *)); for (k = 0; k < n_threads; ++k) sh.km[k] = km_init(); }
 		sh.fp = mm_bseq_open(argv[2]);
 		if (!sh.fp) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
-		kt_pipeline(4, pipeline_step, &sh, 4);
+		kt_pipeline(5, pipeline_step, &sh, 5);
 		mm_bseq_close(sh.fp);
 		if (sh.use_pool) pool_free(&sh.ipool);
 		mm_idx_destroy(mi);
