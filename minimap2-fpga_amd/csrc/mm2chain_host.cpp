@@ -126,6 +126,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		while (c->evs.size() < 2 * (size_t)n_chunks) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->evs.push_back(e); }
 		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st_up));
 		hipStream_t comp[3] = { c->st, c->st2, c->st3 };
+		static const bool dn_stream = getenv("MM2C_PIPE_DN_STREAM") != nullptr;   // experiment: downloads on a stream of their own
 		int nl = 0;
 		for (int k = 0; k < n_chunks; ++k) {
 			const int64_t s0 = cuts[(size_t)k], s1 = cuts[(size_t)k + 1];
@@ -144,12 +145,16 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
 			L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
-			HIP_TRY(hipEventRecord(ev_k, st));
-			HIP_TRY(hipStreamWaitEvent(c->st_dn, ev_k, 0));
-			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, c->st_dn));
-			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, c->st_dn));
+			hipStream_t dn = st;
+			if (dn_stream) { HIP_TRY(hipEventRecord(ev_k, st)); HIP_TRY(hipStreamWaitEvent(c->st_dn, ev_k, 0)); dn = c->st_dn; }
+			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, dn));
+			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, dn));
 		}
-		{ ScopedNs timed(SS.wait_ns); HIP_TRY(hipStreamSynchronize(c->st_dn)); }      // every chunk's kernels precede its download; the uploads precede the kernels
+		{	// every chunk's kernels precede its download; the uploads precede the kernels
+			ScopedNs timed(SS.wait_ns);
+			if (dn_stream) HIP_TRY(hipStreamSynchronize(c->st_dn));
+			else for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamSynchronize(comp[k]));
+		}
 		SS.chunks += (uint64_t)n_chunks;
 		G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
 		G.passes += 1;

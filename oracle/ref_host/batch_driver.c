@@ -223,7 +223,7 @@ static void post_one(void *data, long i, int tid)
  * the steps of consecutive mini-batches overlap, so the GPU call of one batch hides behind the seeding of the next */
 typedef struct {
 	const mm_idx_t *mi; const mm_mapopt_t *opt; mm_bseq_file_t *fp; mm2c_params_t par; int n_threads;
-	pool_t ipool; int use_pool;
+	pool_t ipool; int use_pool, pageable_out;
 	kstring_t str;
 	void **km;
 	bufs_t pool[6];
@@ -276,11 +276,14 @@ static void *pipeline_step(void *shared, int step, void *in)
 				bf->matches = (mm2c_match_t *)mm2c_pinned_alloc((size_t)bf->cap_matches * sizeof(mm2c_match_t));
 			}
 			if (n_h + 1 > bf->cap_hits) {
-				mm2c_pinned_free(bf->hits); mm2c_pinned_free(bf->u); mm2c_pinned_free(bf->b);
+				mm2c_pinned_free(bf->hits);
+				if (sh->pageable_out) { free(bf->u); free(bf->b); } else { mm2c_pinned_free(bf->u); mm2c_pinned_free(bf->b); }
 				bf->cap_hits = (n_h + 1) * 5 / 4;
 				bf->hits = sh->use_pool ? 0 : (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
-				bf->u = (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
-				bf->b = (mm2c_anchor_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 16);
+				/* the chains come back into these; the interface wants room for every anchor although about half of them end up in chains.  Page-locking
+				 * 24 bytes per anchor costs more than it saves when a buffer set serves one mini-batch only (MM2_BATCH_PAGEABLE_OUT=1: plain memory) */
+				bf->u = (uint64_t *)(sh->pageable_out ? malloc((size_t)bf->cap_hits * 8) : mm2c_pinned_alloc((size_t)bf->cap_hits * 8));
+				bf->b = (mm2c_anchor_t *)(sh->pageable_out ? malloc((size_t)bf->cap_hits * 16) : mm2c_pinned_alloc((size_t)bf->cap_hits * 16));
 			}
 			bt->match_off = bf->match_off; bt->hit_off = bf->hit_off; bt->anchor_off = bf->anchor_off; bt->u_off = bf->u_off; bt->b_off = bf->b_off;
 			bt->qlen = bf->qlen; bt->matches = bf->matches; bt->hits = bf->hits; bt->u = bf->u; bt->b = bf->b;
@@ -288,7 +291,7 @@ static void *pipeline_step(void *shared, int step, void *in)
 		bt->match_off[0] = bt->hit_off[0] = 0;
 		n_m = n_h = 0;
 		for (i = 0; i < bt->n; ++i) { n_m += bt->rd[i].n_m; n_h += bt->rd[i].n_a; bt->match_off[i + 1] = n_m; bt->hit_off[i + 1] = n_h; }
-		kt_for(sh->n_threads, pack_one, bt, bt->n);
+		kt_for(sh->n_threads < 4 ? sh->n_threads : 4, pack_one, bt, bt->n);                        /* copies: a few threads saturate memory, the cores seed the next mini-batch */
 		sh->t_pack += realtime() - tt;
 		return bt;
 	} else if (step == 3) {                                                                        /* chain the batch, post all */
@@ -360,6 +363,7 @@ int main(int argc, char *argv[])
 		sh.par.is_cdna = 0; sh.par.n_segs = 1; sh.par.q_span_override = -1; sh.par.flags = 0;
 		sh.mi = mi; sh.opt = &mo; sh.n_threads = n_threads;
 		sh.use_pool = !(getenv("MM2_BATCH_HOSTPOOL") && atoi(getenv("MM2_BATCH_HOSTPOOL")));
+		sh.pageable_out = getenv("MM2_BATCH_PAGEABLE_OUT") && atoi(getenv("MM2_BATCH_PAGEABLE_OUT"));
 		if (sh.use_pool) {
 			double tp = realtime();
 			if (pool_build(mi, &sh.ipool) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }

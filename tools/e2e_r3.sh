@@ -8,8 +8,9 @@ OUT=$REPO/gpurun_out/e2e_$TAG; mkdir -p $OUT; rm -f $OUT/summary.txt
 W=/tmp/e2e_$TAG; mkdir -p $W
 python3 $REPO/tools/make_synth_genome.py $W/syn --genome-mb $GMB --reads $READS > $OUT/gen.log 2>&1
 echo "genome ${GMB} Mb, ${READS} reads, ${THREADS} threads" >> $OUT/summary.txt
-run() {   # name exe K hostpool
+run() {   # name exe K hostpool [pageable_out]
   local name=$1 exe=$2 K=$3 HP=$4
+  export MM2_BATCH_PAGEABLE_OUT=${5:-0}
   local T0=$(date +%s.%N)
   MM2_MINI_BATCH=$K MM2_BATCH_HOSTPOOL=$HP timeout -k 10 300 $REPO/oracle/_ref/$exe -t $THREADS $W/syn.ref.fa $W/syn.reads.fa > $W/$name.paf 2> $OUT/$name.err
   local RC=$?
@@ -21,6 +22,7 @@ for K in 500000000 100000000; do
   run ref_K$K mm2_refhost $K 0
   run batch_pool_K$K mm2_batchhost $K 0
   run batch_hostpool_K$K mm2_batchhost $K 1
+  run batch_pool_pageout_K$K mm2_batchhost $K 0 1
 done
 run gpuhost_K500000000 mm2_gpuhost 500000000 0
 run batch_pool_K500000000_again mm2_batchhost 500000000 0
