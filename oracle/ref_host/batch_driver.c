@@ -281,7 +281,7 @@ static void *pipeline_step(void *shared, int step, void *in)
 				bf->cap_hits = (n_h + 1) * 5 / 4;
 				bf->hits = sh->use_pool ? 0 : (uint64_t *)mm2c_pinned_alloc((size_t)bf->cap_hits * 8);
 				/* the chains come back into these; the interface wants room for every anchor although about half of them end up in chains.  Page-locking
-				 * 24 bytes per anchor costs more than it saves when a buffer set serves one mini-batch only (MM2_BATCH_PAGEABLE_OUT=1: plain memory) */
+				 * 24 bytes per anchor costs more than it saves when a buffer set serves one mini-batch only (measured: 120 000 reads, -K 500M: 6.2 s page-locked, 5.1 s plain; -K 100M: 4.1 / 3.5 s).  MM2_BATCH_PINNED_OUT=1: page-locked */
 				bf->u = (uint64_t *)(sh->pageable_out ? malloc((size_t)bf->cap_hits * 8) : mm2c_pinned_alloc((size_t)bf->cap_hits * 8));
 				bf->b = (mm2c_anchor_t *)(sh->pageable_out ? malloc((size_t)bf->cap_hits * 16) : mm2c_pinned_alloc((size_t)bf->cap_hits * 16));
 			}
@@ -341,12 +341,13 @@ int main(int argc, char *argv[])
 	mm_idx_t *mi;
 	shared_t sh;
 	int n_threads = 1;
-	double t_idx = 0, t_pool = 0, tt;
+	double t_idx = 0, t_pool = 0, t_init = 0, tt;
 	if (argc >= 5 && strcmp(argv[1], "-t") == 0) { n_threads = atoi(argv[2]); argv += 2; argc -= 2; }
 	if (argc < 3) { fprintf(stderr, "usage: %s [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
-	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
 	mm_realtime0 = realtime();
+	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
+	t_init = realtime() - mm_realtime0;
 	defaults(&io, &mo);
 	if (getenv("MM2_MINI_BATCH")) mo.mini_batch_size = atoll(getenv("MM2_MINI_BATCH"));              /* main.c -K */
 	io.flag |= MM_I_NO_SEQ;
@@ -363,7 +364,7 @@ int main(int argc, char *argv[])
 		sh.par.is_cdna = 0; sh.par.n_segs = 1; sh.par.q_span_override = -1; sh.par.flags = 0;
 		sh.mi = mi; sh.opt = &mo; sh.n_threads = n_threads;
 		sh.use_pool = !(getenv("MM2_BATCH_HOSTPOOL") && atoi(getenv("MM2_BATCH_HOSTPOOL")));
-		sh.pageable_out = getenv("MM2_BATCH_PAGEABLE_OUT") && atoi(getenv("MM2_BATCH_PAGEABLE_OUT"));
+		sh.pageable_out = !(getenv("MM2_BATCH_PINNED_OUT") && atoi(getenv("MM2_BATCH_PINNED_OUT")));   /* default: plain memory for the chains */
 		if (sh.use_pool) {
 			double tp = realtime();
 			if (pool_build(mi, &sh.ipool) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
@@ -393,6 +394,8 @@ int main(int argc, char *argv[])
 		        (unsigned long long)st.calls, (unsigned long long)st.chunks, st.total_ns * 1e-9, st.setup_ns * 1e-9, st.alloc_ns * 1e-9, (unsigned long long)st.n_alloc,
 		        st.free_ns * 1e-9, (unsigned long long)st.n_free, st.wait_ns * 1e-9, st.h2d_ns * 1e-9, st.seed_ns * 1e-9, st.dp_ns * 1e-9, st.epi_ns * 1e-9, st.d2h_ns * 1e-9, t_pool);
 	}
+	tt = realtime();
 	mm2c_shutdown();
+	fprintf(stderr, "[mm2_batchhost] HIP start-up (mm2c_init) %.2f s, shut-down %.2f s, whole process %.2f s\n", t_init, realtime() - tt, realtime() - mm_realtime0);
 	return fflush(stdout) == EOF;
 }
