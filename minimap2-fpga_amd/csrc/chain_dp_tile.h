@@ -346,16 +346,18 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // compiler does not know about these loads.  Measured (dense / ava-ont colinear, ms): no prefetch 90.0 / 37.7; first request only once the ring is
 // exhausted 87.6 / 37.9; at the anchor's start 85.5 / 39.4 (kept); at the start only if the last such anchor went beyond the ring 87.0 / 38.8.
 #define MM2C_DONE_FAR ""
+#define MM2C_RD_FAR \
+	"v_readfirstlane_b32 %[lo], %[tlo]\n\t" \
+	"v_readfirstlane_b32 %[lo0], %[tlo0]\n\t"
+#define MM2C_RD_LEAN \
+	"v_readfirstlane_b32 %[lo0], %[tlo0]\n\t"
 #define MM2C_LK_FAR \
-	"v_readlane_b32 %[lo], %[tlo], %[L]\n\t" \
-	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
 	"s_sub_i32 %[fb], %[i0], %[REACH]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lnf_%=\n\t" \
 	MM2C_FAR_REQ \
 	"Lnf_%=:\n\t"
 #define MM2C_LK_LEAN \
-	"v_readlane_b32 %[lo0], %[tlo0], %[L]\n\t" \
 	"v_mov_b32 %[lom1v], %[lo0]\n\t"
 #define MM2C_HF_FAR \
 	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
@@ -462,7 +464,61 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_END_LEAN(SCORE) \
 	"Lend_%=:\n"
 
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
+#define MM2C_READ_ANCHOR(SEG_RD) \
+	"v_readfirstlane_b32 %[pk], %[tw]\n\t" \
+	"v_readfirstlane_b32 %[best], %[tspan]\n\t" \
+	SEG_RD \
+	"v_readfirstlane_b32 %[xi1], %[tx1]\n\t" \
+	"v_readfirstlane_b32 %[qi1], %[tq1]\n\t"
+// price-list probes (tools/probe_prices.sh): extra instructions of one class per anchor (MM2C_PROBE_LK) or per older tile (MM2C_PROBE_LOOP) that
+// change no result -- u1 / t1 are dead at both places -- so that the time per added instruction of each class can be measured on the real kernel
+// (-DMM2C_PROBE=1..6: four plain VALU / four SALU / four v_readlane per anchor, two plain VALU / two SALU / two v_cmp per older tile)
+#define MM2C_P_V "v_add_u32 %[u1], 1, %[u1]\n\t"
+#define MM2C_P_S "s_add_u32 %[t1], %[t1], 1\n\t"
+#define MM2C_P_R "v_readlane_b32 %[t1], %[tw], %[L]\n\t"
+#define MM2C_P_C "v_cmp_eq_u32 vcc, %[u1], %[u1]\n\t"
+#if MM2C_PROBE == 1
+#define MM2C_PROBE_LK MM2C_P_V MM2C_P_V MM2C_P_V MM2C_P_V
+#elif MM2C_PROBE == 2
+#define MM2C_PROBE_LK MM2C_P_S MM2C_P_S MM2C_P_S MM2C_P_S
+#elif MM2C_PROBE == 3
+#define MM2C_PROBE_LK MM2C_P_R MM2C_P_R MM2C_P_R MM2C_P_R
+#elif MM2C_PROBE == 4
+#define MM2C_PROBE_LOOP MM2C_P_V MM2C_P_V
+#elif MM2C_PROBE == 5
+#define MM2C_PROBE_LOOP MM2C_P_S MM2C_P_S
+#elif MM2C_PROBE == 6
+#define MM2C_PROBE_LOOP MM2C_P_C MM2C_P_C
+#elif MM2C_PROBE == 7     /* v_readlane with a constant lane */
+#define MM2C_P_X "v_readlane_b32 %[t1], %[tw], 5\n\t"
+#define MM2C_PROBE_LK MM2C_P_X MM2C_P_X MM2C_P_X MM2C_P_X
+#elif MM2C_PROBE == 8     /* v_readfirstlane */
+#define MM2C_P_X "v_readfirstlane_b32 %[t1], %[tw]\n\t"
+#define MM2C_PROBE_LK MM2C_P_X MM2C_P_X MM2C_P_X MM2C_P_X
+#elif MM2C_PROBE == 9     /* one scalar load per anchor (always the same line) */
+#define MM2C_PROBE_LK "s_load_dwordx2 %[pr], %[aptr], 0x0\n\t"
+#define MM2C_PROBE_OPERAND , [pr] "=&s"(pr)
+#elif MM2C_PROBE == 10    /* two LDS reads per anchor */
+#define MM2C_P_X "ds_read_b32 %[u1], %[addr1]\n\t"
+#define MM2C_PROBE_LK MM2C_P_X MM2C_P_X
+#elif MM2C_PROBE == 11    /* v_readlane of four DIFFERENT registers into four different SGPRs */
+#define MM2C_PROBE_LK "v_readlane_b32 %[t1], %[tw], %[L]\n\tv_readlane_b32 %[t0], %[tx], %[L]\n\tv_readlane_b32 %[last], %[tq], %[L]\n\tv_readlane_b32 %[base], %[tlo0], %[L]\n\t"
+#elif MM2C_PROBE == 12    /* two v_writelane through m0 into a dead register */
+#define MM2C_PROBE_LK "s_mov_b32 m0, %[L]\n\ts_nop 0\n\tv_writelane_b32 %[u1], %[L], m0\n\tv_writelane_b32 %[u1], %[L], m0\n\t"
+#elif MM2C_PROBE == 13    /* four taken branches per anchor */
+#define MM2C_P_X "s_branch 1f\n\ts_nop 0\n1:\n\t"
+#define MM2C_PROBE_LK MM2C_P_X MM2C_P_X MM2C_P_X MM2C_P_X
+#endif
+#ifndef MM2C_PROBE_LK
+#define MM2C_PROBE_LK ""
+#endif
+#ifndef MM2C_PROBE_OPERAND
+#define MM2C_PROBE_OPERAND
+#endif
+#ifndef MM2C_PROBE_LOOP
+#define MM2C_PROBE_LOOP ""
+#endif
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
@@ -471,14 +527,19 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	typedef Lds<NX, NF, false, TABV> LY; \
 	typedef Lds<NX, NF, false, true> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
-	mask_t mask, valid, mk, marked, nm, se, ex; \
+	mask_t mask, valid, mk, marked, nm, se, ex, oh, pr; (void)pr; \
 	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
 		"s_mov_b64 %[ex], exec\n\t" \
-		"s_sub_i32 %[L], 63, %[kstart]\n" \
+		"s_sub_i32 %[L], 63, %[kstart]\n\t" \
+		"s_lshl_b64 %[mask], 1, %[L]\n\t" \
+		"s_lshr_b64 %[oh], %[mask], 1\n\t" \
+		"s_or_b64 %[oh], %[oh], %[mask]\n\t"      /* lanes L and L - 1: the anchor in progress and the next one */ \
+		"s_mov_b64 exec, %[mask]\n\t" \
+		MM2C_READ_ANCHOR(SEG_RD) \
+		"s_mov_b64 exec, %[ex]\n" \
 		"Lk_%=:\n\t" \
-		"v_readlane_b32 %[pk], %[tw], %[L]\n\t" \
-		"v_readlane_b32 %[best], %[tspan], %[L]\n\t" \
+		MM2C_PROBE_LK \
 		"s_mov_b32 %[bestj], -1\n\t" \
 		"s_cmp_lt_i32 %[pk], 0\n\t" \
 		"s_cbranch_scc1 Lexit_%=\n\t" \
@@ -486,8 +547,6 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc1 Ldone_%=\n\t" \
 		SEG_LK \
 		"s_bfe_u32 %[nfull], %[pk], 0xa000f\n\t" \
-		"v_readlane_b32 %[xi1], %[tx1], %[L]\n\t" \
-		"v_readlane_b32 %[qi1], %[tq1], %[L]\n\t" \
 		"s_sub_i32 %[s16], 64, %[L]\n\t" \
 		"v_mov_b32 %[addr], %[addr1]\n\t" \
 		MM2C_NEXT_XQ \
@@ -511,6 +570,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SCORE \
 		"s_branch Lhf_%=\n" \
 		"Lloop_%=:\n\t" \
+		MM2C_PROBE_LOOP \
 		"s_sub_u32 %[n], %[n], 1\n\t" \
 		"s_cbranch_scc1 Lpart_%=\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
@@ -701,10 +761,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SEG_END(SCORE) \
 		"Ldone_%=:\n\t" \
 		SEG_DONE \
-		"s_mov_b32 m0, %[L]\n\t" \
-		"s_nop 0\n\t" \
-		"v_writelane_b32 %[own_f], %[best], m0\n\t" \
-		"v_writelane_b32 %[own_p], %[bestj], m0\n\t" \
+		"s_mov_b64 exec, %[oh]\n\t"               /* commit into lane L (lane L - 1, the next anchor's, is written too: its own commit follows) ... */ \
+		"v_mov_b32 %[own_f], %[best]\n\t" \
+		"v_mov_b32 %[own_p], %[bestj]\n\t" \
+		MM2C_READ_ANCHOR(SEG_RD)                     /* ... and the scalars of the next anchor from the lowest active lane, L - 1 */ \
+		"s_mov_b64 exec, %[ex]\n\t" \
+		"s_lshr_b64 %[oh], %[oh], 1\n\t" \
 		"s_sub_i32 %[L], %[L], 1\n\t" \
 		"s_cmp_ge_i32 %[L], %[Lend]\n\t" \
 		"s_cbranch_scc1 Lk_%=\n" \
@@ -713,10 +775,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
 		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [L] "=&s"(L), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
-		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), \
+		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), [oh] "=&s"(oh), \
 		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
-		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) \
+		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
@@ -728,10 +790,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
+MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmm2chain_hip.so")
+LIB_PATH = os.environ.get("MM2C_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libmm2chain_hip.so")   # MM2C_LIB_PATH: an experimental build (tools/probe_prices.sh)
 
 MM2C_F_IGNORE_SEG = 0x1
 MM2C_F_FORCE_GENERAL = 0x2
