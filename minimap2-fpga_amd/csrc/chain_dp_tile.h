@@ -365,13 +365,12 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-	"s_mov_b64 exec, %[ex]\n\t" \
+	"s_mov_b64 exec, %[valid]\n\t" \
 	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
-	"s_and_b64 %[mask], vcc, %[valid]\n\t" \
-	"s_andn2_b64 %[mask], %[mask], %[mk]\n\t" \
+	"s_andn2_b64 %[mask], vcc, %[mk]\n\t"      /* (exec = valid: vcc is already confined to the lanes that passed) */ \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"s_sub_i32 %[t0], %[i0], %[L]\n\t" \
 	"s_add_i32 %[t0], %[t0], 64\n\t" \
@@ -379,10 +378,10 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
 	"s_mov_b64 exec, %[mask]\n\t" \
 	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
-	"s_mov_b64 exec, %[ex]\n"
+	"s_mov_b64 exec, %[valid]\n"
 #define MM2C_HF_LEAN \
-	"v_cndmask_b32_e64 %[u2], -1, %[vp], %[valid]\n\t" \
-	"v_max_i32 %[u2], %[u2], %[lom1v]\n\t" \
+	"s_mov_b64 exec, %[valid]\n\t" \
+	"v_max_i32 %[u2], %[vp], %[lom1v]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n"
@@ -456,7 +455,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
-	"s_mov_b64 exec, %[ex]\n\t" \
+	"s_mov_b64 exec, %[valid]\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
 	"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
@@ -590,14 +589,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_waitcnt lgkmcnt(0)\n" \
 		"Lhf_%=:\n\t" \
 		SEG_HF \
-		"Lmk_%=:\n\t" \
+		"Lmk_%=:\n\t"                                  /* exec = the lanes that passed the filters, until the fold has looked at the scores */ \
 		"s_waitcnt lgkmcnt(0)\n\t" \
 		ADDF \
-		"v_cndmask_b32_e64 %[sc], %[sent], %[sc], %[valid]\n\t" \
 		"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
-		"s_and_b64 %[marked], vcc, %[valid]\n\t" \
+		"s_and_b64 %[marked], vcc, exec\n\t" \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n\t" \
 		"s_cbranch_vccnz Limp_%=\n\t" \
+		"s_mov_b64 exec, %[ex]\n\t" \
 		SEG_TAIL \
 		"Lfg_%=:\n\t" \
 		"s_lshl_b32 %[t0], %[d], 6\n\t" \
@@ -632,11 +631,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_lshl_b32 %[t0], %[d], 6\n\t" \
 		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
-		"v_readlane_b32 %[t1], %[sc], %[t0]\n\t" \
+		"v_readfirstlane_b32 %[t1], %[sc]\n\t"          /* the first lane that passed = the lowest active lane */ \
 		"s_cmp_gt_i32 %[t1], %[best]\n\t" \
 		"s_cbranch_scc0 Lslow_%=\n\t" \
 		"v_cmp_lt_i32 vcc, %[t1], %[sc]\n\t" \
 		"s_cbranch_vccnz Lslow2_%=\n\t" \
+		"s_mov_b64 exec, %[ex]\n\t" \
 		"s_mov_b32 %[best], %[t1]\n\t" \
 		"s_add_i32 %[t1], %[base], 63\n\t" \
 		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
@@ -652,6 +652,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"Lslow2_%=:\n\t" \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n" \
 		"Lslow_%=:\n\t" \
+		"s_mov_b64 exec, %[ex]\n\t"                     /* the general folds work on all lanes: the lanes that did not pass get the sentinel score */ \
+		"v_cndmask_b32_e64 %[sc], %[sent], %[sc], %[valid]\n\t" \
 		"s_cmp_lg_u64 %[marked], 0\n\t" \
 		"s_cbranch_scc1 Lb2_%=\n\t" \
 		"s_cmp_lg_u32 %[nskip], 0\n\t" \
