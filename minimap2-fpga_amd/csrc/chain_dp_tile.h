@@ -366,14 +366,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"s_mov_b64 exec, %[valid]\n\t" \
-	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n\t" \
+	"ds_read_i8 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
 	"s_andn2_b64 %[mask], vcc, %[mk]\n\t"      /* (exec = valid: vcc is already confined to the lanes that passed) */ \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
-	"s_sub_i32 %[t0], %[i0], %[L]\n\t" \
-	"s_add_i32 %[t0], %[t0], 64\n\t" \
+	"s_add_i32 %[t0], %[icnt1], %[c]\n\t" \
 	"v_mov_b32 %[u1], %[t0]\n\t" \
 	"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
 	"s_mov_b64 exec, %[mask]\n\t" \
@@ -384,7 +383,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_max_i32 %[u2], %[vp], %[lom1v]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
-	"ds_read_u8 %[vb], %[vb] offset:%[STOFF]\n"
+	"ds_read_i8 %[vb], %[vb] offset:%[STOFF]\n"
 #define MM2C_TAIL_FAR \
 	"s_cbranch_scc0 Lret_%=\n\t" \
 	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
@@ -414,8 +413,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_sub_i32 %[n], %[nfull], %[NXM1]\n\t" \
 	"s_mov_b32 %[d], %[NXM1]\n\t" \
 	"s_mov_b32 %[lo], %[lo0]\n\t" \
-	"s_sub_i32 %[s16], %[i0], %[L]\n\t" \
-	"s_add_i32 %[s16], %[s16], 64\n\t" \
+	"s_add_i32 %[s16], %[icnt1], %[c]\n\t" \
 	"v_mov_b32 %[s16v], %[s16]\n" \
 	"Lfloop_%=:\n\t" \
 	"s_add_u32 %[d], %[d], 1\n\t" \
@@ -459,7 +457,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_waitcnt vmcnt(0)\n\t" \
 	"global_load_dword %[vb], %[u2], %[tptr] sc0\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
-	"s_branch Lmk_%=\n"
+	"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
+	"s_branch Lmk2_%=\n"
 #define MM2C_END_LEAN(SCORE) \
 	"Lend_%=:\n"
 
@@ -474,7 +473,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // (-DMM2C_PROBE=1..6: four plain VALU / four SALU / four v_readlane per anchor, two plain VALU / two SALU / two v_cmp per older tile)
 #define MM2C_P_V "v_add_u32 %[u1], 1, %[u1]\n\t"
 #define MM2C_P_S "s_add_u32 %[t1], %[t1], 1\n\t"
-#define MM2C_P_R "v_readlane_b32 %[t1], %[tw], %[L]\n\t"
+#define MM2C_P_R "v_readlane_b32 %[t1], %[tw], %[c]\n\t"
 #define MM2C_P_C "v_cmp_eq_u32 vcc, %[u1], %[u1]\n\t"
 #if MM2C_PROBE == 1
 #define MM2C_PROBE_LK MM2C_P_V MM2C_P_V MM2C_P_V MM2C_P_V
@@ -501,9 +500,9 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_P_X "ds_read_b32 %[u1], %[addr1]\n\t"
 #define MM2C_PROBE_LK MM2C_P_X MM2C_P_X
 #elif MM2C_PROBE == 11    /* v_readlane of four DIFFERENT registers into four different SGPRs */
-#define MM2C_PROBE_LK "v_readlane_b32 %[t1], %[tw], %[L]\n\tv_readlane_b32 %[t0], %[tx], %[L]\n\tv_readlane_b32 %[last], %[tq], %[L]\n\tv_readlane_b32 %[base], %[tlo0], %[L]\n\t"
+#define MM2C_PROBE_LK "v_readlane_b32 %[t1], %[tw], %[c]\n\tv_readlane_b32 %[t0], %[tx], %[c]\n\tv_readlane_b32 %[last], %[tq], %[c]\n\tv_readlane_b32 %[base], %[tlo0], %[c]\n\t"
 #elif MM2C_PROBE == 12    /* two v_writelane through m0 into a dead register */
-#define MM2C_PROBE_LK "s_mov_b32 m0, %[L]\n\ts_nop 0\n\tv_writelane_b32 %[u1], %[L], m0\n\tv_writelane_b32 %[u1], %[L], m0\n\t"
+#define MM2C_PROBE_LK "s_mov_b32 m0, %[c]\n\ts_nop 0\n\tv_writelane_b32 %[u1], %[c], m0\n\tv_writelane_b32 %[u1], %[c], m0\n\t"
 #elif MM2C_PROBE == 13    /* four taken branches per anchor */
 #define MM2C_P_X "s_branch 1f\n\ts_nop 0\n1:\n\t"
 #define MM2C_PROBE_LK MM2C_P_X MM2C_P_X MM2C_P_X MM2C_P_X
@@ -525,13 +524,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 { \
 	typedef Lds<NX, NF, false, TABV> LY; \
 	typedef Lds<NX, NF, false, true> LYT; \
-	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, L, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
+	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, c, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
 	mask_t mask, valid, mk, marked, nm, se, ex, oh, pr; (void)pr; \
 	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
 		"s_mov_b64 %[ex], exec\n\t" \
-		"s_sub_i32 %[L], 63, %[kstart]\n\t" \
-		"s_lshl_b64 %[mask], 1, %[L]\n\t" \
+		"s_sub_i32 %[c], %[kstart], %[cnt]\n\t"    /* the anchor counter: position in the tile - anchors of the tile, in [-64, -1]; its carry ends the loop and its low byte is the LDS stamp */ \
+		"s_sub_i32 %[t0], 63, %[kstart]\n\t" \
+		"s_lshl_b64 %[mask], 1, %[t0]\n\t" \
 		"s_lshr_b64 %[oh], %[mask], 1\n\t" \
 		"s_or_b64 %[oh], %[oh], %[mask]\n\t"      /* lanes L and L - 1: the anchor in progress and the next one */ \
 		"s_mov_b64 exec, %[mask]\n\t" \
@@ -541,20 +541,16 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		MM2C_PROBE_LK \
 		"s_mov_b32 %[bestj], -1\n\t" \
 		"s_cmp_lt_i32 %[pk], 0\n\t" \
-		"s_cbranch_scc1 Lexit_%=\n\t" \
-		"s_bitcmp1_b32 %[pk], 29\n\t" \
-		"s_cbranch_scc1 Ldone_%=\n\t" \
+		"s_cbranch_scc1 Lspec_%=\n\t"              /* bit 31: not for this loop, or (bit 29 too) no window at all */ \
 		SEG_LK \
-		"s_bfe_u32 %[nfull], %[pk], 0xa000f\n\t" \
-		"s_sub_i32 %[s16], 64, %[L]\n\t" \
+		"s_bfe_u32 %[n], %[pk], 0x40015\n\t"       /* whole older tiles inside the window */ \
 		"v_mov_b32 %[addr], %[addr1]\n\t" \
 		MM2C_NEXT_XQ \
 		"s_add_i32 %[span1], %[best], -1\n\t" \
 		"s_mov_b32 %[nskip], 0\n\t" \
-		"s_and_b32 %[part], %[nfull], 63\n\t" \
-		"s_lshr_b32 %[nfull], %[nfull], 6\n\t" \
-		"s_mov_b32 %[n], %[nfull]\n\t" \
-		"v_mov_b32 %[s16v], %[s16]\n\t" \
+		"s_bfe_u32 %[part], %[pk], 0x6000f\n\t"    /* lanes of the partly covered tile behind them */ \
+		"s_mov_b32 %[nfull], %[n]\n\t" \
+		"v_mov_b32 %[s16v], %[c]\n\t" \
 		"s_and_b32 %[t0], %[pk], 63\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_bfe_u32 %[t1], %[pk], 0x70008\n\t" \
@@ -591,8 +587,9 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SEG_HF \
 		"Lmk_%=:\n\t"                                  /* exec = the lanes that passed the filters, until the fold has looked at the scores */ \
 		"s_waitcnt lgkmcnt(0)\n\t" \
+		"v_cmp_eq_u32 vcc, %[c], %[vb]\n" \
+		"Lmk2_%=:\n\t" \
 		ADDF \
-		"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
 		"s_and_b64 %[marked], vcc, exec\n\t" \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n\t" \
 		"s_cbranch_vccnz Limp_%=\n\t" \
@@ -628,8 +625,6 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_and_b32 %[addr], %[RBM1], %[addr]\n\t" \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
-		"s_lshl_b32 %[t0], %[d], 6\n\t" \
-		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
 		"v_readfirstlane_b32 %[t1], %[sc]\n\t"          /* the first lane that passed = the lowest active lane */ \
 		"s_cmp_gt_i32 %[t1], %[best]\n\t" \
@@ -638,8 +633,9 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_vccnz Lslow2_%=\n\t" \
 		"s_mov_b64 exec, %[ex]\n\t" \
 		"s_mov_b32 %[best], %[t1]\n\t" \
-		"s_add_i32 %[t1], %[base], 63\n\t" \
-		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
+		"s_lshl_b32 %[t1], %[d], 6\n\t" \
+		"s_sub_i32 %[bestj], %[i063], %[t1]\n\t"   /* i0 + 63 - 64 d - lane */ \
+		"s_sub_i32 %[bestj], %[bestj], %[t0]\n\t" \
 		"s_sub_i32 %[nskip], %[nskip], 1\n\t" \
 		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
 		"s_bitset0_b64 %[marked], %[t0]\n\t" \
@@ -654,6 +650,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"Lslow_%=:\n\t" \
 		"s_mov_b64 exec, %[ex]\n\t"                     /* the general folds work on all lanes: the lanes that did not pass get the sentinel score */ \
 		"v_cndmask_b32_e64 %[sc], %[sent], %[sc], %[valid]\n\t" \
+		"s_lshl_b32 %[t0], %[d], 6\n\t" \
+		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 		"s_cmp_lg_u64 %[marked], 0\n\t" \
 		"s_cbranch_scc1 Lb2_%=\n\t" \
 		"s_cmp_lg_u32 %[nskip], 0\n\t" \
@@ -769,25 +767,28 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		MM2C_READ_ANCHOR(SEG_RD)                     /* ... and the scalars of the next anchor from the lowest active lane, L - 1 */ \
 		"s_mov_b64 exec, %[ex]\n\t" \
 		"s_lshr_b64 %[oh], %[oh], 1\n\t" \
-		"s_sub_i32 %[L], %[L], 1\n\t" \
-		"s_cmp_ge_i32 %[L], %[Lend]\n\t" \
-		"s_cbranch_scc1 Lk_%=\n" \
+		"s_add_u32 %[c], %[c], 1\n\t"              /* carry out: that was the tile's last anchor */ \
+		"s_cbranch_scc0 Lk_%=\n\t" \
+		"s_branch Lexit_%=\n" \
+		"Lspec_%=:\n\t" \
+		"s_bitcmp1_b32 %[pk], 29\n\t" \
+		"s_cbranch_scc1 Ldone_%=\n" \
 		"Lexit_%=:\n\t" \
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
 		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
-		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [L] "=&s"(L), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
+		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [c] "=&s"(c), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), [oh] "=&s"(oh), \
 		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
-		: [i0] "s"(i0), [kstart] "s"(k_start), [Lend] "s"(64 - cnt), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
+		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 2), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc"); \
-	return 63 - L; \
+	return cnt + c; \
 }
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
@@ -925,7 +926,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		const int w_l = min(rl, idx - lo_l);                      // own-tile predecessors inside the window: lanes lane + 1 .. lane + w
 		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);   // the window clamped to what the ring holds; its anchors in older tiles (<= 64 (NX - 1))
 		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);   // bits 0-5: lanes to scan, bits 8-14: the first of them, bits 15-24: bef
-		if (lo_l >= idx) tw_l |= 1 << 29;
+		if (lo_l >= idx) tw_l |= (int)0xa0000000;             // no window at all: bit 29, and bit 31 so that the loop needs one test for both rare cases
 		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
