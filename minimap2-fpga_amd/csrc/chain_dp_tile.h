@@ -70,16 +70,17 @@ __device__ __forceinline__ void write_lane2(int &v0, int &v1, int a0, int a1, in
 }
 
 // ---------------------------------------------------------------- LDS layout of one wave (byte offsets into the kernel's only LDS object)
-// rings are structure-of-arrays indexed by the anchor itself: anchor j of the task lives at dword (j mod 64 NX) of the x / q rings (NX tiles, a
-// power of two, the tile in progress included: 64 (NX - 1) anchors before it are reachable), at dword (j mod 64 NF) of the f / p rings
-// (the NF tiles before the one in progress: its own f / p are in registers until it is finished) and at halfword (j mod SN) of the stamp ring
+// rings are indexed by the anchor itself: anchor j of the task lives in the 8-byte slot (j mod 64 NX) of the x / q ring as the pair {x, q} (NX tiles,
+// a power of two, the tile in progress included: 64 (NX - 1) anchors before it are reachable), in the 8-byte slot (j mod 64 NF) of the f / p ring as
+// the pair {f - FBIAS, p} (the NF tiles before the one in progress: its own f / p are in registers until it is finished) and at byte (j mod SN) of
+// the stamp ring.  Pairs: one ds_read_b64 per tile instead of two ds_read_b32 (an LDS instruction costs the loop about as much as a VALU one).
 template <int NX, int NF, bool GEN, bool TAB>
 struct Lds {
-	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q rings
-	static constexpr int X = 0, Q = NX * 256, F = 2 * NX * 256, Pp = F + NF * 256, ST = Pp + NF * 256, GAP = ST + SN,
+	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q ring
+	static constexpr int XQ = 0, FP = NX * 512, ST = FP + NF * 512, GAP = ST + SN,
 	                     G = GAP + (TAB ? 1024 : 0), BYTES = G + (GEN ? NX * 64 : 0);
-	static constexpr int RB = NX * 256;          // bytes of one x / q ring array
-	static constexpr int FMASK = NF * 256 - 1;   // slot of a tile in the f / p rings = its x / q slot mod NF (NF a power of two dividing NX)
+	static constexpr int RB = NX * 512;          // bytes of the x / q ring
+	static constexpr int FMASK = NF * 512 - 1;   // slot of a tile in the f / p ring = its x / q slot mod NF (NF a power of two dividing NX)
 };
 
 constexpr int FBIAS = 14;   // min(dq, dr, span) - gap cost = min3(dq - 1, dr - 1, span - 1) - linear part + (clz(dd | 1) >> 1) - 14 (chain.c:207-209,218)
@@ -162,9 +163,9 @@ template <class LY, int NF>
 __device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, int base, int rl, int &fj, int &pj)
 {
 	if (depth <= NF) {
-		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 4
-		fj = *(const int *)(M.lds + LY::F + o) + FBIAS;           // the ring holds f - FBIAS and p (piece-relative), see the end of the tile loop
-		pj = *(const int *)(M.lds + LY::Pp + o);
+		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 8
+		const int2 fp = *(const int2 *)(M.lds + LY::FP + o);      // the ring holds f - FBIAS and p (piece-relative), see the end of the tile loop
+		fj = fp.x + FBIAS; pj = fp.y;
 	} else {
 		const int j = max(base + rl, 0);                          // lanes before the window of a partly covered tile may point before the task
 		fj = __hip_atomic_load(&M.f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -243,28 +244,30 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	// ---- whole tiles from the LDS ring
 #pragma nounroll
 	for (int cfull = FAR ? min(n_full, NX - 1) : n_full; cfull > 0; --cfull) {
-		const int xj = *(const int *)(M.lds + LY::X + addr), qj = *(const int *)(M.lds + LY::Q + addr);
+		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
+		const int xj = xq.x, qj = xq.y;
 		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
 		const int dd = absdiff(dr1, dq1);
 		mask_t same = ~0ull;
-		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 2)) : 0;
+		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 3)) : 0;
 		const mask_t valid = chunk_filter<GEN, true, DR0>(P, X, ~0ull, dr1, dq1, dd, gj, same);
 		if (valid != 0) {
 			int fj, pj;
 			ring_fp<LY, NF>(M, addr, depth, base, X.rl, fj, pj);
 			if (chunk_finish<LY, SKIP, GEN, GS1, FAR, TAB>(P, X, M, valid, same, dr1, dq1, dd, fj, pj, base, lane, c)) return;
 		}
-		addr = (addr - 256) & (LY::RB - 1);                   // one tile back
+		addr = (addr - 512) & (LY::RB - 1);                   // one tile back
 		base -= 64; ++depth;
 	}
 	if (!FAR || n_full < NX - 1) {
 		// ---- the last, partly covered tile, from the ring
 		if (part == 0) return;
-		const int xj = *(const int *)(M.lds + LY::X + addr), qj = *(const int *)(M.lds + LY::Q + addr);
+		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
+		const int xj = xq.x, qj = xq.y;
 		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
 		const int dd = absdiff(dr1, dq1);
 		mask_t same = ~0ull;
-		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 2)) : 0;
+		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 3)) : 0;
 		const mask_t valid = chunk_filter<GEN, false, DR0>(P, X, first_lanes(part), dr1, dq1, dd, gj, same);
 		if (valid != 0) {
 			int fj, pj;
@@ -322,17 +325,26 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_FILTER(X, Q) "v_sub_u32 %[dr], %[xi1], " X "\n\t" "v_sub_u32 %[dq], %[qi1], " Q "\n\t"
 #define MM2C_FILTER2 "v_sad_u32 %[dd], %[dr], %[dq], 0\n\t" "v_sub_u32_e64 %[u1], %[dq], %[mdqbw] clamp\n\t" "v_max_u32 %[u1], %[u1], %[dd]\n\t" \
 	"v_cmp_ge_u32 vcc, %[bw], %[u1]\n\t"
-#define MM2C_NEXT_XQ "ds_read_b32 %[nx], %[addr] offset:%[XOFF]\n\t" "ds_read_b32 %[nq], %[addr] offset:%[QOFF]\n\t" \
-	"v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
+// x / q of an older tile and f - FBIAS / p of a scored one arrive as pairs (one ds_read_b64 each).  Their halves are used one by one, and the
+// operand syntax of inline assembly cannot name half of a 64-bit operand: the four values live in FIXED registers (MM2C_R_X .. MM2C_R_P) that the
+// block lists as clobbers, so the compiler keeps them free across it.
+#define MM2C_R_XQ "v[62:63]"
+#define MM2C_R_X "v62"
+#define MM2C_R_Q "v63"
+#define MM2C_R_FP "v[60:61]"
+#define MM2C_R_F "v60"
+#define MM2C_R_P "v61"
+#define MM2C_NEXT_XQ "ds_read_b64 " MM2C_R_XQ ", %[addr] offset:%[XQOFF]\n\t" \
+	"v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
 // x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
 #define MM2C_FAR_REQ "v_add_u32 %[u2], %[fb], %[rl]\n\t" "v_max_i32 %[u2], 0, %[u2]\n\t" "v_lshlrev_b32 %[u2], 4, %[u2]\n\t" \
 	"global_load_dword %[fx], %[u2], %[aptr]\n\t" "global_load_dword %[fq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
 #define MM2C_SCORE_CMP "v_or_b32 %[va], 1, %[dd]\n\t" "v_ffbh_u32 %[va], %[va]\n\t" "v_lshrrev_b32 %[va], 1, %[va]\n\t" "v_cvt_f32_u32 %[vc], %[dd]\n\t" \
 	"v_mul_f32 %[vc], %[avg], %[vc]\n\t" "v_cvt_i32_f32 %[vc], %[vc]\n\t" "v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t" "v_sub_u32 %[sc], %[sc], %[vc]\n\t"
-#define MM2C_ADDF_CMP "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t"   /* vf = f[j] - 14 */
+#define MM2C_ADDF_CMP "v_add3_u32 %[sc], %[sc], %[va], " MM2C_R_F "\n\t"   /* vf = f[j] - 14 */
 #define MM2C_SCORE_TAB "v_min_u32 %[va], 0x1ff, %[dd]\n\t" "v_lshlrev_b32 %[va], 1, %[va]\n\t" "ds_read_i16 %[va], %[va] offset:%[GAPOFF]\n\t" \
 	"v_min3_i32 %[sc], %[dq], %[dr], %[span1]\n\t"
-#define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], %[vf]\n\t" "v_add_u32 %[sc], 14, %[sc]\n\t"   /* vf = f[j] - 14; the table holds 1 - cost */
+#define MM2C_ADDF_TAB "v_add3_u32 %[sc], %[sc], %[va], " MM2C_R_F "\n\t" "v_add_u32 %[sc], 14, %[sc]\n\t"   /* vf = f[j] - 14; the table holds 1 - cost */
 
 // ---- the segments in which the two instantiations of the loop differ.  `far`: the tile holds an anchor whose window reaches beyond the LDS ring
 // (bit 30 of its tw word): stamps with a target before the ring go to the global scratch, and a scan that runs through the whole ring without
@@ -360,27 +372,27 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_LK_LEAN \
 	"v_mov_b32 %[lom1v], %[lo0]\n\t"
 #define MM2C_HF_FAR \
-	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+	"v_cmp_le_i32 vcc, %[lo], " MM2C_R_P "\n\t" \
 	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
-	"v_and_b32 %[u2], %[SNM1], %[vp]\n\t" \
+	"v_and_b32 %[u2], %[SNM1], " MM2C_R_P "\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"s_mov_b64 exec, %[valid]\n\t" \
 	"ds_read_i8 %[vb], %[vb] offset:%[STOFF]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
-	"v_cmp_le_i32 vcc, %[lo0], %[vp]\n\t" \
+	"v_cmp_le_i32 vcc, %[lo0], " MM2C_R_P "\n\t" \
 	"s_andn2_b64 %[mask], vcc, %[mk]\n\t"      /* (exec = valid: vcc is already confined to the lanes that passed) */ \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
 	"s_add_i32 %[t0], %[icnt1], %[c]\n\t" \
 	"v_mov_b32 %[u1], %[t0]\n\t" \
-	"v_lshlrev_b32 %[u2], 2, %[vp]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, " MM2C_R_P "\n\t" \
 	"s_mov_b64 exec, %[mask]\n\t" \
 	"global_store_dword %[u2], %[u1], %[tptr] sc0\n\t" \
 	"s_mov_b64 exec, %[valid]\n"
 #define MM2C_HF_LEAN \
 	"s_mov_b64 exec, %[valid]\n\t" \
-	"v_max_i32 %[u2], %[vp], %[lom1v]\n\t" \
+	"v_max_i32 %[u2], " MM2C_R_P ", %[lom1v]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"ds_read_i8 %[vb], %[vb] offset:%[STOFF]\n"
@@ -441,16 +453,16 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_add_u32 %[u2], %[base], %[rl]\n\t" \
 	"v_max_i32 %[u2], 0, %[u2]\n\t" \
 	"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
-	"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
-	"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+	"global_load_dword " MM2C_R_P ", %[u2], %[pptr] sc0\n\t" \
+	"global_load_dword " MM2C_R_F ", %[u2], %[fptr] sc0\n\t" \
 	SCORE \
 	"s_waitcnt vmcnt(0)\n\t" \
-	"v_add_u32 %[vf], -14, %[vf]\n\t" \
-	"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
-	"v_max_i32 %[vp], -1, %[vp]\n\t" \
-	"v_cmp_le_i32 vcc, %[lo], %[vp]\n\t" \
+	"v_add_u32 " MM2C_R_F ", -14, " MM2C_R_F "\n\t" \
+	"v_subrev_u32 " MM2C_R_P ", %[pbase], " MM2C_R_P "\n\t" \
+	"v_max_i32 " MM2C_R_P ", -1, " MM2C_R_P "\n\t" \
+	"v_cmp_le_i32 vcc, %[lo], " MM2C_R_P "\n\t" \
 	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
-	"v_lshlrev_b32 %[u1], 2, %[vp]\n\t" \
+	"v_lshlrev_b32 %[u1], 2, " MM2C_R_P "\n\t" \
 	"s_mov_b64 exec, %[mk]\n\t" \
 	"global_store_dword %[u1], %[s16v], %[tptr] sc0\n\t" \
 	"s_mov_b64 exec, %[valid]\n\t" \
@@ -526,7 +538,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 	typedef Lds<NX, NF, false, true> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, c, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
 	mask_t mask, valid, mk, marked, nm, se, ex, oh, pr; (void)pr; \
-	int nx, nq, dr, dq, dd, u1, u2, vf, vp, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
+	int dr, dq, dd, u1, u2, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
 		"s_mov_b64 %[ex], exec\n\t" \
 		"s_sub_i32 %[c], %[kstart], %[cnt]\n\t"    /* the anchor counter: position in the tile - anchors of the tile, in [-64, -1]; its carry ends the loop and its low byte is the LDS stamp */ \
@@ -559,8 +571,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_mov_b32 %[d], 0\n\t" \
-		"v_add_u32 %[vf], -14, %[own_f]\n\t" \
-		"v_mov_b32 %[vp], %[own_p]\n\t" \
+		"v_add_u32 " MM2C_R_F ", -14, %[own_f]\n\t" \
+		"v_mov_b32 " MM2C_R_P ", %[own_p]\n\t" \
 		"v_mov_b32 %[vb], %[ownst]\n\t" \
 		SCORE \
 		"s_branch Lhf_%=\n" \
@@ -569,18 +581,17 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_sub_u32 %[n], %[n], 1\n\t" \
 		"s_cbranch_scc1 Lpart_%=\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
-		MM2C_FILTER("%[nx]", "%[nq]") MM2C_NEXT_XQ MM2C_FILTER2 \
+		MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "") MM2C_NEXT_XQ MM2C_FILTER2 \
 		"s_cbranch_vccz Lloop_%=\n\t" \
 		"s_mov_b64 %[valid], vcc\n\t" \
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
-		"v_add_u32 %[vb], 0x200, %[addr]\n\t" \
-		"v_bfe_u32 %[vb], %[vb], 2, %[RBBITS]\n\t" \
+		"v_add_u32 %[vb], 0x400, %[addr]\n\t" \
+		"v_bfe_u32 %[vb], %[vb], 3, %[RBBITS]\n\t" \
 		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
 		"s_cbranch_scc1 Lfg_%=\n\t" \
 		"v_and_b32 %[u2], %[FMASK], %[addr]\n\t" \
-		"ds_read_b32 %[vp], %[u2] offset:%[POFF]\n\t" \
-		"ds_read_b32 %[vf], %[u2] offset:%[FOFF]\n\t" \
+		"ds_read_b64 " MM2C_R_FP ", %[u2] offset:%[FPOFF]\n\t" \
 		SCORE \
 		"s_waitcnt lgkmcnt(0)\n" \
 		"Lhf_%=:\n\t" \
@@ -601,27 +612,27 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
 		"v_max_i32 %[u2], 0, %[u2]\n\t" \
 		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
-		"global_load_dword %[vp], %[u2], %[pptr] sc0\n\t" \
-		"global_load_dword %[vf], %[u2], %[fptr] sc0\n\t" \
+		"global_load_dword " MM2C_R_P ", %[u2], %[pptr] sc0\n\t" \
+		"global_load_dword " MM2C_R_F ", %[u2], %[fptr] sc0\n\t" \
 		SCORE \
 		"s_waitcnt vmcnt(0)\n\t" \
-		"v_subrev_u32 %[vp], %[pbase], %[vp]\n\t" \
-		"v_max_i32 %[vp], -1, %[vp]\n\t" \
-		"v_add_u32 %[vf], -14, %[vf]\n\t" \
+		"v_subrev_u32 " MM2C_R_P ", %[pbase], " MM2C_R_P "\n\t" \
+		"v_max_i32 " MM2C_R_P ", -1, " MM2C_R_P "\n\t" \
+		"v_add_u32 " MM2C_R_F ", -14, " MM2C_R_F "\n\t" \
 		"s_branch Lhf_%=\n" \
 		"Lpart_%=:\n\t" \
 		"s_mov_b32 %[n], 0\n\t" \
 		"s_cmp_eq_u32 %[part], 0\n\t" \
 		"s_cbranch_scc1 Lend_%=\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
-		MM2C_FILTER("%[nx]", "%[nq]") MM2C_FILTER2 \
+		MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "") MM2C_FILTER2 \
 		"s_sub_i32 %[t0], 64, %[part]\n\t" \
 		"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
 		"s_mov_b32 %[part], 0\n\t" \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lend_%=\n\t" \
 		"s_add_i32 %[d], %[nfull], 1\n\t" \
-		"v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" \
+		"v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t" \
 		"v_and_b32 %[addr], %[RBM1], %[addr]\n\t" \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
@@ -779,15 +790,15 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [c] "=&s"(c), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
 		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), [oh] "=&s"(oh), \
-		  [nx] "=&v"(nx), [nq] "=&v"(nq), [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), [vf] "=&v"(vf), [vp] "=&v"(vp), \
+		  [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
-		  [XOFF] "n"(LY::X), [QOFF] "n"(LY::Q), [FOFF] "n"(LY::F), [POFF] "n"(LY::Pp), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
-		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 2), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
-		: "memory", "vcc", "scc"); \
+		  [XQOFF] "n"(LY::XQ), [FPOFF] "n"(LY::FP), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
+		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 3), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P); \
 	return cnt + c; \
 }
 
@@ -809,7 +820,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
               const uint8_t *__restrict__ cls, int my_cls)
 {
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
-	static_assert(512 % (NF * 256) == 0, "the hand-written loop takes a tile's f / p ring slot from the x / q ring address two tiles further on");
+	static_assert(2 % NF == 0, "the hand-written loop takes a tile's f / p ring slot from the x / q ring address two tiles further on");
 	typedef Lds<NX, NF, GEN, TAB> LY;
 	constexpr int SN = LY::SN;
 	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...
@@ -888,10 +899,9 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 		const int stamp_lo = i0 - 64 * (NX - 1);   // oldest anchor reachable without global memory while this tile is processed
 		{
-			const int o = (idx & (SN - 1)) << 2;   // the tile enters the x / q rings (its slot held the tile NX tiles back)
-			*(int *)(lds + LY::X + o) = own_x;
-			*(int *)(lds + LY::Q + o) = own_q;
-			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 2)) = (uint8_t)own_g;
+			const int o = (idx & (SN - 1)) << 3;   // the tile enters the x / q ring (its slot held the tile NX tiles back)
+			*(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
+			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 3)) = (uint8_t)own_g;
 		}
 		if (FAR) {
 			// global stamp scratch t[]: zeroed lazily, only once this task's windows can reach beyond the LDS ring
@@ -912,7 +922,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (i0 == 0) eq_prev &= ~(1ull << 63);
 		}
 		X.stamp_lo = stamp_lo;
-		const int addr0 = ((idx - 64) & (SN - 1)) << 2;       // per lane: byte offset of its anchor of the tile before in the x / q rings
+		const int addr0 = ((idx - 64) & (SN - 1)) << 3;       // per lane: byte offset of its anchor of the tile before in the x / q ring
 
 		// per-anchor scalars of the tile, kept per lane (the hand-written loop fetches them with v_readlane): window start, LDS stamp, number
 		// of own-tile predecessors inside the window; bit 31 of the latter marks the anchors that take the C++ path (x equal to the
@@ -970,9 +980,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// ---- the finished tile: results leave in coalesced stores ...
 		if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 		{
-			const int o = (idx << 2) & LY::FMASK;    // ... and enters the f / p rings
-			*(int *)(lds + LY::F + o) = own_f - FBIAS;        // what the hand-written score adds: f[j] and its constant term in one
-			*(int *)(lds + LY::Pp + o) = own_p;
+			const int o = (idx << 3) & LY::FMASK;    // ... and enters the f / p ring: what the hand-written score adds (f[j] and its constant term in one), and p
+			*(int2 *)(lds + LY::FP + o) = make_int2(own_f - FBIAS, own_p);
 		}
 		cur = nxt; cur_st = nxt_st;
 	}
