@@ -361,16 +361,14 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_RD_FAR \
 	"v_readfirstlane_b32 %[lo], %[tlo]\n\t" \
 	"v_readfirstlane_b32 %[lo0], %[tlo0]\n\t"
-#define MM2C_RD_LEAN \
-	"v_readfirstlane_b32 %[lo0], %[tlo0]\n\t"
+#define MM2C_RD_LEAN ""
 #define MM2C_LK_FAR \
 	"s_sub_i32 %[fb], %[i0], %[REACH]\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Lnf_%=\n\t" \
 	MM2C_FAR_REQ \
 	"Lnf_%=:\n\t"
-#define MM2C_LK_LEAN \
-	"v_mov_b32 %[lom1v], %[lo0]\n\t"
+#define MM2C_LK_LEAN ""
 #define MM2C_HF_FAR \
 	"v_cmp_le_i32 vcc, %[lo], " MM2C_R_P "\n\t" \
 	"s_and_b64 %[mk], vcc, %[valid]\n\t" \
@@ -392,7 +390,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b64 exec, %[valid]\n"
 #define MM2C_HF_LEAN \
 	"s_mov_b64 exec, %[valid]\n\t" \
-	"v_max_i32 %[u2], " MM2C_R_P ", %[lom1v]\n\t" \
+	"v_max_i32 %[u2], " MM2C_R_P ", %[lomc]\n\t" \
 	"v_and_b32 %[u2], %[SNM1], %[u2]\n\t" \
 	"ds_write_b8 %[u2], %[s16v] offset:%[STOFF]\n\t" \
 	"ds_read_i8 %[vb], %[vb] offset:%[STOFF]\n"
@@ -532,7 +530,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
-                                    int addr1, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
+                                    int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
 { \
 	typedef Lds<NX, NF, false, TABV> LY; \
 	typedef Lds<NX, NF, false, true> LYT; \
@@ -556,8 +554,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc1 Lspec_%=\n\t"              /* bit 31: not for this loop, or (bit 29 too) no window at all */ \
 		SEG_LK \
 		"s_bfe_u32 %[n], %[pk], 0x40015\n\t"       /* whole older tiles inside the window */ \
-		"v_mov_b32 %[addr], %[addr1]\n\t" \
-		MM2C_NEXT_XQ \
+		"ds_read_b64 " MM2C_R_XQ ", %[addr1] offset:%[XQOFF]\n\t" \
+		"v_mov_b32 %[addr], %[addr2]\n\t" \
 		"s_add_i32 %[span1], %[best], -1\n\t" \
 		"s_mov_b32 %[nskip], 0\n\t" \
 		"s_bfe_u32 %[part], %[pk], 0x6000f\n\t"    /* lanes of the partly covered tile behind them */ \
@@ -795,7 +793,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
-		  [addr1] "v"(addr1), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
+		  [addr1] "v"(addr1), [addr2] "v"(addr2), [lomc] "v"(lomc), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XQOFF] "n"(LY::XQ), [FPOFF] "n"(LY::FP), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 3), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P); \
@@ -923,6 +921,12 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		X.stamp_lo = stamp_lo;
 		const int addr0 = ((idx - 64) & (SN - 1)) << 3;       // per lane: byte offset of its anchor of the tile before in the x / q ring
+		const int addr0b = ((idx - 128) & (SN - 1)) << 3;     // ... and of the tile before that
+		// lean tiles (every window inside the ring): a stamp may go to any slot the ring holds, also one before the anchor's own window -- nothing
+		// reads it during this anchor's scan and its value is this anchor's alone -- so the threshold below which a target is diverted is a constant of
+		// the tile, the ring's oldest anchor; the sink, stamp_lo - 1 = i0 + 63 (mod SN), is the slot of the tile's last anchor, which no scan of this tile reads
+		int lomc_v = stamp_lo - 1;
+		asm volatile("" : "+v"(lomc_v));
 
 		// per-anchor scalars of the tile, kept per lane (the hand-written loop fetches them with v_readlane): window start, LDS stamp, number
 		// of own-tile predecessors inside the window; bit 31 of the latter marks the anchors that take the C++ path (x equal to the
@@ -941,14 +945,14 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (e_l > rl) tw_l |= (int)0x80000000;
 		const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
 		const int ownst = idx & (SN - 1);                     // byte offset of the anchor's slot in the stamp ring
-		const int tx1_l = own_x - 1, tq1_l = own_q - 1, lom1_l = lo_c - 1;
+		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
 				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
-				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lom1_l) : MM2C_CALL(scan_tile_asm_cmp, lom1_l);   // lean: window start - 1, the sink slot of the stamp store
+				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
 #undef MM2C_CALL
 				k = __builtin_amdgcn_readfirstlane(k);
 				if (k >= cnt) break;
