@@ -314,7 +314,9 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			// measured with every task in one class (short / long ring, ms per 3.28e8 anchors): ava-ont mixed (3.3 tiles per anchor by this
 			// count) 118 / 96, dense (0.85) 83.6 / 82.3, asm20 mixed (0.5) 99.7 / 110.6, headline (0.05) 50.1 / 61.5: the long ring, at half the
 			// occupancy, pays only where scans go far beyond the short one
-			if (lane == 0) cls_out[task] = (n >= 1024 && 10 * s_far > 15 * (unsigned long long)n) ? 1 : 0;
+			// round 3 (faster ring path): dense 80.4 / 76.0, asm20 mixed 93.2 / 102.3, ava-ont mixed 113.5 / 91.6, headline 45.5 / 56.2 -> the bar sits between
+			// asm20 mixed (0.5) and dense (0.85)
+			if (lane == 0) cls_out[task] = (n >= 1024 && 10 * s_far > 7 * (unsigned long long)n) ? 1 : 0;
 		} else if (lane == 0) cls_out[task] = far_ring == 2 ? 1 : 0;
 	}
 	if (avg_out && n > 0) {
