@@ -16,7 +16,13 @@ mm2chain.init()
 if os.environ.get("MM2C_SOAK_CUT"):          # exercise the device-side cut of plans on small tasks as well
     mm2chain.tune("plan_cut_min", 100); mm2chain.tune("seg_min", int(os.environ["MM2C_SOAK_CUT"]))
 t0 = time.time(); n_anchor = 0; bad = 0
+budget = float(os.environ.get("MM2C_SOAK_SECONDS", "0")); t_last = time.time()
 for r in range(rounds):
+    if budget and time.time() - t0 > budget:
+        rounds = r
+        break
+    if time.time() - t_last > 60:
+        t_last = time.time(); print(f"... round {r}, {time.time() - t0:.0f} s", flush=True)
     rng = np.random.default_rng(seed0 + r)
     n_segs = int(rng.choice([1, 1, 1, 2, 3]))
     P = params.make_params(max_dist_x=int(rng.choice([0, 50, 700, 5000, 10000, 100000])), max_dist_y=int(rng.choice([-5, 60, 700, 5000, 10000])),

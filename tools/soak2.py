@@ -64,7 +64,13 @@ def device_chains(off, a, f, p, min_cnt, min_sc):
     return [(u[uo[k]:uo[k + 1]], b[bo[k]:bo[k + 1]]) for k in range(off.size - 1)]
 
 
+budget = float(os.environ.get("MM2C_SOAK_SECONDS", "0")); t_last = time.time()
 for r in range(rounds):
+    if budget and time.time() - t0 > budget:
+        rounds = r
+        break
+    if time.time() - t_last > 60:
+        t_last = time.time(); print(f"... round {r}, {time.time() - t0:.0f} s", flush=True)
     rng = np.random.default_rng(seed0 * 100003 + r)
     # 1. arbitrary forests
     sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 9000))])) for _ in range(int(rng.integers(1, 12)))]
