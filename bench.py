@@ -17,6 +17,12 @@ import os
 import sys
 import time
 
+# The host-buffer pipelines of the library keep an upload stream and three compute streams busy side by side; the runtime spreads a process's
+# streams over GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams on one queue run one after the other (measured:
+# 23.0 ms per 4.1e7 anchors with the default in this process, 16.8 ms with 16 queues).  Read when the runtime starts, so set before any GPU call;
+# mm2c_init does the same for hosts that reach the runtime through the library first.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -387,10 +393,13 @@ def main():
         pa = mm2chain.PinnedArray(a_host.shape, np.uint64); pf = mm2chain.PinnedArray(fh.shape, np.int32); pp = mm2chain.PinnedArray(ph.shape, np.int32)
         pa.array[:] = a_host
         mm2chain.chain_batch_host_into(P, off_host, pa.array, pf.array, pp.array)
-        th = time.perf_counter()
-        mm2chain.chain_batch_host_into(P, off_host, pa.array, pf.array, pp.array)
-        th = time.perf_counter() - th
-        out["host_streamed_pinned"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s",
+        ths = []
+        for _ in range(10):                                                  # short bursts after host-side work: the first calls run before the GPU clocks are up
+            th = time.perf_counter()
+            mm2chain.chain_batch_host_into(P, off_host, pa.array, pf.array, pp.array)
+            ths.append(time.perf_counter() - th)
+        th = min(ths)
+        out["host_streamed_pinned"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s", "ms_of_10_calls": [round(t * 1e3, 2) for t in ths],
                                        "sample": "same call with anchors and outputs in page-locked host memory (mm2c_pinned_alloc): chunks uploaded back to back on one stream, "
                                                  "their kernels on three compute streams, f / p downloaded on a third",
                                        "matches_resident": bool(np.array_equal(pf.array, fh) and np.array_equal(pp.array, ph))}

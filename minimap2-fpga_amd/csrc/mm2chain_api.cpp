@@ -361,6 +361,10 @@ int mm2c_init(int device_ordinal)
 {
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (G.ready) return 0;
+	// the pipelines of the host-buffer entries run an upload stream and three compute streams side by side; with the runtime's default of four
+	// hardware queues per process two of them can land on one queue and then take turns (profiles/r3_e2e.md).  Only effective when this is the
+	// process's first contact with the runtime; a host that starts HIP itself sets GPU_MAX_HW_QUEUES in its environment.
+	(void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	int n_dev = 0;
 	hipError_t e = hipGetDeviceCount(&n_dev);
 	if (e != hipSuccess || n_dev <= 0)

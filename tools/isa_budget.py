@@ -161,7 +161,7 @@ if __name__ == "__main__":
     print("\n## Paths\n")
     print("| path | plain VALU | scalar-side VALU | SALU | branch | LDS | VMEM | waitcnt / nop |")
     print("|---|---|---|---|---|---|---|---|")
-    for name, c in (("per anchor, fixed: scalars by `v_readlane`, first x/q request, commit by `v_writelane`", fixed),
+    for name, c in (("per anchor, fixed: scalars by `v_readfirstlane` under a one-hot exec, first x / q request, commit by `v_mov` under the same mask", fixed),
                     ("+ own-tile chunk, no lane passes the filters", own),
                     ("per older tile, no lane passes (`Lloop` … `s_cbranch_vccz`)", empty),
                     ("+ a lane passes, f/p from the LDS ring, stamps, score, fold A (no lane beats the best)", scored),
