@@ -584,11 +584,11 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b64 %[valid], vcc\n\t" \
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
-		"v_add_u32 %[vb], 0x400, %[addr]\n\t" \
-		"v_bfe_u32 %[vb], %[vb], 3, %[RBBITS]\n\t" \
+		"v_add_u32 %[vb], 0x400, %[addr]\n\t"           /* the running address is two tiles further on: back to this tile's */ \
+		"v_and_b32 %[u2], %[FMASK], %[vb]\n\t"          /* its slot in the f / p ring */ \
+		"v_bfe_u32 %[vb], %[vb], 3, %[RBBITS]\n\t"      /* its slot in the stamp ring */ \
 		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
 		"s_cbranch_scc1 Lfg_%=\n\t" \
-		"v_and_b32 %[u2], %[FMASK], %[addr]\n\t" \
 		"ds_read_b64 " MM2C_R_FP ", %[u2] offset:%[FPOFF]\n\t" \
 		SCORE \
 		"s_waitcnt lgkmcnt(0)\n" \
@@ -818,7 +818,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
               const uint8_t *__restrict__ cls, int my_cls)
 {
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
-	static_assert(2 % NF == 0, "the hand-written loop takes a tile's f / p ring slot from the x / q ring address two tiles further on");
+	static_assert(NF <= NX, "the f / p ring holds a prefix of the tiles of the x / q ring");
 	typedef Lds<NX, NF, GEN, TAB> LY;
 	constexpr int SN = LY::SN;
 	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...

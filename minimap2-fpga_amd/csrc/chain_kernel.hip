@@ -53,6 +53,9 @@
 #define MM2C_NX 8        // tiles of x / q in the LDS ring of the tile kernel: 384 anchors before the own tile pass the filters without global memory
 #define MM2C_NF 2        // tiles of f / p beside them (deeper ones are fetched from L2 for the lanes that passed)
 #endif
+#ifndef MM2C_NF1
+#define MM2C_NF1 2       // ... of the instantiation with the long x / q ring (ring-size class 1)
+#endif
 #include "chain_dp_tile.h"
 
 namespace mm2c {
@@ -571,7 +574,7 @@ static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagg
 template <int NX, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
 static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, bool classes, int my_cls)
 {
-	constexpr int NF = MM2C_NF;
+	constexpr int NF = NX > MM2C_NX ? MM2C_NF1 : MM2C_NF;
 	if (L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
 		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,

@@ -448,6 +448,7 @@ int mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64
 
 void mm2c_shutdown(void)
 {
+	std::lock_guard<std::mutex> bl(g_batch_mu);       // same order as get_batch_ctx: the batch context's lock, then the library's
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!G.ready) return;
 	(void)hipSetDevice(cur_device());
@@ -455,7 +456,8 @@ void mm2c_shutdown(void)
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
 	for (size_t k = 0; k < G.devices.size() && k < 64; ++k) if (g_slot_ctx[k].st) { (void)hipSetDevice(G.devices[k]); (void)hipDeviceSynchronize(); g_slot_ctx[k].release(); }
 	(void)hipSetDevice(G.device);
-	{ std::lock_guard<std::mutex> bl(g_batch_mu); if (g_batch_ctx.st) g_batch_ctx.release(); g_batch_epoch = ~0ull; }
+	if (g_batch_ctx.st) g_batch_ctx.release();
+	g_batch_epoch = ~0ull;
 	release_combiner();
 	release_seed_aux();
 	dev_cache_release();
