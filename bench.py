@@ -401,7 +401,7 @@ def main():
         th = min(ths)
         out["host_streamed_pinned"] = {"value": int(off_host[-1]) / th, "unit": "anchors/s", "ms_of_10_calls": [round(t * 1e3, 2) for t in ths],
                                        "sample": "same call with anchors and outputs in page-locked host memory (mm2c_pinned_alloc): chunks uploaded back to back on one stream, "
-                                                 "their kernels on three compute streams, f / p downloaded on a third",
+                                                 "their kernels and downloads on three compute streams in turn",
                                        "matches_resident": bool(np.array_equal(pf.array, fh) and np.array_equal(pp.array, ph))}
     except StopIteration:
         pass

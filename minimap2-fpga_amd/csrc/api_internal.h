@@ -110,8 +110,8 @@ struct ThreadCtx {
 	WholeSlot whole[2];
 	SeedSlot seed[2];
 	hipStream_t st = nullptr, st2 = nullptr;   // st2: second compute stream of the pipelined big-batch path
-	hipStream_t st3 = nullptr, st_up = nullptr, st_dn = nullptr;   // ... its third compute stream, its upload stream and its download stream
-	std::vector<hipEvent_t> evs;               // ... and its events (two per chunk in flight), kept for the next call
+	hipStream_t st3 = nullptr, st_up = nullptr;   // ... its third compute stream and its upload stream
+	std::vector<hipEvent_t> evs;               // ... and its events (one per chunk in flight), kept for the next call
 	hipEvent_t ev = nullptr;
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
 	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
@@ -121,7 +121,7 @@ struct ThreadCtx {
 		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
 		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
 		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
-		if (st3) (void)hipStreamDestroy(st3); if (st_up) (void)hipStreamDestroy(st_up); if (st_dn) (void)hipStreamDestroy(st_dn);
+		if (st3) (void)hipStreamDestroy(st3); if (st_up) (void)hipStreamDestroy(st_up);
 		for (hipEvent_t e : evs) (void)hipEventDestroy(e);
 		whole[0].release(); whole[1].release();
 		seed[0].release(); seed[1].release();

@@ -100,9 +100,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	} else if (n_req == 1 && total >= 2 * pipe_chunk) {
 		// big batch: a three-stage pipeline over chunks of whole pieces.  One stream uploads the chunks back to back (PCIe never idles), the
 		// kernels of chunk k start when its upload has landed -- on one of three compute streams in turn, so that the kernels of consecutive
-		// chunks overlap (a chunk does not fill the GPU: its kernel lasts as long as its longest task, whatever the chunk's size) -- and a
-		// third stream downloads f / p of the chunks as they finish (PCIe is full duplex).  With page-locked caller buffers the batch takes
-		// about (upload of everything) + (kernel + download of the last chunk).  [Two streams that each ran upload, kernels, download for
+		// chunks overlap (a chunk does not fill the GPU: its kernel lasts as long as its longest task, whatever the chunk's size) -- and each
+		// compute stream downloads f / p of its chunk behind its kernels (PCIe is full duplex).  With page-locked caller buffers the batch takes
+		// about (upload of everything) + (kernel + download of the last chunk).  [Round 2: two streams that each ran upload, kernels, download for
 		// every other chunk moved in lockstep: both uploaded, then both computed -- measured 15.9 ms for 2 * 10^7 anchors against 14.2 unpipelined.]
 		if (!c->st2) HIP_TRY(create_partner_stream(&c->st2));
 		if (!c->st3) {
@@ -111,7 +111,6 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			HIP_TRY(least != greatest ? hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking));
 		}
 		if (!c->st_up) HIP_TRY(hipStreamCreateWithFlags(&c->st_up, hipStreamNonBlocking));
-		if (!c->st_dn) HIP_TRY(hipStreamCreateWithFlags(&c->st_dn, hipStreamNonBlocking));
 		const HostReq &q = *reqs[0];
 		const mm2c_anchor_t *src = q.a + q.off[0];
 		int32_t *dst_f = q.f + q.off[0], *dst_p = q.p + q.off[0];
@@ -123,16 +122,15 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			cuts.push_back(s1); s0 = s1;
 		}
 		const int n_chunks = (int)cuts.size() - 1;
-		while (c->evs.size() < 2 * (size_t)n_chunks) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->evs.push_back(e); }
+		while (c->evs.size() < (size_t)n_chunks) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->evs.push_back(e); }
 		HIP_TRY(hipMemcpyAsync(c->d_in + o_off, hm, meta_bytes, hipMemcpyHostToDevice, c->st_up));
 		hipStream_t comp[3] = { c->st, c->st2, c->st3 };
-		static const bool dn_stream = getenv("MM2C_PIPE_DN_STREAM") != nullptr;   // experiment: downloads on a stream of their own
 		int nl = 0;
 		for (int k = 0; k < n_chunks; ++k) {
 			const int64_t s0 = cuts[(size_t)k], s1 = cuts[(size_t)k + 1];
 			const int64_t a0 = seg_off[(size_t)s0], a1 = seg_off[(size_t)s1];
 			hipStream_t st = comp[k % 3];
-			hipEvent_t ev_up = c->evs[2 * (size_t)k], ev_k = c->evs[2 * (size_t)k + 1];
+			hipEvent_t ev_up = c->evs[(size_t)k];
 			HIP_TRY(hipMemcpyAsync(c->d_in + o_a + (size_t)a0 * 16, src + a0, (size_t)(a1 - a0) * 16, hipMemcpyHostToDevice, c->st_up));
 			HIP_TRY(hipEventRecord(ev_up, c->st_up));
 			HIP_TRY(hipStreamWaitEvent(st, ev_up, 0));
@@ -145,15 +143,14 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
 			L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
-			hipStream_t dn = st;
-			if (dn_stream) { HIP_TRY(hipEventRecord(ev_k, st)); HIP_TRY(hipStreamWaitEvent(c->st_dn, ev_k, 0)); dn = c->st_dn; }
-			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, dn));
-			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, dn));
+			// each compute stream downloads its own chunk (a separate download stream behind an event turned the copies into blit kernels that
+			// held up the next upload: profiles/r3_e2e.md)
+			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(dst_p + a0, L.d_p + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
 		}
 		{	// every chunk's kernels precede its download; the uploads precede the kernels
 			ScopedNs timed(SS.wait_ns);
-			if (dn_stream) HIP_TRY(hipStreamSynchronize(c->st_dn));
-			else for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamSynchronize(comp[k]));
+			for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamSynchronize(comp[k]));
 		}
 		SS.chunks += (uint64_t)n_chunks;
 		G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
