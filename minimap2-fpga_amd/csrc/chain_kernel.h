@@ -41,6 +41,8 @@ struct LaunchArgs {
 	const float *d_avg;         // per task or nullptr (computed on the device, chain.c:48-49)
 	float *d_avg_ws = nullptr;  // n_tasks floats of workspace: when d_avg is nullptr the prepass computes avg_qspan_scaled into it
 	uint8_t *d_cls = nullptr;   // n_tasks bytes of workspace, or nullptr: ring-size class per task, written by the prepass (tile kernel only)
+	unsigned long long *d_cls_stat = nullptr;   // two counters, zero on entry: anchors of the class-1 tasks and of all tasks (chain_cls_settle), or nullptr
+	int far_thr10 = 7;          // far_ring 1: a task takes the long ring when it expects more than far_thr10 / 10 tiles beyond the short ring per anchor
 	int far_ring = 0;           // 0: one ring size; 1: tasks whose scans are expected to leave the 448-anchor ring get the long ring; 2: every task gets it
 	const int32_t *d_pbase;     // per task or nullptr: added to every p >= 0 on output (tasks that are pieces of a caller's task)
 	int32_t *d_f, *d_p;

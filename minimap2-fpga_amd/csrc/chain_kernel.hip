@@ -237,7 +237,8 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
-                   float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring)
+                   float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
+                   unsigned long long *__restrict__ cls_stat /* [anchors of class-1 tasks, anchors of all tasks], or nullptr */)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -319,7 +320,11 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			// occupancy, pays only where scans go far beyond the short one
 			// round 3 (faster ring path): dense 80.4 / 76.0, asm20 mixed 93.2 / 102.3, ava-ont mixed 113.5 / 91.6, headline 45.5 / 56.2 -> the bar sits between
 			// asm20 mixed (0.5) and dense (0.85)
-			if (lane == 0) cls_out[task] = (n >= 1024 && 10 * s_far > 7 * (unsigned long long)n) ? 1 : 0;
+			if (lane == 0) {
+				const int c = (n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
+				cls_out[task] = (uint8_t)c;
+				if (cls_stat) { atomicAdd(&cls_stat[1], (unsigned long long)n); if (c) atomicAdd(&cls_stat[0], (unsigned long long)n); }
+			}
 		} else if (lane == 0) cls_out[task] = far_ring == 2 ? 1 : 0;
 	}
 	if (avg_out && n > 0) {
@@ -329,6 +334,22 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 		__syncthreads();
 		if (lane == 0) avg_out[task] = (float)(__dmul_rn(.01, (double)(float)s_sum) / (double)n);
 	}
+}
+
+// ---------------------------------------------------------------- ring-size classes: one class for a batch that is nearly of one kind
+// The two classes are two launches that run one after the other, and each ends with the GPU part empty while its last tasks finish.  A handful
+// of long tasks in a launch of their own costs the batch the whole length of one of them (ragged mixed stream: 53.1 -> 59.6 ms for a few reads
+// of 8 800 anchors), and a stream whose tasks sit around the bar is cut in two halves (dense stream at a bar of 0.9: 89 ms against 76 / 80 for
+// one class).  So: when the class-1 tasks hold less than a quarter of the batch's anchors every task runs in class 0, when they hold more than
+// three quarters every task runs in class 1 (any task is correct in either); in between the split stands.
+__global__ void __launch_bounds__(256)
+chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long long *__restrict__ cls_stat)
+{
+	const unsigned long long far = cls_stat[0], all = cls_stat[1];
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= n_tasks) return;
+	if (4 * far < all) cls[t] = 0;
+	else if (4 * far > 3 * all) cls[t] = 1;
 }
 
 // ---------------------------------------------------------------- the reference's HW/SW prediction pass, chain.c:53-78
@@ -672,9 +693,14 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
-	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring);
+	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && L.far_ring == 1 ? L.d_cls_stat : (unsigned long long *)nullptr);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
+	if (e == hipSuccess && tile && L.far_ring == 1 && L.d_cls && L.d_cls_stat) {
+		hipLaunchKernelGGL(chain_cls_settle, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_cls, L.d_cls_stat);
+		e = hipGetLastError();
+		if (n_launches) ++*n_launches;
+	}
 	if (e == hipSuccess && L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL(chain_cut, dim3((unsigned)L.n_tasks), dim3(64), 0, st, L.cut.seg_min, L.n_tasks, L.d_offsets, L.d_order,
 		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut, tile && L.far_ring != 0 ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr);

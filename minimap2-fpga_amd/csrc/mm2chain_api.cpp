@@ -404,6 +404,8 @@ int mm2c_init(int device_ordinal)
 	if (ef) G.epi_fused = atoi(ef) != 0;
 	const char *fr = getenv("MM2C_FAR_RING");            // 0: one LDS ring size for every task; 2: the long ring for every task (tests)
 	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
+	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
+	if (ft) G.far_thr10 = std::max(0, atoi(ft));
 	G.ready = true;
 	return 0;
 }
@@ -493,6 +495,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "far_ring") == 0) {
 		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "far_ring must be 0, 1 or 2");
 		G.far_ring = value;
+		return 0;
+	}
+	if (strcmp(key, "far_ring_threshold") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "far_ring_threshold (tenths of a far tile per anchor) must be >= 0");
+		G.far_thr10 = value;
 		return 0;
 	}
 	if (strcmp(key, "force_tab") == 0) {
@@ -618,7 +625,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
-	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, nt);
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 16);   // class per task + the two counters of chain_cls_settle
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -678,7 +685,9 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.n_tasks = pl->n_tasks; L.d_offsets = pl->d_off_user ? pl->d_off_user : pl->d_off; L.d_order = pl->d_order;
 	L.d_anchors = d_anchors; L.d_avg = d_avg_qspan; L.d_pbase = nullptr; L.d_f = d_f; L.d_p = d_p; L.d_t = pl->d_t; L.d_st = pl->d_st; L.d_status = pl->d_status;
 	L.d_avg_ws = pl->d_avg_ws;
-	L.d_cls = pl->d_cls; L.far_ring = G.far_ring;
+	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
+	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
+	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 16, st));
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
