@@ -38,6 +38,7 @@ struct Global {
 	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
 	std::atomic<int> ring_class{3};
 	std::atomic<int> far_thr10{7};                      // ... from this many tenths of an expected far tile per anchor
+	std::atomic<int> compact_ring{1};                   // tile kernel: the compact x / q ring for the tasks whose q values allow it (0: never; the parity tests run both)
 	std::atomic<int> force_tab{0};                      // tile kernel: gap cost from the LDS table also when gap_scale == 1 (tests; slower)
 	std::atomic<int> far_ring{1};                       // plans: tasks whose scans are expected to leave the short LDS ring run with a ring twice as long (0: never, 2: all)
 	std::atomic<int> epi_fused{1};                      // device epilogue: tasks that fit the LDS take the fused kernel (0: kernels A, B, C for every task)

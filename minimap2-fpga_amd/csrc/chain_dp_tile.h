@@ -74,13 +74,22 @@ __device__ __forceinline__ void write_lane2(int &v0, int &v1, int a0, int a1, in
 // a power of two, the tile in progress included: 64 (NX - 1) anchors before it are reachable), in the 8-byte slot (j mod 64 NF) of the f / p ring as
 // the pair {f - FBIAS, p} (the NF tiles before the one in progress: its own f / p are in registers until it is finished) and at byte (j mod SN) of
 // the stamp ring.  Pairs: one ds_read_b64 per tile instead of two ds_read_b32 (an LDS instruction costs the loop about as much as a VALU one).
-template <int NX, int NF, bool GEN, bool TAB>
+// C16 (compact x / q ring, round 3): the slot holds the LOW 16 BITS of x and of q in one dword.  Inside the window of anchor i every
+// x_i - x_j lies in [0, max_dist_x] (that is what the window is, chain.c:192), so with max_dist_x < 2^16 the difference of the low halves
+// mod 2^16 IS dr; q_i - q_j is not bounded by the window, but a pair only passes with 0 < dq <= max_dq (chain.c:202-203), and when the
+// task's q values span at most 65535 - max_dq no other difference can alias into that range mod 2^16 -- the prepass checks that per task
+// (chain_window_start: bit 1 of the task's class sends it to the 32-bit instantiation).  Half the LDS per ring anchor: the ring of 16 tiles
+// costs what the ring of 8 did.
+template <int NX, int NF, bool GEN, bool TAB, bool C16 = false>
 struct Lds {
 	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q ring
-	static constexpr int XQ = 0, FP = NX * 512, ST = FP + NF * 512, GAP = ST + SN,
+	static constexpr int XS = C16 ? 4 : 8;       // bytes of an x / q slot
+	static constexpr int TILE = 64 * XS;         // ... of a tile in the x / q ring
+	static constexpr int RB = SN * XS;           // ... of the x / q ring
+	static constexpr int XQ = 0, FP = RB, ST = FP + NF * 512, GAP = ST + SN,
 	                     G = GAP + (TAB ? 1024 : 0), BYTES = G + (GEN ? NX * 64 : 0);
-	static constexpr int RB = NX * 512;          // bytes of the x / q ring
 	static constexpr int FMASK = NF * 512 - 1;   // slot of a tile in the f / p ring = its x / q slot mod NF (NF a power of two dividing NX)
+	static constexpr int SBITS = __builtin_ctz(SN);
 };
 
 constexpr int FBIAS = 14;   // min(dq, dr, span) - gap cost = min3(dq - 1, dr - 1, span - 1) - linear part + (clz(dd | 1) >> 1) - 14 (chain.c:207-209,218)
@@ -163,7 +172,7 @@ template <class LY, int NF>
 __device__ __forceinline__ void ring_fp(const TileMem &M, int addr, int depth, int base, int rl, int &fj, int &pj)
 {
 	if (depth <= NF) {
-		const int o = addr & LY::FMASK;                           // (j mod 64 NF) * 8
+		const int o = (LY::XS == 4 ? addr << 1 : addr) & LY::FMASK;   // (j mod 64 NF) * 8
 		const int2 fp = *(const int2 *)(M.lds + LY::FP + o);      // the ring holds f - FBIAS and p (piece-relative), see the end of the tile loop
 		fj = fp.x + FBIAS; pj = fp.y;
 	} else {
@@ -219,11 +228,26 @@ __device__ __forceinline__ bool far_chunk(const KParams &P, const AnchorCtx &X, 
 // ---------------------------------------------------------------- the look-back scan of one anchor, chain.c:197-235 (C++ path: every variant)
 // k = position of the anchor inside its tile (first anchor i0); own_* = the tile itself in registers (lane L = anchor i0 + 63 - L; f / p of its
 // finished anchors); addr0 = per-lane byte offset of this lane's anchor of the tile before in the x / q rings.  DR0: test dr != 0 per lane.
-template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool DR0>
+// x / q of one ring tile for this lane (byte offset addr) as dr - 1, dq - 1.  C16: from the low halves, mod 2^16 (see Lds<>); the value -1 (dr == 0 /
+// dq == 0) is kept as -1 so that the tests on it read as in the 32-bit form
+template <class LY>
+__device__ __forceinline__ void ring_dr_dq(const AnchorCtx &X, const TileMem &M, int addr, int &dr1, int &dq1)
+{
+	if (LY::XS == 8) {
+		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
+		dr1 = X.xi1 - xq.x; dq1 = X.qi1 - xq.y;
+	} else {
+		const unsigned xq = *(const unsigned *)(M.lds + LY::XQ + addr);
+		dr1 = (int)((unsigned)(X.xi1 + 1 - (int)(xq & 0xffffu)) & 0xffffu) - 1;
+		dq1 = (int)((unsigned)(X.qi1 + 1 - (int)(xq >> 16)) & 0xffffu) - 1;
+	}
+}
+
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool DR0, bool C16 = false>
 __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X, const TileMem &M, int lane, int i0, int k, mask_t eq_run,
                                             int own_x, int own_q, int own_g, int own_f, int own_p, int addr0, Carry &c)
 {
-	typedef Lds<NX, NF, GEN, TAB> LY;
+	typedef Lds<NX, NF, GEN, TAB, C16> LY;
 	// ---- the own tile: anchors i-1 .. i0 sit in lanes 64-k .. 63
 	if (k > 0) {
 		mask_t m = ~0ull << (64 - k);
@@ -244,9 +268,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	// ---- whole tiles from the LDS ring
 #pragma nounroll
 	for (int cfull = FAR ? min(n_full, NX - 1) : n_full; cfull > 0; --cfull) {
-		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
-		const int xj = xq.x, qj = xq.y;
-		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
+		int dr1, dq1;
+		ring_dr_dq<LY>(X, M, addr, dr1, dq1);
 		const int dd = absdiff(dr1, dq1);
 		mask_t same = ~0ull;
 		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 3)) : 0;
@@ -256,15 +279,14 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 			ring_fp<LY, NF>(M, addr, depth, base, X.rl, fj, pj);
 			if (chunk_finish<LY, SKIP, GEN, GS1, FAR, TAB>(P, X, M, valid, same, dr1, dq1, dd, fj, pj, base, lane, c)) return;
 		}
-		addr = (addr - 512) & (LY::RB - 1);                   // one tile back
+		addr = (addr - LY::TILE) & (LY::RB - 1);              // one tile back
 		base -= 64; ++depth;
 	}
 	if (!FAR || n_full < NX - 1) {
 		// ---- the last, partly covered tile, from the ring
 		if (part == 0) return;
-		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
-		const int xj = xq.x, qj = xq.y;
-		const int dr1 = X.xi1 - xj, dq1 = X.qi1 - qj;
+		int dr1, dq1;
+		ring_dr_dq<LY>(X, M, addr, dr1, dq1);
 		const int dd = absdiff(dr1, dq1);
 		mask_t same = ~0ull;
 		const int gj = GEN ? *(const uint8_t *)(M.lds + LY::G + (addr >> 3)) : 0;
@@ -334,8 +356,22 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_R_FP "v[60:61]"
 #define MM2C_R_F "v60"
 #define MM2C_R_P "v61"
-#define MM2C_NEXT_XQ "ds_read_b64 " MM2C_R_XQ ", %[addr] offset:%[XQOFF]\n\t" \
-	"v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
+// ---- what depends on the slot size of the x / q ring (Lds<>::XS): the 32-bit form `W` and the compact form `C` (low halves of x and q in one dword)
+// first request of an anchor; request of the next tile + the running address one tile back; the filter's two subtractions on a ring tile; the f / p and
+// stamp slots of a scored ring tile from the running address (which is two tiles further on); the running address one tile back (partly covered tile)
+#define MM2C_XQ1_W "ds_read_b64 " MM2C_R_XQ ", %[addr1] offset:%[XQOFF]\n\t"
+#define MM2C_XQ1_C "ds_read_b32 " MM2C_R_X ", %[addr1] offset:%[XQOFF]\n\t"
+#define MM2C_BACK_W "v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
+#define MM2C_BACK_C "v_add_u32 %[addr], 0xffffff00, %[addr]\n\t" "v_and_b32 %[addr], %[RBM1], %[addr]\n\t"
+#define MM2C_NEXT_XQ_W "ds_read_b64 " MM2C_R_XQ ", %[addr] offset:%[XQOFF]\n\t" MM2C_BACK_W
+#define MM2C_NEXT_XQ_C "ds_read_b32 " MM2C_R_X ", %[addr] offset:%[XQOFF]\n\t" MM2C_BACK_C
+#define MM2C_RFILTER_W MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "")
+// 16-bit subtractions: (x_i - 1 - x_j) mod 2^16 and (q_i - 1 - q_j) mod 2^16, zero-extended (SDWA: the result goes to the low word, the rest is padded with zeros)
+#define MM2C_RFILTER_C \
+	"v_sub_u16_sdwa %[dr], %[xi1], " MM2C_R_X " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
+	"v_sub_u16_sdwa %[dq], %[qi1], " MM2C_R_X " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+#define MM2C_OLDADDR_W "v_add_u32 %[vb], 0x400, %[addr]\n\t"
+#define MM2C_OLDADDR_C "v_add_lshl_u32 %[vb], %[addr], %[c200], 1\n\t"
 // x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
 #define MM2C_FAR_REQ "v_add_u32 %[u2], %[fb], %[rl]\n\t" "v_max_i32 %[u2], 0, %[u2]\n\t" "v_lshlrev_b32 %[u2], 4, %[u2]\n\t" \
 	"global_load_dword %[fx], %[u2], %[aptr]\n\t" "global_load_dword %[fq], %[u2], %[aptr] offset:8\n\t" "s_sub_i32 %[fb], %[fb], 64\n\t"
@@ -526,14 +562,14 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #ifndef MM2C_PROBE_LOOP
 #define MM2C_PROBE_LOOP ""
 #endif
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
                                     int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
 { \
-	typedef Lds<NX, NF, false, TABV> LY; \
-	typedef Lds<NX, NF, false, true> LYT; \
+	typedef Lds<NX, NF, false, TABV, C16V> LY; \
+	typedef Lds<NX, NF, false, true, C16V> LYT; \
 	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, c, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
 	mask_t mask, valid, mk, marked, nm, se, ex, oh, pr; (void)pr; \
 	int dr, dq, dd, u1, u2, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
@@ -554,7 +590,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc1 Lspec_%=\n\t"              /* bit 31: not for this loop, or (bit 29 too) no window at all */ \
 		SEG_LK \
 		"s_bfe_u32 %[n], %[pk], 0x40015\n\t"       /* whole older tiles inside the window */ \
-		"ds_read_b64 " MM2C_R_XQ ", %[addr1] offset:%[XQOFF]\n\t" \
+		XQ1 \
 		"v_mov_b32 %[addr], %[addr2]\n\t" \
 		"s_add_i32 %[span1], %[best], -1\n\t" \
 		"s_mov_b32 %[nskip], 0\n\t" \
@@ -579,14 +615,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_sub_u32 %[n], %[n], 1\n\t" \
 		"s_cbranch_scc1 Lpart_%=\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
-		MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "") MM2C_NEXT_XQ MM2C_FILTER2 \
+		RFILTER NEXT_XQ MM2C_FILTER2 \
 		"s_cbranch_vccz Lloop_%=\n\t" \
 		"s_mov_b64 %[valid], vcc\n\t" \
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
-		"v_add_u32 %[vb], 0x400, %[addr]\n\t"           /* the running address is two tiles further on: back to this tile's */ \
+		OLDADDR                                        /* the running address is two tiles further on: back to this tile's (in units of 8-byte slots) */ \
 		"v_and_b32 %[u2], %[FMASK], %[vb]\n\t"          /* its slot in the f / p ring */ \
-		"v_bfe_u32 %[vb], %[vb], 3, %[RBBITS]\n\t"      /* its slot in the stamp ring */ \
+		"v_bfe_u32 %[vb], %[vb], 3, %[SBITS]\n\t"       /* its slot in the stamp ring */ \
 		"s_cmp_gt_u32 %[d], %[NFI]\n\t" \
 		"s_cbranch_scc1 Lfg_%=\n\t" \
 		"ds_read_b64 " MM2C_R_FP ", %[u2] offset:%[FPOFF]\n\t" \
@@ -623,15 +659,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cmp_eq_u32 %[part], 0\n\t" \
 		"s_cbranch_scc1 Lend_%=\n\t" \
 		"s_waitcnt lgkmcnt(0)\n\t" \
-		MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "") MM2C_FILTER2 \
+		RFILTER MM2C_FILTER2 \
 		"s_sub_i32 %[t0], 64, %[part]\n\t" \
 		"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
 		"s_mov_b32 %[part], 0\n\t" \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lend_%=\n\t" \
 		"s_add_i32 %[d], %[nfull], 1\n\t" \
-		"v_add_u32 %[addr], 0xfffffe00, %[addr]\n\t" \
-		"v_and_b32 %[addr], %[RBM1], %[addr]\n\t" \
+		BACK \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
 		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
@@ -791,35 +826,47 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
 		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
-		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
+		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [c200] "s"(0x200), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [addr2] "v"(addr2), [lomc] "v"(lomc), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XQOFF] "n"(LY::XQ), [FPOFF] "n"(LY::FP), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
-		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [RBBITS] "n"(__builtin_ctz(LY::RB) - 3), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
+		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [SBITS] "n"(LY::SBITS), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P); \
 	return cnt + c; \
 }
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_cmp_far, false, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
-MM2C_SCAN_TILE_ASM(scan_tile_asm_tab_far, true, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%=")
+#define MM2C_RING_W MM2C_XQ1_W, MM2C_NEXT_XQ_W, MM2C_RFILTER_W, MM2C_OLDADDR_W, MM2C_BACK_W
+#define MM2C_RING_C MM2C_XQ1_C, MM2C_NEXT_XQ_C, MM2C_RFILTER_C, MM2C_OLDADDR_C, MM2C_BACK_C
+#define MM2C_SCAN_TILE_ASM_(...) MM2C_SCAN_TILE_ASM(__VA_ARGS__)
+#define MM2C_LEAN MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%="
+#define MM2C_FARS MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%="
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp, false, false, MM2C_RING_W, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab, true, false, MM2C_RING_W, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_far, false, false, MM2C_RING_W, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_FARS)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far, true, false, MM2C_RING_W, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_FARS)
+// the same four over the compact x / q ring
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_c, false, true, MM2C_RING_C, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_c, true, true, MM2C_RING_C, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_far_c, false, true, MM2C_RING_C, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_FARS)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_c, true, true, MM2C_RING_C, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_FARS)
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
-template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+// C16: the compact x / q ring (Lds<>), for the variants with the hand-written loop; the launcher picks it per task (cls bit 1 clear)
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
 __global__ void __launch_bounds__(64)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
               int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live,
-              const uint8_t *__restrict__ cls, int my_cls)
+              const uint8_t *__restrict__ cls, int my_cls, int cls_mask)
 {
+	static_assert(!C16 || (SKIP && !GEN && (GS1 || TAB)), "the compact ring belongs to the variants of the hand-written loop");
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
 	static_assert(NF <= NX, "the f / p ring holds a prefix of the tiles of the x / q ring");
-	typedef Lds<NX, NF, GEN, TAB> LY;
+	typedef Lds<NX, NF, GEN, TAB, C16> LY;
 	constexpr int SN = LY::SN;
 	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...
 	const bool ASM = ASMV && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // ... when its three-instruction filter applies (max_dq - 1 >= bw: every preset)
@@ -830,7 +877,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if (task >= n_tasks) return;
 	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut): the grid is sized for the worst case
 	if (only_flagged && status[task] == 0) return;
-	if (cls && cls[task] != my_cls) return;                   // ring-size classes (chain_window_start): this task belongs to the other instantiation
+	if (cls && (cls[task] & cls_mask) != my_cls) return;      // classes (chain_window_start: bit 0 ring size, bit 1 32-bit ring): this task belongs to another instantiation
 	const int64_t base0 = offsets[task];
 	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base0));
 	if (n <= 0) return;
@@ -897,8 +944,9 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 		const int stamp_lo = i0 - 64 * (NX - 1);   // oldest anchor reachable without global memory while this tile is processed
 		{
-			const int o = (idx & (SN - 1)) << 3;   // the tile enters the x / q ring (its slot held the tile NX tiles back)
-			*(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
+			const int o = (idx & (SN - 1)) * LY::XS;   // the tile enters the x / q ring (its slot held the tile NX tiles back)
+			if (C16) *(unsigned *)(lds + LY::XQ + o) = ((unsigned)own_x & 0xffffu) | ((unsigned)own_q << 16);
+			else *(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
 			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 3)) = (uint8_t)own_g;
 		}
 		if (FAR) {
@@ -920,8 +968,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (i0 == 0) eq_prev &= ~(1ull << 63);
 		}
 		X.stamp_lo = stamp_lo;
-		const int addr0 = ((idx - 64) & (SN - 1)) << 3;       // per lane: byte offset of its anchor of the tile before in the x / q ring
-		const int addr0b = ((idx - 128) & (SN - 1)) << 3;     // ... and of the tile before that
+		const int addr0 = ((idx - 64) & (SN - 1)) * LY::XS;   // per lane: byte offset of its anchor of the tile before in the x / q ring
+		const int addr0b = ((idx - 128) & (SN - 1)) * LY::XS; // ... and of the tile before that
 		// lean tiles (every window inside the ring): a stamp may go to any slot the ring holds, also one before the anchor's own window -- nothing
 		// reads it during this anchor's scan and its value is this anchor's alone -- so the threshold below which a target is diverted is a constant of
 		// the tile, the ring's oldest anchor; the sink, stamp_lo - 1 = i0 + 63 (mod SN), is the slot of the tile's last anchor, which no scan of this tile reads
@@ -951,7 +999,10 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
                                  LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
-				if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
+				if (C16) {
+					if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far_c, lo_l);
+					else k = TAB ? MM2C_CALL(scan_tile_asm_tab_c, lo_l) : MM2C_CALL(scan_tile_asm_cmp_c, lo_l);
+				} else if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
 				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
 #undef MM2C_CALL
 				k = __builtin_amdgcn_readfirstlane(k);
@@ -975,8 +1026,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				if (GEN) X.seg_i = rdlane(own_g, L);                                                 // chain.c:191
 				X.lo = lo; X.stamp = i + 1; X.s16 = 1 + k; X.s16_v = X.s16;             // LDS stamps: unique within the tile (the ring is wiped per tile)
 				X.far_mode = FAR && lo < stamp_lo;
-				if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
-				else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);
+				if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false, C16>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
+				else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true, C16>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);
 			}
 			// ---- commit anchor i (chain.c:236) into its lane of the own tile
 			write_lane2(own_f, own_p, __builtin_amdgcn_readfirstlane(c.best), __builtin_amdgcn_readfirstlane(c.best_j), L);

@@ -40,7 +40,9 @@ struct LaunchArgs {
 	const void *d_anchors;      // 16 B per anchor
 	const float *d_avg;         // per task or nullptr (computed on the device, chain.c:48-49)
 	float *d_avg_ws = nullptr;  // n_tasks floats of workspace: when d_avg is nullptr the prepass computes avg_qspan_scaled into it
-	uint8_t *d_cls = nullptr;   // n_tasks bytes of workspace, or nullptr: ring-size class per task, written by the prepass (tile kernel only)
+	uint8_t *d_cls = nullptr;   // n_tasks bytes of workspace, or nullptr: class per task, written by the prepass (tile kernel only): bit 0 long ring, bit 1 the
+	                            // task needs the 32-bit x / q ring (its q values span more than the compact ring can tell apart, chain_dp_tile.h Lds<>)
+	int compact = 1;            // 0: never the compact x / q ring (mm2c_tune("compact_ring", 0); the parity tests run both)
 	unsigned long long *d_cls_stat = nullptr;   // two counters, zero on entry: anchors of the class-1 tasks and of all tasks (chain_cls_settle), or nullptr
 	int far_thr10 = 7;          // far_ring 1: a task takes the long ring when it expects more than far_thr10 / 10 tiles beyond the short ring per anchor
 	int far_ring = 0;           // 0: one ring size; 1: tasks whose scans are expected to leave the 448-anchor ring get the long ring; 2: every task gets it
@@ -62,6 +64,7 @@ struct LaunchInfo {
 	int skip, gen, gs1, far_, tab;
 	int asm_loop;    // the hand-written per-tile loop (scan_tile_asm_*) runs, not scan_anchor<>
 	int classes;     // ring-size classes: class-1 tasks run the instantiation with 2 * nx tiles
+	int c16;         // tasks whose q values allow it run the instantiations with the compact x / q ring (per task: bit 1 of its class clear)
 	int cut;         // tasks are cut into pieces on the device first
 };
 

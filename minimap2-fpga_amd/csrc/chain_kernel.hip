@@ -56,6 +56,15 @@
 #ifndef MM2C_NF1
 #define MM2C_NF1 2       // ... of the instantiation with the long x / q ring (ring-size class 1)
 #endif
+// the instantiation with the compact x / q ring (4 bytes per ring anchor instead of 8): 16 tiles cost the LDS that 8 cost in the 32-bit form, so there is one
+// ring size for every task that takes it (measured, ms headline / dense / asm20 mixed: 8 tiles + 2 of f / p 46.6 / 59.6 / 94.7, 16 + 2 44.0 / 59.9 / 80.0,
+// 8 + 4 44.3 / 62.2 / 87.1, 16 + 4 46.3 / 62.3 / 82.7; the 32-bit rings with ring-size classes 45.7 / 75.2 / 93.9)
+#ifndef MM2C_CNX
+#define MM2C_CNX 16
+#endif
+#ifndef MM2C_CNF
+#define MM2C_CNF 2
+#endif
 #include "chain_dp_tile.h"
 
 namespace mm2c {
@@ -238,7 +247,8 @@ __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
                    float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
-                   unsigned long long *__restrict__ cls_stat /* [anchors of class-1 tasks, anchors of all tasks], or nullptr */)
+                   unsigned long long *__restrict__ cls_stat /* [anchors of class-1 tasks, anchors of all tasks], or nullptr */,
+                   unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -258,7 +268,9 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	__shared__ int s_prev;
 	__shared__ unsigned long long s_sum;
 	__shared__ unsigned long long s_far;
-	if (lane == 0) { s_prev = 0; s_sum = 0; s_far = 0; }
+	__shared__ int s_qmin, s_qmax;
+	if (lane == 0) { s_prev = 0; s_sum = 0; s_far = 0; s_qmin = INT_MAX; s_qmax = INT_MIN; }
+	int q_min = INT_MAX, q_max = INT_MIN;                             // of this lane's anchors (compact ring: bit 1 of the class)
 	const int max_dq = min(P.max_dist_x, P.max_dist_y);
 	uint64_t far_sum = 0;                                             // expected tiles beyond the short ring, see below
 	uint64_t span_sum = 0;                                            // chain.c:48: spans of this lane's anchors
@@ -266,7 +278,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
 		const int i = i0 + lane, cnt = min(256, n - i0);
 		const ulonglong2 cur = nxt;
-		if (i < n) { s_x[i & (RING - 1)] = cur.x; span_sum += (cur.y >> 32) & 0xff; }
+		if (i < n) { s_x[i & (RING - 1)] = cur.x; span_sum += (cur.y >> 32) & 0xff; q_min = min(q_min, (int)(uint32_t)cur.y); q_max = max(q_max, (int)(uint32_t)cur.y); }
 		__syncthreads();                                            // the tile is in the ring; s_prev of the tile before is visible
 		if (i + 256 < n) nxt = a[i + 256];
 		const int range_lo = max(s_prev, max(i0 - P.max_iter, 0)), len = i0 + cnt - range_lo;
@@ -311,6 +323,11 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 		if (i < n && lane == cnt - 1) s_prev = lo;
 	}
 	if (cls_out && n > 0) {
+		// bit 1: the task's q values span more than the compact x / q ring tells apart (chain_dp_tile.h, Lds<>): it runs with the 32-bit ring
+		for (int o = 32; o > 0; o >>= 1) { q_min = min(q_min, __shfl_xor(q_min, o)); q_max = max(q_max, __shfl_xor(q_max, o)); }
+		if ((lane & 63) == 0) { atomicMin(&s_qmin, q_min); atomicMax(&s_qmax, q_max); }
+		__syncthreads();
+		const int wide = (q_span_max == 0 || (unsigned)s_qmax - (unsigned)s_qmin > q_span_max) ? 2 : 0;
 		if (far_ring == 1) {
 			for (int o = 32; o > 0; o >>= 1) far_sum += __shfl_xor(far_sum, o);
 			if ((lane & 63) == 0 && far_sum) atomicAdd(&s_far, (unsigned long long)far_sum);
@@ -322,10 +339,10 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			// asm20 mixed (0.5) and dense (0.85)
 			if (lane == 0) {
 				const int c = (n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
-				cls_out[task] = (uint8_t)c;
+				cls_out[task] = (uint8_t)(c | wide);
 				if (cls_stat) { atomicAdd(&cls_stat[1], (unsigned long long)n); if (c) atomicAdd(&cls_stat[0], (unsigned long long)n); }
 			}
-		} else if (lane == 0) cls_out[task] = far_ring == 2 ? 1 : 0;
+		} else if (lane == 0) cls_out[task] = (uint8_t)((far_ring == 2 ? 1 : 0) | wide);
 	}
 	if (avg_out && n > 0) {
 		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
@@ -348,8 +365,8 @@ chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long
 	const unsigned long long far = cls_stat[0], all = cls_stat[1];
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= n_tasks) return;
-	if (4 * far < all) cls[t] = 0;
-	else if (4 * far > 3 * all) cls[t] = 1;
+	if (4 * far < all) cls[t] &= 2;                           // (bit 1, the 32-bit ring, is the task's own)
+	else if (4 * far > 3 * all) cls[t] |= 1;
 }
 
 // ---------------------------------------------------------------- the reference's HW/SW prediction pass, chain.c:53-78
@@ -592,46 +609,66 @@ static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagg
 }
 
 // ---- second-generation kernel (chain_dp_tile.h): x / q rings of NX tiles, f / p rings of NF tiles
-template <int NX, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
-static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, bool classes, int my_cls)
+// with_cls: the kernel takes the tasks whose class (prepass) masked with cls_mask equals my_cls
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
+static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, bool with_cls, int my_cls, int cls_mask)
 {
-	constexpr int NF = NX > MM2C_NX ? MM2C_NF1 : MM2C_NF;
 	if (L.cut.max_pieces > 0) {
-		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
+		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
 		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,
-		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count, classes ? (const uint8_t *)L.cut.d_cls : (const uint8_t *)nullptr, my_cls);
+		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count, with_cls ? (const uint8_t *)L.cut.d_cls : (const uint8_t *)nullptr, my_cls, cls_mask);
 		return hipGetLastError();
 	}
-	hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
+	hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
 	                   L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t,
-	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, classes ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr, my_cls);
+	                   L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, with_cls ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr, my_cls, cls_mask);
 	return hipGetLastError();
 }
 
-// the short ring (MM2C_NX tiles) for every task, or -- ring-size classes, variants with the hand-written loop only -- the short ring for class 0
-// and a ring of twice the length (half the occupancy) for class 1
-template <bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
-static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged)
+// the class array of the prepass reaches the kernels (plans have it; the piece arrays of a device-side cut must carry it too)
+static bool have_cls(const LaunchArgs &L) { return L.d_cls != nullptr && (L.cut.max_pieces == 0 || L.cut.d_cls != nullptr); }
+// ring-size classes: class-1 tasks run the instantiation with the long ring (variants with the hand-written loop only)
+static bool use_classes(const LaunchArgs &L, bool skip, bool gen) { return !gen && skip && L.far_ring != 0 && have_cls(L); }
+// the compact x / q ring (chain_dp_tile.h, Lds<>): differences of the low halves are exact when max_dist_x < 2^16 and, per task, the q values span
+// at most 65535 - max_dq; returns that bound for the prepass (0: not used)
+static unsigned compact_q_span(const LaunchArgs &L, bool asm_loop)
 {
-	const bool classes = !GEN && SKIP && L.far_ring != 0 && L.d_cls != nullptr && (L.cut.max_pieces == 0 || L.cut.d_cls != nullptr);
-	hipError_t e = launch_tile_nx<MM2C_NX, SKIP, GEN, GS1, FAR, TAB>(L, d_avg, st, only_flagged, classes, 0);
-	if (e != hipSuccess || !classes) return e;
-	if constexpr (!GEN && SKIP) return launch_tile_nx<2 * MM2C_NX, SKIP, GEN, GS1, FAR, TAB>(L, d_avg, st, only_flagged, true, 1);
+	const KParams &P = L.P;
+	if (!L.compact || !asm_loop || !have_cls(L) || P.max_dist_x < 0 || P.max_dist_x > 65535 || P.max_dq < 1 || P.max_dq > 32768) return 0;
+	return 65535u - (unsigned)P.max_dq;
+}
+
+// The 32-bit rings: one ring size for every task, or -- ring-size classes, variants with the hand-written loop only -- the short ring for class 0 and a ring of
+// twice the length for class 1.  Where the compact x / q ring applies, the tasks whose q values allow it (bit 1 of the class clear) take the one instantiation
+// with it instead (a ring of MM2C_CNX tiles, whatever their ring-size class).  Every instantiation is launched over all tasks and returns at once for the tasks
+// of another one (0.02 ms per launch); the 32-bit ones go first: they hold the longest tasks (a wide span of q values comes with a long read).
+template <bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB>
+static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, int *n_launches)
+{
+	const bool classes = use_classes(L, SKIP, GEN);
+	bool c16 = false;
+	if constexpr (SKIP && !GEN && (GS1 || TAB)) c16 = compact_q_span(L, L.P.bw >= 0 && L.P.max_dq - 1 >= L.P.bw) != 0;
+	const int wide = c16 ? 2 : 0, mask = (c16 ? 2 : 0) | (classes ? 1 : 0);
+	hipError_t e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, st, only_flagged, mask != 0, wide, mask);
+	if constexpr (!GEN && SKIP)
+		if (e == hipSuccess && classes) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, st, only_flagged, true, wide | 1, mask); if (n_launches) ++*n_launches; }
+	if constexpr (SKIP && !GEN && (GS1 || TAB))
+		if (e == hipSuccess && c16) { e = launch_tile_nx<MM2C_CNX, MM2C_CNF, SKIP, GEN, GS1, FAR, TAB, true>(L, d_avg, st, only_flagged, true, 0, 2); if (n_launches) ++*n_launches; }
 	return e;
 }
 
 template <bool SKIP, bool FAR>
-static hipError_t launch_tile_sf(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool gen, bool gs1, bool tab, int only_flagged)
+static hipError_t launch_tile_sf(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool gen, bool gs1, bool tab, int only_flagged, int *nl)
 {
-	if (tab && !gen) return launch_tile_one<SKIP, false, true, FAR, true>(L, d_avg, st, only_flagged);   // the table absorbs gap_scale
-	if (gen) return gs1 ? launch_tile_one<SKIP, true, true, FAR, false>(L, d_avg, st, only_flagged) : launch_tile_one<SKIP, true, false, FAR, false>(L, d_avg, st, only_flagged);
-	return gs1 ? launch_tile_one<SKIP, false, true, FAR, false>(L, d_avg, st, only_flagged) : launch_tile_one<SKIP, false, false, FAR, false>(L, d_avg, st, only_flagged);
+	if (tab && !gen) return launch_tile_one<SKIP, false, true, FAR, true>(L, d_avg, st, only_flagged, nl);   // the table absorbs gap_scale
+	if (gen) return gs1 ? launch_tile_one<SKIP, true, true, FAR, false>(L, d_avg, st, only_flagged, nl) : launch_tile_one<SKIP, true, false, FAR, false>(L, d_avg, st, only_flagged, nl);
+	return gs1 ? launch_tile_one<SKIP, false, true, FAR, false>(L, d_avg, st, only_flagged, nl) : launch_tile_one<SKIP, false, false, FAR, false>(L, d_avg, st, only_flagged, nl);
 }
 
-static hipError_t launch_tile(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool skip, bool gen, bool gs1, bool far_, bool tab, int only_flagged)
+static hipError_t launch_tile(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool skip, bool gen, bool gs1, bool far_, bool tab, int only_flagged, int *nl)
 {
-	if (skip) return far_ ? launch_tile_sf<true, true>(L, d_avg, st, gen, gs1, tab, only_flagged) : launch_tile_sf<true, false>(L, d_avg, st, gen, gs1, tab, only_flagged);
-	return far_ ? launch_tile_sf<false, true>(L, d_avg, st, gen, gs1, tab, only_flagged) : launch_tile_sf<false, false>(L, d_avg, st, gen, gs1, tab, only_flagged);
+	if (skip) return far_ ? launch_tile_sf<true, true>(L, d_avg, st, gen, gs1, tab, only_flagged, nl) : launch_tile_sf<true, false>(L, d_avg, st, gen, gs1, tab, only_flagged, nl);
+	return far_ ? launch_tile_sf<false, true>(L, d_avg, st, gen, gs1, tab, only_flagged, nl) : launch_tile_sf<false, false>(L, d_avg, st, gen, gs1, tab, only_flagged, nl);
 }
 
 template <int R, bool GEN, bool FAR>
@@ -685,7 +722,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
 		info->skip = skip; info->gen = want_gen; info->gs1 = gs1; info->far_ = t0 ? far_ : (tile ? far_old : far_); info->tab = t0 && tab && !want_gen;
 		info->asm_loop = t0 && skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // = ASM of chain_dp_tile
-		info->classes = t0 && !want_gen && skip && L.far_ring != 0 && L.d_cls != nullptr && (L.cut.max_pieces == 0 || L.cut.d_cls != nullptr);
+		info->classes = t0 && use_classes(L, skip, want_gen);
+		info->c16 = t0 && compact_q_span(L, info->asm_loop != 0) != 0;
 		info->cut = L.cut.max_pieces > 0;
 	}
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
@@ -693,7 +731,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
-	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && L.far_ring == 1 ? L.d_cls_stat : (unsigned long long *)nullptr);
+	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && L.far_ring == 1 ? L.d_cls_stat : (unsigned long long *)nullptr,
+	                   tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
 	if (e == hipSuccess && tile && L.far_ring == 1 && L.d_cls && L.d_cls_stat) {
@@ -703,7 +742,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	}
 	if (e == hipSuccess && L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL(chain_cut, dim3((unsigned)L.n_tasks), dim3(64), 0, st, L.cut.seg_min, L.n_tasks, L.d_offsets, L.d_order,
-		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut, tile && L.far_ring != 0 ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr);
+		                   (const uint4 *)L.d_anchors, d_avg, L.d_st, L.cut, tile ? (const uint8_t *)L.d_cls : (const uint8_t *)nullptr);   // (far_ring 0: bit 1, the 32-bit ring, still counts)
 		e = hipGetLastError();
 		if (n_launches) ++*n_launches;
 	}
@@ -715,7 +754,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 		const bool gen = want_gen || pass == 1;
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
-		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged); if (n_launches) ++*n_launches; continue; }
+		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged, n_launches); if (n_launches) ++*n_launches; continue; }
 		if (tile) { e = launch_r<256>(L1, st, skip, gen, gs1, far_old, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {
 		case 256: e = launch_r<256>(L1, st, skip, gen, gs1, far_, flagged); break;

@@ -404,6 +404,8 @@ int mm2c_init(int device_ordinal)
 	if (ef) G.epi_fused = atoi(ef) != 0;
 	const char *fr = getenv("MM2C_FAR_RING");            // 0: one LDS ring size for every task; 2: the long ring for every task (tests)
 	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
+	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
+	if (cr) G.compact_ring = atoi(cr) != 0;
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
 	if (ft) G.far_thr10 = std::max(0, atoi(ft));
 	G.ready = true;
@@ -500,6 +502,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "far_ring_threshold") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "far_ring_threshold (tenths of a far tile per anchor) must be >= 0");
 		G.far_thr10 = value;
+		return 0;
+	}
+	if (strcmp(key, "compact_ring") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "compact_ring must be 0 or 1");
+		G.compact_ring = value;
 		return 0;
 	}
 	if (strcmp(key, "force_tab") == 0) {
@@ -688,7 +695,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
 	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
 	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 16, st));
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
@@ -767,8 +774,8 @@ int mm2c_plan_last_variant(mm2c_plan_t *pl, char *buf, size_t len)
 	if (!pl || !buf || len == 0) return fail(MM2C_E_ARG, "NULL argument");
 	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
 	const mm2c::LaunchInfo &I = pl->info;
-	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
-	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut);
+	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
+	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16);
 	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
 	return 0;
 }

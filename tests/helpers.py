@@ -50,3 +50,34 @@ def assert_same(f, p, f_ref, p_ref, offsets=None, what=""):
         task = int(np.searchsorted(np.asarray(offsets), i, side="right") - 1) if offsets is not None else -1
         raise AssertionError(f"{what}: {bad.size} of {f.size} anchors differ; first at {i} (task {task}): "
                              f"f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}")
+
+
+def respan_q(rng, task, max_dq, mode):
+    """A copy of one task (uint64 [n, 2]) with its query positions moved so that the compact x / q ring of the tile kernel (chain_dp_tile.h, Lds<>:
+    differences of the low 16 bits) meets its corners; x and the order of the anchors stay.  The ring is exact while the task's q values span at
+    most 65535 - max_dq; the prepass sends every other task to the 32-bit ring.
+      1: every q shifted by one large constant (the span stays: still compact, the low halves wrap)
+      2: multiples of 65536 added to random anchors (differences that alias mod 2^16: must be recognised as a wide task)
+      3: one anchor moved so that the span is exactly 65535 - max_dq (the last compact value);   4: one more (the first wide one)
+      5: q values spread over about 60 000 (compact for the usual max_dq, pairs with dq just below / above 2^16 - max_dq)"""
+    t = np.array(task, dtype=np.uint64).reshape(-1, 2).copy()
+    if t.shape[0] == 0 or mode == 0:
+        return t
+    q = (t[:, 1] & np.uint64(0xffffffff)).astype(np.int64)
+    hi = t[:, 1] & np.uint64(0xffffffff00000000)
+    bound = 65535 - max(int(max_dq), 0)
+    if mode == 1:
+        q = q + int(rng.integers(1 << 16, (1 << 31) - int(q.max()) - 1))
+    elif mode == 2:
+        q = q + 65536 * rng.integers(0, 3, q.shape[0]) * (rng.random(q.shape[0]) < 0.3)
+    elif mode in (3, 4):
+        k = int(rng.integers(0, q.shape[0]))
+        q = np.minimum(q, int(q.min()) + max(bound, 0))
+        q[k] = int(q.min()) + max(bound, 0) + (1 if mode == 4 else 0)
+        if q.shape[0] > 1:
+            q[(k + 1) % q.shape[0]] = int(q.min())
+    elif mode == 5:
+        q = int(q.min()) + (q - int(q.min())) % 60000 + (rng.random(q.shape[0]) < 0.2) * rng.integers(0, 60000, q.shape[0])
+        q = int(q.min()) + (q - int(q.min())) % 60000
+    t[:, 1] = hi | (q.astype(np.uint64) & np.uint64(0xffffffff))
+    return t

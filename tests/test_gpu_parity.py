@@ -179,6 +179,35 @@ def test_ring_size_classes_in_one_batch(far_ring):
     assert_same(f, p, f_ref, p_ref, off, f"far_ring={far_ring}")
 
 
+@pytest.mark.parametrize("preset,compact", [("map-ont", 1), ("map-ont", 0), ("ava-ont", 1), ("asm20", 1)])
+def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, knobs):
+    """The tile kernel keeps the LOW 16 BITS of x and q of the ring anchors (4 bytes per anchor, Lds<..., C16>): exact while max_dist_x < 2^16 and the
+    task's q values span at most 65535 - max_dq; the prepass (chain_window_start) sends every other task to the instantiations with the 32-bit ring.
+    One batch with tasks on both sides of that bound and at it: q shifted by large constants (low halves wrap), multiples of 65536 added to random
+    anchors (differences that alias mod 2^16), a span of exactly 65535 - max_dq and one more, q spread over 60 000, tasks long enough to be cut into
+    pieces on the device (pieces inherit the class)."""
+    from helpers import respan_q
+    from mm2chain import params, synth
+    P = {"map-ont": params.map_ont, "ava-ont": params.ava_ont, "asm20": params.asm20}[preset]()
+    max_dq = min(P.max_dist_x, P.max_dist_y)
+    rng = np.random.default_rng(77)
+    knobs("compact_ring", compact)
+    knobs("plan_cut_min", 6000)
+    tasks = []
+    for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("mixed", 9000, 300000), ("colinear", 2500, None), ("dense", 7000, 30000),
+                                          ("mixed", 700, None), ("sparse", 500, None), ("mixed", 1, None), ("dense", 1500, 3000)]):
+        base = synth.make_stream(prof, 1, n, seed=880 + k, locus=locus)[1].numpy().view(np.uint64)
+        for mode in ((0, 1, 2, 3, 4, 5) if n <= 4000 else (0, 2, 5)):
+            tasks.append(respan_q(rng, base, max_dq, mode))
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    v = []
+    f, p = gpu_batch(P, off, a, variant=v)
+    assert_same(f, p, f_ref, p_ref, off, f"{preset}, compact_ring={compact}: {v[0]}")
+    assert f"compact={compact}" in v[0] and "loop=asm" in v[0], v
+
+
 def test_ava_ont_and_asm20_shapes():
     from mm2chain import params
     for P, span in ((params.ava_ont(), 15), (params.asm20(), 19)):
@@ -702,12 +731,12 @@ def knobs():
     """tuning knobs a test changes, put back afterwards (results never depend on them; the instantiation that runs does)"""
     import mm2chain
     yield mm2chain.tune
-    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0),
+    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("compact_ring", 1),
                      ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256)):
         mm2chain.tune(key, val)
 
 
-@pytest.mark.parametrize("route", ["asm", "asm-tab", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024"])
+@pytest.mark.parametrize("route", ["asm", "asm-32-bit-ring", "asm-tab", "asm-tab-32-bit-ring", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024"])
 def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs):
     """The reference-produced vectors through the instantiations that carry the throughput.  With max_skip = 1023 and max_iter = 1024 the
     max-skip machinery of chain.c:226-233 is compiled in and runs (stamps, skip counter, the folds) but cannot fire: among at most 1024
@@ -717,7 +746,8 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
     ring-size classes off / forced, tasks cut into pieces on the device, and the first-generation kernel with each of its ring sizes.
     Which instantiation ran is asserted from mm2c_plan_last_variant."""
     from mm2chain import params
-    if route == "asm-tab": knobs("force_tab", 1)
+    if route in ("asm-tab", "asm-tab-32-bit-ring"): knobs("force_tab", 1)
+    if route.endswith("32-bit-ring"): knobs("compact_ring", 0)
     if route == "asm-short-ring-only": knobs("far_ring", 0)
     if route == "asm-long-ring-only": knobs("far_ring", 2)
     if route == "asm-device-cut": knobs("plan_cut_min", 1000); knobs("seg_min", 64)
@@ -733,7 +763,8 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
             assert v[0].startswith(f"chain_dp_wave<R={route[5:]},SKIP=1"), v
         else:
             assert v[0].startswith("chain_dp_tile<") and "SKIP=1" in v[0] and "GEN=0" in v[0] and "FAR=1" in v[0] and "loop=asm" in v[0], v
-            assert ("TAB=1" in v[0]) == (route == "asm-tab" and bw <= 511), v
+            assert ("TAB=1" in v[0]) == (route.startswith("asm-tab") and bw <= 511), v
+            assert ("compact=1" in v[0]) == (not route.endswith("32-bit-ring")), v
             assert ("classes=1" in v[0]) == (route != "asm-short-ring-only"), v
             assert ("cut=1" in v[0]) == (int(np.diff(off).max()) >= (1000 if route == "asm-device-cut" else 8192)), v   # plan_cut_min
         n += a.shape[0]

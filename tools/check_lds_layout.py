@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Link-time guard for the hand-written loop of chain_dp_tile (csrc/chain_dp_tile.h).
 
-The assembly addresses the kernel's LDS from byte 0 with immediate offsets (struct Lds<NX, NF, GEN, TAB>), which is only right while the
+The assembly addresses the kernel's LDS from byte 0 with immediate offsets (struct Lds<NX, NF, GEN, TAB, C16>), which is only right while the
 kernel owns exactly ONE LDS object.  A second `__shared__` object in that kernel would be laid out beside it and the group segment of the
 kernel would grow by its size, so: for every chain_dp_tile instantiation in the library's gfx950 code objects, the
 `.group_segment_fixed_size` of the kernel descriptor must equal Lds<>::BYTES computed from the template arguments in the kernel's name.
@@ -18,10 +18,10 @@ import msgpack
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def lds_bytes(nx, nf, gen, tab):
-    """Lds<NX, NF, GEN, TAB>::BYTES of csrc/chain_dp_tile.h: x / q rings (NX tiles), f / p rings (NF tiles), one stamp byte per ring anchor,
-    the gap-cost table, the segment-id ring"""
-    return 2 * nx * 256 + 2 * nf * 256 + 64 * nx + (1024 if tab else 0) + (64 * nx if gen else 0)
+def lds_bytes(nx, nf, gen, tab, c16):
+    """Lds<NX, NF, GEN, TAB, C16>::BYTES of csrc/chain_dp_tile.h: x / q ring (NX tiles of 64 slots of 8 bytes, 4 in the compact form), f / p ring
+    (NF tiles), one stamp byte per ring anchor, the gap-cost table, the segment-id ring"""
+    return nx * 64 * (4 if c16 else 8) + 2 * nf * 256 + 64 * nx + (1024 if tab else 0) + (64 * nx if gen else 0)
 
 
 def elf_sections(elf):
@@ -78,12 +78,12 @@ def check(path, verbose=False):
     seen, bad = 0, []
     for triple, elf in code_objects(data):
         for name, lds in kernels_of(elf):
-            # _ZN4mm2c13chain_dp_tileILi8ELi2ELb1ELb0ELb1ELb1ELb0EEEv...: <NX, NF, SKIP, GEN, GS1, FAR, TAB>
-            m = re.match(r"_ZN4mm2c13chain_dp_tileILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])EEE", name)
+            # _ZN4mm2c13chain_dp_tileILi8ELi2ELb1ELb0ELb1ELb1ELb0ELb1EEEv...: <NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>
+            m = re.match(r"_ZN4mm2c13chain_dp_tileILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])EEE", name)
             if not m:
                 continue
-            nx, nf, _skip, gen, _gs1, _far, tab = (int(v) for v in m.groups())
-            want = lds_bytes(nx, nf, gen, tab)
+            nx, nf, _skip, gen, _gs1, _far, tab, c16 = (int(v) for v in m.groups())
+            want = lds_bytes(nx, nf, gen, tab, c16)
             seen += 1
             if verbose:
                 print(f"{triple} chain_dp_tile<{','.join(m.groups())}>: group segment {lds} B, Lds<>::BYTES {want} B")
