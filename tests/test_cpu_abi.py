@@ -110,7 +110,8 @@ def test_hand_written_loop_owns_the_kernels_only_lds_object():
     import check_lds_layout
     seen, bad = check_lds_layout.check(os.path.join(ROOT, "minimap2-fpga_amd", "libmm2chain_hip.so"))
     assert seen >= 20 and not bad, bad
-    assert check_lds_layout.lds_bytes(8, 2, 0, 0) == 5632      # 5.5 KB per wave: 28 waves per CU
+    assert check_lds_layout.lds_bytes(8, 2, 0, 0, 0) == 5632   # 5.5 KB per wave: 28 waves per CU
+    assert check_lds_layout.lds_bytes(16, 2, 0, 0, 1) == 6144  # the compact ring: 16 tiles in 6 KB, 26 waves per CU
 
 
 def test_split_model_getter_returns_the_header_constants():
