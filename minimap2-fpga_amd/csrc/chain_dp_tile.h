@@ -366,10 +366,17 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_NEXT_XQ_W "ds_read_b64 " MM2C_R_XQ ", %[addr] offset:%[XQOFF]\n\t" MM2C_BACK_W
 #define MM2C_NEXT_XQ_C "ds_read_b32 " MM2C_R_X ", %[addr] offset:%[XQOFF]\n\t" MM2C_BACK_C
 #define MM2C_RFILTER_W MM2C_FILTER("" MM2C_R_X "", "" MM2C_R_Q "")
-// 16-bit subtractions: (x_i - 1 - x_j) mod 2^16 and (q_i - 1 - q_j) mod 2^16, zero-extended (SDWA: the result goes to the low word, the rest is padded with zeros)
-#define MM2C_RFILTER_C \
-	"v_sub_u16_sdwa %[dr], %[xi1], " MM2C_R_X " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
-	"v_sub_u16_sdwa %[dq], %[qi1], " MM2C_R_X " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+#define MM2C_OWNFILTER_W MM2C_FILTER("%[tx]", "%[tq]")
+#define MM2C_FARFILTER_W MM2C_FILTER("%[fx]", "%[fq]")
+#define MM2C_RDXQ_W "v_readfirstlane_b32 %[xi1], %[tx1]\n\t" "v_readfirstlane_b32 %[qi1], %[tq1]\n\t"
+// 16-bit subtractions: (x_i - 1 - x_j) mod 2^16 and (q_i - 1 - q_j) mod 2^16, zero-extended (SDWA: the result goes to the low word, the rest is padded with
+// zeros).  The anchor's own x - 1 and q - 1 travel as ONE packed word too (xi1: low halves of x - 1 | q - 1 << 16; one v_readfirstlane per anchor less), the own
+// tile is filtered from its packed word (the operand tx: what the tile wrote into the ring), and a tile from memory (fx, fq: 32-bit loads) by its low halves
+#define MM2C_SUB16(D, S0SEL, V, S1SEL) "v_sub_u16_sdwa " D ", %[xi1], " V " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" S0SEL " src1_sel:" S1SEL "\n\t"
+#define MM2C_RFILTER_C MM2C_SUB16("%[dr]", "WORD_0", MM2C_R_X, "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", MM2C_R_X, "WORD_1")
+#define MM2C_OWNFILTER_C MM2C_SUB16("%[dr]", "WORD_0", "%[tx]", "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", "%[tx]", "WORD_1")
+#define MM2C_FARFILTER_C MM2C_SUB16("%[dr]", "WORD_0", "%[fx]", "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", "%[fq]", "WORD_0")
+#define MM2C_RDXQ_C "v_readfirstlane_b32 %[xi1], %[tx1]\n\t"
 #define MM2C_OLDADDR_W "v_add_u32 %[vb], 0x400, %[addr]\n\t"
 #define MM2C_OLDADDR_C "v_add_lshl_u32 %[vb], %[addr], %[c200], 1\n\t"
 // x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
@@ -448,7 +455,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_cbranch_scc1 Ldone_%=\n" \
 	"Lret_%=:\n\t" \
 	"s_branch Lloop_%=\n"
-#define MM2C_END_FAR(SCORE) \
+#define MM2C_END_FAR(SCORE, FARFILTER) \
 	"Lend_%=:\n\t" \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Ldone_%=\n\t" \
@@ -466,7 +473,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_sub_u32 %[n], %[n], 1\n\t" \
 	"s_cbranch_scc1 Lfpart_%=\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
-	MM2C_FILTER("%[fx]", "%[fq]") MM2C_FAR_REQ MM2C_FILTER2 \
+	FARFILTER MM2C_FAR_REQ MM2C_FILTER2 \
 	"s_cbranch_vccz Lfloop_%=\n\t" \
 	"s_mov_b64 %[valid], vcc\n\t" \
 	"s_branch Lfold_%=\n" \
@@ -475,7 +482,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_cmp_eq_u32 %[part], 0\n\t" \
 	"s_cbranch_scc1 Ldone_%=\n\t" \
 	"s_waitcnt vmcnt(0)\n\t" \
-	MM2C_FILTER("%[fx]", "%[fq]") MM2C_FILTER2 \
+	FARFILTER MM2C_FILTER2 \
 	"s_sub_i32 %[t0], 64, %[part]\n\t" \
 	"s_lshr_b64 %[mask], -1, %[t0]\n\t" \
 	"s_mov_b32 %[part], 0\n\t" \
@@ -505,15 +512,14 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_waitcnt vmcnt(0)\n\t" \
 	"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
 	"s_branch Lmk2_%=\n"
-#define MM2C_END_LEAN(SCORE) \
+#define MM2C_END_LEAN(SCORE, FARFILTER) \
 	"Lend_%=:\n"
 
-#define MM2C_READ_ANCHOR(SEG_RD) \
+#define MM2C_READ_ANCHOR(SEG_RD, RDXQ) \
 	"v_readfirstlane_b32 %[pk], %[tw]\n\t" \
 	"v_readfirstlane_b32 %[best], %[tspan]\n\t" \
 	SEG_RD \
-	"v_readfirstlane_b32 %[xi1], %[tx1]\n\t" \
-	"v_readfirstlane_b32 %[qi1], %[tq1]\n\t"
+	RDXQ
 // price-list probes (tools/probe_prices.sh): extra instructions of one class per anchor (MM2C_PROBE_LK) or per older tile (MM2C_PROBE_LOOP) that
 // change no result -- u1 / t1 are dead at both places -- so that the time per added instruction of each class can be measured on the real kernel
 // (-DMM2C_PROBE=1..6: four plain VALU / four SALU / four v_readlane per anchor, two plain VALU / two SALU / two v_cmp per older tile)
@@ -562,7 +568,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #ifndef MM2C_PROBE_LOOP
 #define MM2C_PROBE_LOOP ""
 #endif
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, OWNFILTER, FARFILTER, RDXQ, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
@@ -581,7 +587,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_lshr_b64 %[oh], %[mask], 1\n\t" \
 		"s_or_b64 %[oh], %[oh], %[mask]\n\t"      /* lanes L and L - 1: the anchor in progress and the next one */ \
 		"s_mov_b64 exec, %[mask]\n\t" \
-		MM2C_READ_ANCHOR(SEG_RD) \
+		MM2C_READ_ANCHOR(SEG_RD, RDXQ) \
 		"s_mov_b64 exec, %[ex]\n" \
 		"Lk_%=:\n\t" \
 		MM2C_PROBE_LK \
@@ -601,7 +607,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_bfe_u32 %[t1], %[pk], 0x70008\n\t" \
 		"s_bfm_b64 %[mask], %[t0], %[t1]\n\t" \
-		MM2C_FILTER("%[tx]", "%[tq]") MM2C_FILTER2 \
+		OWNFILTER MM2C_FILTER2 \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
 		"s_mov_b32 %[d], 0\n\t" \
@@ -802,13 +808,13 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cmp_eq_u32 %[last], 63\n\t" \
 		"s_cbranch_scc1 Lret_%=\n\t" \
 		"s_branch Ldone_%=\n" \
-		SEG_END(SCORE) \
+		SEG_END(SCORE, FARFILTER) \
 		"Ldone_%=:\n\t" \
 		SEG_DONE \
 		"s_mov_b64 exec, %[oh]\n\t"               /* commit into lane L (lane L - 1, the next anchor's, is written too: its own commit follows) ... */ \
 		"v_mov_b32 %[own_f], %[best]\n\t" \
 		"v_mov_b32 %[own_p], %[bestj]\n\t" \
-		MM2C_READ_ANCHOR(SEG_RD)                     /* ... and the scalars of the next anchor from the lowest active lane, L - 1 */ \
+		MM2C_READ_ANCHOR(SEG_RD, RDXQ)                     /* ... and the scalars of the next anchor from the lowest active lane, L - 1 */ \
 		"s_mov_b64 exec, %[ex]\n\t" \
 		"s_lshr_b64 %[oh], %[oh], 1\n\t" \
 		"s_add_u32 %[c], %[c], 1\n\t"              /* carry out: that was the tile's last anchor */ \
@@ -837,8 +843,8 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-#define MM2C_RING_W MM2C_XQ1_W, MM2C_NEXT_XQ_W, MM2C_RFILTER_W, MM2C_OLDADDR_W, MM2C_BACK_W
-#define MM2C_RING_C MM2C_XQ1_C, MM2C_NEXT_XQ_C, MM2C_RFILTER_C, MM2C_OLDADDR_C, MM2C_BACK_C
+#define MM2C_RING_W MM2C_XQ1_W, MM2C_NEXT_XQ_W, MM2C_RFILTER_W, MM2C_OLDADDR_W, MM2C_BACK_W, MM2C_OWNFILTER_W, MM2C_FARFILTER_W, MM2C_RDXQ_W
+#define MM2C_RING_C MM2C_XQ1_C, MM2C_NEXT_XQ_C, MM2C_RFILTER_C, MM2C_OLDADDR_C, MM2C_BACK_C, MM2C_OWNFILTER_C, MM2C_FARFILTER_C, MM2C_RDXQ_C
 #define MM2C_SCAN_TILE_ASM_(...) MM2C_SCAN_TILE_ASM(__VA_ARGS__)
 #define MM2C_LEAN MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%="
 #define MM2C_FARS MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%="
@@ -856,7 +862,7 @@ MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_c, true, true, MM2C_RING_C, MM2C_SCORE
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
 // C16: the compact x / q ring (Lds<>), for the variants with the hand-written loop; the launcher picks it per task (cls bit 1 clear)
 template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (Lds<NX, NF, GEN, TAB, C16>::BYTES <= 6144 ? 7 : 1))   // waves per SIMD the LDS leaves room for: at most 72 VGPRs then (the 16-tile compact ring came out at 73)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
@@ -934,6 +940,9 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		int prev_last = rdlane(own_x, 0);
 		own_x = (int)cur.x; own_q = (int)cur.z;
 		own_g = (cur.w >> 16) & 0xff;                                         // MM_SEED_SEG_MASK mmpriv.h:22-23
+		const int own_xq = (int)(((unsigned)own_x & 0xffffu) | ((unsigned)own_q << 16));               // compact ring: the low halves of x and q ...
+		const int own_xq1 = (int)(((unsigned)(own_x - 1) & 0xffffu) | ((unsigned)(own_q - 1) << 16));   // ... and of x - 1 and q - 1
+		(void)own_xq; (void)own_xq1;
 		if (!GEN && !(P.flags & KF_IGNORE_SEG)) {
 			// the simple variant assumes one segment id per task; anything else is redone by the general one
 			if (i0 == 0) seg0 = rdlane(own_g, 63);
@@ -945,7 +954,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		const int stamp_lo = i0 - 64 * (NX - 1);   // oldest anchor reachable without global memory while this tile is processed
 		{
 			const int o = (idx & (SN - 1)) * LY::XS;   // the tile enters the x / q ring (its slot held the tile NX tiles back)
-			if (C16) *(unsigned *)(lds + LY::XQ + o) = ((unsigned)own_x & 0xffffu) | ((unsigned)own_q << 16);
+			if (C16) *(int *)(lds + LY::XQ + o) = own_xq;
 			else *(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
 			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 3)) = (uint8_t)own_g;
 		}
@@ -1000,8 +1009,12 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
                                  LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
 				if (C16) {
-					if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far_c, lo_l);
-					else k = TAB ? MM2C_CALL(scan_tile_asm_tab_c, lo_l) : MM2C_CALL(scan_tile_asm_cmp_c, lo_l);
+					// the compact forms take packed words where the 32-bit ones take x and q: the tile's own {x, q} halves and the anchors' {x - 1, q - 1} halves
+#define MM2C_CALLC(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_xq, own_xq1, own_xq, own_xq1, span_l, lo_c, \
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+					if (FAR && tile_far) k = TAB ? MM2C_CALLC(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_far_c, lo_l);
+					else k = TAB ? MM2C_CALLC(scan_tile_asm_tab_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_c, lo_l);
+#undef MM2C_CALLC
 				} else if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
 				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
 #undef MM2C_CALL
