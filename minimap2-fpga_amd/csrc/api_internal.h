@@ -38,6 +38,7 @@ struct Global {
 	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
 	std::atomic<int> ring_class{3};
 	std::atomic<int> far_thr10{7};                      // ... from this many tenths of an expected far tile per anchor
+	std::atomic<int> split_streams{1};                  // plans: the instantiations a batch is split over (32-bit / compact ring) run side by side on two streams
 	std::atomic<int> compact_ring{1};                   // tile kernel: the compact x / q ring for the tasks whose q values allow it (0: never; the parity tests run both)
 	std::atomic<int> force_tab{0};                      // tile kernel: gap cost from the LDS table also when gap_scale == 1 (tests; slower)
 	std::atomic<int> far_ring{1};                       // plans: tasks whose scans are expected to leave the short LDS ring run with a ring twice as long (0: never, 2: all)
@@ -182,6 +183,10 @@ inline int resolve_stream(void *stream, int device, hipStream_t *out)
 void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
 void release_seed_aux();                            // mm2chain_seeds.cpp
+// a pooled set of helper streams (distinct priorities = hardware queues of their own) and fork / join events, kept between plans (mm2chain_seeds.cpp)
+struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; };
+hipError_t aux_acquire(int device, AuxSet *out);
+void aux_release(const AuxSet &a);
 // for callers that have already waited for the stream(s) the plan ran on: no device-wide wait (chunks of a pipelined batch overlap)
 void plan_destroy_synced(mm2c_plan_t *pl);          // mm2chain_api.cpp
 void seedplan_destroy_synced(mm2c_seedplan_t *pl);  // mm2chain_seeds.cpp

@@ -42,6 +42,8 @@ struct LaunchArgs {
 	float *d_avg_ws = nullptr;  // n_tasks floats of workspace: when d_avg is nullptr the prepass computes avg_qspan_scaled into it
 	uint8_t *d_cls = nullptr;   // n_tasks bytes of workspace, or nullptr: class per task, written by the prepass (tile kernel only): bit 0 long ring, bit 1 the
 	                            // task needs the 32-bit x / q ring (its q values span more than the compact ring can tell apart, chain_dp_tile.h Lds<>)
+	hipStream_t side = nullptr; // with ev_fork / ev_join: when the batch is split over the 32-bit and the compact instantiations, the 32-bit ones run on this stream
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // beside the compact one (two launches one after the other each end with the GPU part empty)
 	int compact = 1;            // 0: never the compact x / q ring (mm2c_tune("compact_ring", 0); the parity tests run both)
 	unsigned long long *d_cls_stat = nullptr;   // two counters, zero on entry: anchors of the class-1 tasks and of all tasks (chain_cls_settle), or nullptr
 	int far_thr10 = 7;          // far_ring 1: a task takes the long ring when it expects more than far_thr10 / 10 tiles beyond the short ring per anchor

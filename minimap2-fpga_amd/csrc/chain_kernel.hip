@@ -649,11 +649,18 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 	bool c16 = false;
 	if constexpr (SKIP && !GEN && (GS1 || TAB)) c16 = compact_q_span(L, L.P.bw >= 0 && L.P.max_dq - 1 >= L.P.bw) != 0;
 	const int wide = c16 ? 2 : 0, mask = (c16 ? 2 : 0) | (classes ? 1 : 0);
-	hipError_t e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, st, only_flagged, mask != 0, wide, mask);
+	// the 32-bit instantiations beside the compact one: on the side stream, between a fork and a join event
+	const bool fork = c16 && L.side != nullptr && L.ev_fork != nullptr && L.ev_join != nullptr;
+	hipStream_t sw = fork ? L.side : st;
+	hipError_t e = hipSuccess;
+	if (fork) { e = hipEventRecord(L.ev_fork, st); if (e == hipSuccess) e = hipStreamWaitEvent(sw, L.ev_fork, 0); }
+	if (e == hipSuccess) e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, mask != 0, wide, mask);
 	if constexpr (!GEN && SKIP)
-		if (e == hipSuccess && classes) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, st, only_flagged, true, wide | 1, mask); if (n_launches) ++*n_launches; }
+		if (e == hipSuccess && classes) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, true, wide | 1, mask); if (n_launches) ++*n_launches; }
+	if (fork && e == hipSuccess) e = hipEventRecord(L.ev_join, sw);
 	if constexpr (SKIP && !GEN && (GS1 || TAB))
 		if (e == hipSuccess && c16) { e = launch_tile_nx<MM2C_CNX, MM2C_CNF, SKIP, GEN, GS1, FAR, TAB, true>(L, d_avg, st, only_flagged, true, 0, 2); if (n_launches) ++*n_launches; }
+	if (fork && e == hipSuccess) e = hipStreamWaitEvent(st, L.ev_join, 0);
 	return e;
 }
 

@@ -344,6 +344,7 @@ struct mm2c_plan {
 	int64_t n_tasks = 0, total = 0;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr; uint8_t *d_cls = nullptr;
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
+	mm2c_api::AuxSet aux;                   // helper stream + fork / join events (pooled): taken by the first run that may split its tasks over two instantiations
 	bool ran = false, epi_ran = false;
 	mm2c::LaunchInfo info = {};             // what the last run launched (mm2c_plan_last_variant)
 	std::vector<int32_t> sizes_desc;        // task sizes, longest first (host copy: bounds the number of pieces of the device-side cut)
@@ -404,6 +405,8 @@ int mm2c_init(int device_ordinal)
 	if (ef) G.epi_fused = atoi(ef) != 0;
 	const char *fr = getenv("MM2C_FAR_RING");            // 0: one LDS ring size for every task; 2: the long ring for every task (tests)
 	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
+	const char *ss = getenv("MM2C_SPLIT_STREAMS");       // 0: the instantiations of a split batch run one after the other on the caller's stream
+	if (ss) G.split_streams = atoi(ss) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
@@ -502,6 +505,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "far_ring_threshold") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "far_ring_threshold (tenths of a far tile per anchor) must be >= 0");
 		G.far_thr10 = value;
+		return 0;
+	}
+	if (strcmp(key, "split_streams") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "split_streams must be 0 or 1");
+		G.split_streams = value;
 		return 0;
 	}
 	if (strcmp(key, "compact_ring") == 0) {
@@ -662,6 +670,7 @@ static void plan_destroy_impl(mm2c_plan_t *pl, bool wait)
 		if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 		if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
+		aux_release(pl->aux);                 // the helper stream joins the plan's stream at the end of every run: idle once that stream has been waited for
 	}
 	delete pl;
 }
@@ -722,6 +731,10 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 			HIP_TRY(hipMemsetAsync(pl->d_cut, 0, 256 + (((size_t)max_pieces * 4 + 255) & ~(size_t)255) + (((size_t)pl->n_tasks * 4 + 255) & ~(size_t)255), st));   // count + status + has_cut
 			L.cut = pl->cut;
 		}
+	}
+	if (G.split_streams && G.compact_ring && G.ring_class >= 3) {
+		if (pl->aux.device < 0) HIP_TRY(aux_acquire(pl->device, &pl->aux));
+		L.side = pl->aux.aux[2]; L.ev_fork = pl->aux.fork[0]; L.ev_join = pl->aux.fork[1];   // (aux[2]: the helper stream of middle priority)
 	}
 	HIP_TRY(hipEventRecord(pl->ev_pre, st));
 	int nl = 0;

@@ -22,10 +22,11 @@ struct mm2c_seedplan {
 // helper streams and fork / join events of the seed plans, kept between plans: a pipelined batch makes a plan per chunk, and creating three
 // streams of distinct priority per plan cost milliseconds each
 namespace {
-struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; };
 std::mutex g_aux_mu;
 std::vector<AuxSet> g_aux_free;
+}
 
+namespace mm2c_api {
 hipError_t aux_acquire(int device, AuxSet *out)
 {
 	{
@@ -57,9 +58,7 @@ void aux_release(const AuxSet &a)
 	std::lock_guard<std::mutex> lk(g_aux_mu);
 	g_aux_free.push_back(a);
 }
-} // namespace
 
-namespace mm2c_api {
 void release_seed_aux()                       // mm2c_shutdown
 {
 	std::lock_guard<std::mutex> lk(g_aux_mu);
