@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
                    float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
-                   unsigned long long *__restrict__ cls_stat /* [anchors of class-1 tasks, anchors of all tasks], or nullptr */,
+                   unsigned long long *__restrict__ cls_stat /* anchors of [class-1 tasks, all tasks, -, tasks with the 32-bit ring], or nullptr */,
                    unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */)
 {
 	const int lane = threadIdx.x;
@@ -340,9 +340,15 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			if (lane == 0) {
 				const int c = (n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
 				cls_out[task] = (uint8_t)(c | wide);
-				if (cls_stat) { atomicAdd(&cls_stat[1], (unsigned long long)n); if (c) atomicAdd(&cls_stat[0], (unsigned long long)n); }
+				if (cls_stat) {
+					atomicAdd(&cls_stat[1], (unsigned long long)n); if (c) atomicAdd(&cls_stat[0], (unsigned long long)n);
+					if (wide) atomicAdd(&cls_stat[3], (unsigned long long)n);
+				}
 			}
-		} else if (lane == 0) cls_out[task] = (uint8_t)((far_ring == 2 ? 1 : 0) | wide);
+		} else if (lane == 0) {
+			cls_out[task] = (uint8_t)((far_ring == 2 ? 1 : 0) | wide);
+			if (cls_stat) { atomicAdd(&cls_stat[1], (unsigned long long)n); if (wide) atomicAdd(&cls_stat[3], (unsigned long long)n); }
+		}
 	}
 	if (avg_out && n > 0) {
 		// avg_qspan_scaled of the task (chain.c:48-49), so that the DP kernel does not sweep the anchors a second time
@@ -359,14 +365,24 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 // of 8 800 anchors), and a stream whose tasks sit around the bar is cut in two halves (dense stream at a bar of 0.9: 89 ms against 76 / 80 for
 // one class).  So: when the class-1 tasks hold less than a quarter of the batch's anchors every task runs in class 0, when they hold more than
 // three quarters every task runs in class 1 (any task is correct in either); in between the split stands.
+// The same goes for the split between the compact and the 32-bit x / q ring (they run side by side on two streams where the caller has a second one, which
+// takes the edge off: ragged mixed stream, 18 % of the anchors in tasks with the 32-bit ring, 54.6 -> 48.0 ms; but the longest tasks are the ones with the
+// 32-bit ring, and with neighbours on their CUs they last longer): when the tasks that need the 32-bit ring hold more than wide_pct % of the anchors, every
+// task takes it (ragged dense stream, 65 %: 86.2 ms split, 83.8 not; ragged asm20, 60 %: 108.2 / 106.6).
 __global__ void __launch_bounds__(256)
-chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long long *__restrict__ cls_stat)
+chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long long *__restrict__ cls_stat, int settle_ring, int wide_pct)
 {
-	const unsigned long long far = cls_stat[0], all = cls_stat[1];
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= n_tasks) return;
-	if (4 * far < all) cls[t] &= 2;                           // (bit 1, the 32-bit ring, is the task's own)
-	else if (4 * far > 3 * all) cls[t] |= 1;
+	const bool all_wide = 100 * cls_stat[3] > (unsigned long long)wide_pct * cls_stat[1];
+	const unsigned long long far = cls_stat[0], all = cls_stat[1];   // (over every task: counted among the few tasks with the 32-bit ring alone the split often stands, 47.6 -> 54.1 ms on the ragged mixed stream)
+	int c = cls[t];
+	if (all_wide) c |= 2;
+	if (settle_ring) {
+		if (4 * far < all) c &= 2;                            // (bit 1, the 32-bit ring, is the task's own)
+		else if (4 * far > 3 * all) c |= 1;
+	}
+	cls[t] = (uint8_t)c;
 }
 
 // ---------------------------------------------------------------- the reference's HW/SW prediction pass, chain.c:53-78
@@ -736,14 +752,16 @@ hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches,
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
+	const unsigned c16_bound = tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
-	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && L.far_ring == 1 ? L.d_cls_stat : (unsigned long long *)nullptr,
-	                   tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u);
+	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile ? L.d_cls_stat : (unsigned long long *)nullptr,
+	                   c16_bound);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
-	if (e == hipSuccess && tile && L.far_ring == 1 && L.d_cls && L.d_cls_stat) {
-		hipLaunchKernelGGL(chain_cls_settle, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_cls, L.d_cls_stat);
+	if (e == hipSuccess && tile && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {
+		hipLaunchKernelGGL(chain_cls_settle, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_cls, L.d_cls_stat, L.far_ring == 1 ? 1 : 0,
+		                   c16_bound != 0 ? L.wide_pct : 100);
 		e = hipGetLastError();
 		if (n_launches) ++*n_launches;
 	}

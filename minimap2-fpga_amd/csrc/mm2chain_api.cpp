@@ -407,6 +407,8 @@ int mm2c_init(int device_ordinal)
 	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
 	const char *ss = getenv("MM2C_SPLIT_STREAMS");       // 0: the instantiations of a split batch run one after the other on the caller's stream
 	if (ss) G.split_streams = atoi(ss) != 0;
+	const char *wp = getenv("MM2C_WIDE_SHARE_THRESHOLD"); // % of the anchors in tasks that need the 32-bit ring from which every task takes it
+	if (wp) G.wide_pct = std::max(0, std::min(100, atoi(wp)));
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
@@ -505,6 +507,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "far_ring_threshold") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "far_ring_threshold (tenths of a far tile per anchor) must be >= 0");
 		G.far_thr10 = value;
+		return 0;
+	}
+	if (strcmp(key, "wide_share_threshold") == 0) {
+		if (value < 0 || value > 100) return fail(MM2C_E_ARG, "wide_share_threshold is a percentage");
+		G.wide_pct = value;
 		return 0;
 	}
 	if (strcmp(key, "split_streams") == 0) {
@@ -640,7 +647,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
-	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 16);   // class per task + the two counters of chain_cls_settle
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 32);   // class per task + the four counters of chain_cls_settle
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -703,8 +710,8 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_avg_ws = pl->d_avg_ws;
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
 	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
-	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 16, st));
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring;
+	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32, st));
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of

@@ -59,7 +59,8 @@ def respan_q(rng, task, max_dq, mode):
       1: every q shifted by one large constant (the span stays: still compact, the low halves wrap)
       2: multiples of 65536 added to random anchors (differences that alias mod 2^16: must be recognised as a wide task)
       3: one anchor moved so that the span is exactly 65535 - max_dq (the last compact value);   4: one more (the first wide one)
-      5: q values spread over about 60 000 (compact for the usual max_dq, pairs with dq just below / above 2^16 - max_dq)"""
+      5: q values spread over about 60 000 (compact for the usual max_dq, pairs with dq just below / above 2^16 - max_dq)
+      6: multiples of 2^24 added to random anchors;   7: multiples of 65536 up to 2^24 (wide tasks of every size, as 2)"""
     t = np.array(task, dtype=np.uint64).reshape(-1, 2).copy()
     if t.shape[0] == 0 or mode == 0:
         return t
@@ -70,6 +71,10 @@ def respan_q(rng, task, max_dq, mode):
         q = q + int(rng.integers(1 << 16, (1 << 31) - int(q.max()) - 1))
     elif mode == 2:
         q = q + 65536 * rng.integers(0, 3, q.shape[0]) * (rng.random(q.shape[0]) < 0.3)
+    elif mode == 6:
+        q = q + (1 << 24) * rng.integers(0, 3, q.shape[0]) * (rng.random(q.shape[0]) < 0.3)
+    elif mode == 7:
+        q = q + 65536 * rng.integers(0, 250, q.shape[0]) * (rng.random(q.shape[0]) < 0.5)
     elif mode in (3, 4):
         k = int(rng.integers(0, q.shape[0]))
         q = np.minimum(q, int(q.min()) + max(bound, 0))

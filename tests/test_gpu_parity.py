@@ -179,32 +179,34 @@ def test_ring_size_classes_in_one_batch(far_ring):
     assert_same(f, p, f_ref, p_ref, off, f"far_ring={far_ring}")
 
 
-@pytest.mark.parametrize("preset,compact", [("map-ont", 1), ("map-ont", 0), ("ava-ont", 1), ("asm20", 1)])
-def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, knobs):
+@pytest.mark.parametrize("preset,compact,wide_pct", [("map-ont", 1, 100), ("map-ont", 1, 40), ("map-ont", 1, 0), ("map-ont", 0, 40), ("ava-ont", 1, 100), ("asm20", 1, 100)])
+def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, wide_pct, knobs):
     """The tile kernel keeps the LOW 16 BITS of x and q of the ring anchors (4 bytes per anchor, Lds<..., C16>): exact while max_dist_x < 2^16 and the
     task's q values span at most 65535 - max_dq; the prepass (chain_window_start) sends every other task to the instantiations with the 32-bit ring.
     One batch with tasks on both sides of that bound and at it: q shifted by large constants (low halves wrap), multiples of 65536 added to random
     anchors (differences that alias mod 2^16), a span of exactly 65535 - max_dq and one more, q spread over 60 000, tasks long enough to be cut into
-    pieces on the device (pieces inherit the class)."""
+    pieces on the device (pieces inherit the class).  wide_share_threshold: the share of the batch's anchors in tasks with the 32-bit ring from which
+    every task takes it (100: the split always stands, 0: never)."""
     from helpers import respan_q
     from mm2chain import params, synth
     P = {"map-ont": params.map_ont, "ava-ont": params.ava_ont, "asm20": params.asm20}[preset]()
     max_dq = min(P.max_dist_x, P.max_dist_y)
     rng = np.random.default_rng(77)
     knobs("compact_ring", compact)
+    knobs("wide_share_threshold", wide_pct)
     knobs("plan_cut_min", 6000)
     tasks = []
     for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("mixed", 9000, 300000), ("colinear", 2500, None), ("dense", 7000, 30000),
                                           ("mixed", 700, None), ("sparse", 500, None), ("mixed", 1, None), ("dense", 1500, 3000)]):
         base = synth.make_stream(prof, 1, n, seed=880 + k, locus=locus)[1].numpy().view(np.uint64)
-        for mode in ((0, 1, 2, 3, 4, 5) if n <= 4000 else (0, 2, 5)):
+        for mode in ((0, 1, 2, 3, 4, 5, 6, 7) if n <= 4000 else (0, 2, 5, 7)):
             tasks.append(respan_q(rng, base, max_dq, mode))
     a = np.concatenate(tasks)
     off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
     f_ref, p_ref = oracle_batch(P, off, a)
     v = []
     f, p = gpu_batch(P, off, a, variant=v)
-    assert_same(f, p, f_ref, p_ref, off, f"{preset}, compact_ring={compact}: {v[0]}")
+    assert_same(f, p, f_ref, p_ref, off, f"{preset}, compact_ring={compact}, wide_share_threshold={wide_pct}: {v[0]}")
     assert f"compact={compact}" in v[0] and "loop=asm" in v[0], v
 
 
@@ -731,7 +733,7 @@ def knobs():
     """tuning knobs a test changes, put back afterwards (results never depend on them; the instantiation that runs does)"""
     import mm2chain
     yield mm2chain.tune
-    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("compact_ring", 1),
+    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
                      ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256)):
         mm2chain.tune(key, val)
 

@@ -32,6 +32,8 @@ for r in range(rounds):
                            n_segs=n_segs)
     mm2chain.tune("far_ring", int(rng.choice([1, 1, 2, 0])))   # ring-size classes of the tile kernel: chosen per task, all long, all short
     mm2chain.tune("compact_ring", int(rng.choice([1, 1, 1, 0])))   # the compact x / q ring for the tasks whose q values allow it, or never
+    mm2chain.tune("wide_share_threshold", int(rng.choice([100, 100, 40, 0])))   # ... and the share of anchors in 32-bit-ring tasks from which every task takes that ring
+    mm2chain.tune("split_streams", int(rng.choice([1, 1, 0])))
     mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 4, 4, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
@@ -46,7 +48,7 @@ for r in range(rounds):
             _, a = synth.make_stream(prof, 1, int(rng.integers(1, 3000)), seed=int(rng.integers(0, 1 << 30)), q_span=int(rng.choice([15, 19])),
                                      locus=int(rng.choice([3000, 20000, 100000])) if prof != "sparse" else None)
             tasks.append(a.numpy().view(np.uint64))
-    tasks = [respan_q(rng, t, min(P.max_dist_x, P.max_dist_y), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))) for t in tasks]   # corners of the compact ring's bound on q
+    tasks = [respan_q(rng, t, min(P.max_dist_x, P.max_dist_y), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7]))) for t in tasks]   # corners of the compact ring's bound on q
     a = np.concatenate(tasks); off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
     f_ref, p_ref = oracle_batch(P, off, a)
     f, p = gpu_batch(P, off, a)
@@ -55,5 +57,5 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1)
+mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
