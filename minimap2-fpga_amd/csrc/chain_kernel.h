@@ -7,6 +7,7 @@
 namespace mm2c {
 
 enum { KF_IGNORE_SEG = 0x1, KF_FORCE_GENERAL = 0x2 };
+constexpr int CLS_STAT_SLOTS = 64;   // sets of class counters the tasks of a batch spread their atomic additions over (chain_window_start -> chain_cls_settle)
 
 // scalars of one mm_chain_dp call (mmpriv.h:65), passed by value to the kernel
 struct KParams {
@@ -45,7 +46,7 @@ struct LaunchArgs {
 	hipStream_t side = nullptr; // with ev_fork / ev_join: when the batch is split over the 32-bit and the compact instantiations, the 32-bit ones run on this stream
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // beside the compact one (two launches one after the other each end with the GPU part empty)
 	int compact = 1;            // 0: never the compact x / q ring (mm2c_tune("compact_ring", 0); the parity tests run both)
-	unsigned long long *d_cls_stat = nullptr;   // four counters, zero on entry (chain_cls_settle), or nullptr
+	unsigned long long *d_cls_stat = nullptr;   // CLS_STAT_SLOTS sets of four counters, zero on entry (chain_cls_settle), or nullptr
 	int wide_pct = 40;          // when the tasks that need the 32-bit x / q ring hold more than this share of the batch's anchors, every task takes it
 	int far_thr10 = 7;          // far_ring 1: a task takes the long ring when it expects more than far_thr10 / 10 tiles beyond the short ring per anchor
 	int far_ring = 0;           // 0: one ring size; 1: tasks whose scans are expected to leave the 448-anchor ring get the long ring; 2: every task gets it

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256)
 chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
                    float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
-                   unsigned long long *__restrict__ cls_stat /* anchors of [class-1 tasks, all tasks, -, tasks with the 32-bit ring], or nullptr */,
+                   unsigned long long *__restrict__ cls_stat /* CLS_STAT_SLOTS sets of [anchors of class-1 tasks, of all tasks, -, of tasks with the 32-bit ring], or nullptr */,
                    unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */)
 {
 	const int lane = threadIdx.x;
@@ -341,13 +341,14 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 				const int c = (n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
 				cls_out[task] = (uint8_t)(c | wide);
 				if (cls_stat) {
-					atomicAdd(&cls_stat[1], (unsigned long long)n); if (c) atomicAdd(&cls_stat[0], (unsigned long long)n);
-					if (wide) atomicAdd(&cls_stat[3], (unsigned long long)n);
+					unsigned long long *cs = cls_stat + 4 * (task & (CLS_STAT_SLOTS - 1));   // 64 sets of counters: 65 536 tasks adding to ONE set cost the dense stream's prepass 0.6 ms
+					atomicAdd(&cs[1], (unsigned long long)n); if (c) atomicAdd(&cs[0], (unsigned long long)n);
+					if (wide) atomicAdd(&cs[3], (unsigned long long)n);
 				}
 			}
 		} else if (lane == 0) {
 			cls_out[task] = (uint8_t)((far_ring == 2 ? 1 : 0) | wide);
-			if (cls_stat) { atomicAdd(&cls_stat[1], (unsigned long long)n); if (wide) atomicAdd(&cls_stat[3], (unsigned long long)n); }
+			if (cls_stat) { unsigned long long *cs = cls_stat + 4 * (task & (CLS_STAT_SLOTS - 1)); atomicAdd(&cs[1], (unsigned long long)n); if (wide) atomicAdd(&cs[3], (unsigned long long)n); }
 		}
 	}
 	if (avg_out && n > 0) {
@@ -372,10 +373,15 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 __global__ void __launch_bounds__(256)
 chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long long *__restrict__ cls_stat, int settle_ring, int wide_pct)
 {
+	__shared__ unsigned long long s_tot[4];
+	if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
+	__syncthreads();
+	if (threadIdx.x < 4 * CLS_STAT_SLOTS) atomicAdd(&s_tot[threadIdx.x & 3], cls_stat[threadIdx.x]);
+	__syncthreads();
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= n_tasks) return;
-	const bool all_wide = 100 * cls_stat[3] > (unsigned long long)wide_pct * cls_stat[1];
-	const unsigned long long far = cls_stat[0], all = cls_stat[1];   // (over every task: counted among the few tasks with the 32-bit ring alone the split often stands, 47.6 -> 54.1 ms on the ragged mixed stream)
+	const bool all_wide = 100 * s_tot[3] > (unsigned long long)wide_pct * s_tot[1];
+	const unsigned long long far = s_tot[0], all = s_tot[1];   // (over every task: counted among the few tasks with the 32-bit ring alone the split often stands, 47.6 -> 54.1 ms on the ragged mixed stream)
 	int c = cls[t];
 	if (all_wide) c |= 2;
 	if (settle_ring) {

@@ -647,7 +647,7 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_t, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
-	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 32);   // class per task + the four counters of chain_cls_settle
+	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 32 * mm2c::CLS_STAT_SLOTS);   // class per task + the counter sets of chain_cls_settle
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -710,7 +710,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_avg_ws = pl->d_avg_ws;
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
 	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
-	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32, st));
+	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32 * mm2c::CLS_STAT_SLOTS, st));
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
