@@ -862,7 +862,7 @@ MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_c, true, true, MM2C_RING_C, MM2C_SCORE
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
 // C16: the compact x / q ring (Lds<>), for the variants with the hand-written loop; the launcher picks it per task (cls bit 1 clear)
 template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
-__global__ void __launch_bounds__(64, (Lds<NX, NF, GEN, TAB, C16>::BYTES <= 6144 ? 7 : 1))   // waves per SIMD the LDS leaves room for: at most 72 VGPRs then (the 16-tile compact ring came out at 73)
+__global__ void __launch_bounds__(64, (C16 && Lds<NX, NF, GEN, TAB, C16>::BYTES <= 6144 ? 7 : 1))   // the compact ring leaves room for 7 waves per SIMD: at most 72 VGPRs then (it came out at 73)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,

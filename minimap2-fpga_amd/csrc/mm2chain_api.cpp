@@ -406,7 +406,7 @@ int mm2c_init(int device_ordinal)
 	const char *fr = getenv("MM2C_FAR_RING");            // 0: one LDS ring size for every task; 2: the long ring for every task (tests)
 	if (fr) G.far_ring = std::max(0, std::min(2, atoi(fr)));
 	const char *ss = getenv("MM2C_SPLIT_STREAMS");       // 0: the instantiations of a split batch run one after the other on the caller's stream
-	if (ss) G.split_streams = atoi(ss) != 0;
+	if (ss) G.split_streams = std::max(0, std::min(2, atoi(ss)));
 	const char *wp = getenv("MM2C_WIDE_SHARE_THRESHOLD"); // % of the anchors in tasks that need the 32-bit ring from which every task takes it
 	if (wp) G.wide_pct = std::max(0, std::min(100, atoi(wp)));
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
@@ -515,7 +515,7 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	if (strcmp(key, "split_streams") == 0) {
-		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "split_streams must be 0 or 1");
+		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "split_streams must be 0, 1 (batches of mixed task sizes) or 2 (every batch)");
 		G.split_streams = value;
 		return 0;
 	}
@@ -739,9 +739,14 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 			L.cut = pl->cut;
 		}
 	}
-	if (G.split_streams && G.compact_ring && G.ring_class >= 3) {
+	// Two streams for a batch that is split between the compact and the 32-bit instantiations (chain_kernel.hip, launch_tile_one).  Which tasks take which is
+	// decided on the device (the span of their q values), so the host goes by what it knows, the task sizes: a batch of equal-sized tasks is taken to be of one
+	// kind and runs on the caller's stream alone -- beside a kernel that has all the tasks, the other one's workgroups (one per task, each returning at once) only
+	// take slots away from it: 25.8 -> 26.5 ms on the colinear stream, 35.1 -> 36.8 on ava-ont colinear, whose device-side cut sizes the grid for 1.3 million pieces.
+	const bool mixed_sizes = !pl->sizes_desc.empty() && (int64_t)pl->sizes_desc[0] * 4 > (int64_t)pl->sizes_desc[pl->sizes_desc.size() / 2] * 5;
+	if (G.split_streams && G.compact_ring && G.ring_class >= 3 && (mixed_sizes || G.split_streams > 1)) {
 		if (pl->aux.device < 0) HIP_TRY(aux_acquire(pl->device, &pl->aux));
-		L.side = pl->aux.aux[2]; L.ev_fork = pl->aux.fork[0]; L.ev_join = pl->aux.fork[1];   // (aux[2]: the helper stream of middle priority)
+		L.side = pl->aux.aux[0]; L.ev_fork = pl->aux.fork[0]; L.ev_join = pl->aux.fork[1];   // (aux[0]: the helper stream of highest priority -- the 32-bit instantiations hold the longest tasks)
 	}
 	HIP_TRY(hipEventRecord(pl->ev_pre, st));
 	int nl = 0;

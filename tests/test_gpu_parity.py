@@ -194,6 +194,7 @@ def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, w
     rng = np.random.default_rng(77)
     knobs("compact_ring", compact)
     knobs("wide_share_threshold", wide_pct)
+    knobs("split_streams", 2 if wide_pct == 100 else 1 if wide_pct == 40 else 0)   # the two kinds side by side on two streams: always / for batches of mixed task sizes / never
     knobs("plan_cut_min", 6000)
     tasks = []
     for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("mixed", 9000, 300000), ("colinear", 2500, None), ("dense", 7000, 30000),

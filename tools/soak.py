@@ -33,7 +33,7 @@ for r in range(rounds):
     mm2chain.tune("far_ring", int(rng.choice([1, 1, 2, 0])))   # ring-size classes of the tile kernel: chosen per task, all long, all short
     mm2chain.tune("compact_ring", int(rng.choice([1, 1, 1, 0])))   # the compact x / q ring for the tasks whose q values allow it, or never
     mm2chain.tune("wide_share_threshold", int(rng.choice([100, 100, 40, 0])))   # ... and the share of anchors in 32-bit-ring tasks from which every task takes that ring
-    mm2chain.tune("split_streams", int(rng.choice([1, 1, 0])))
+    mm2chain.tune("split_streams", int(rng.choice([1, 2, 2, 0])))
     mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 4, 4, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
