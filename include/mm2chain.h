@@ -76,7 +76,11 @@ int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_by
  * 256/512/1024 anchors of LDS ring per task; "far_ring" 1 = plans give tasks whose scans are expected to go far beyond the 448-anchor
  * LDS ring of the tile kernel an instantiation with a ring twice as long (chosen per task by the prepass; default; env MM2C_FAR_RING), 0 = never,
  * 2 = every task; "epi_fused" 1 = the device epilogue keeps the per-anchor state of tasks of up to
- * 7 680 anchors in LDS (default; env MM2C_EPI_FUSED), 0 = in HBM for every task; "force_tab" 1 = the tile kernel reads the gap
+ * 7 680 anchors in LDS (default; env MM2C_EPI_FUSED), 0 = in HBM for every task; "compact_ring" 1 = tasks whose query positions span at most 65535 - min(max_dist_x, max_dist_y) (reads of up to about 55-60 kb) run
+ * an instantiation of the tile kernel whose LDS ring keeps the low 16 bits of x and q only (16 tiles of look-back in the LDS of 8; default; env MM2C_COMPACT_RING),
+ * 0 = never; "split_streams" 1 = a plan whose tasks differ in size runs the instantiations its batch is split over side by side on two streams (default;
+ * env MM2C_SPLIT_STREAMS), 2 = every plan, 0 = never; "wide_share_threshold" = when the tasks that need the 32-bit ring hold more than this percentage of the
+ * batch's anchors every task takes it (default 40); "force_tab" 1 = the tile kernel reads the gap
  * cost from its LDS table also when gap_scale is 1 (default 0: computed; tests); "seg_min" = shortest piece (anchors) a task is cut into at
  * empty-window positions (default 256, 0 = never cut); "plan_cut" 0/1 = plans cut their tasks of at least "plan_cut_min" anchors (default
  * 8192) into such pieces on the device before the DP (default 1); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for
