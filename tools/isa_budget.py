@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "minimap2-fpga_amd/csrc/chain_dp_tile.h")).read()
 
-TOKEN = re.compile(r'"((?:[^"\\]|\\.)*)"|(MM2C_[A-Z0-9_]+)(\(([^()]*)\))?|\b(SCORE|ADDF|SEG_LK|SEG_HF|SEG_TAIL|SEG_END|R|CTRL|X|Q)\b')
+TOKEN = re.compile(r'"((?:[^"\\]|\\.)*)"|(MM2C_[A-Z0-9_]+)(\(([^()]*)\))?|\b(SCORE|ADDF|SEG_RD|SEG_LK|SEG_HF|SEG_TAIL|SEG_END|SEG_DONE|XQ1|NEXT_XQ|RFILTER|OLDADDR|BACK|OWNFILTER|FARFILTER|RDXQ|R|CTRL|X|Q|D|S0SEL|S1SEL|V)\b')
 
 
 def logical_defines(src):
@@ -80,13 +80,16 @@ def classify(ins):
     return "other"
 
 
-def blocks(tab, far=False):
+def blocks(tab, far=False, wide=False):
     params, body = DEFS["MM2C_SCAN_TILE_ASM"]
     body = body[body.index("asm volatile("):]
-    body = body[:body.index(": [best]")].replace("SEG_END(SCORE)", "SEG_END")
+    body = body[:body.index(": [best]")].replace("SEG_END(SCORE, FARFILTER)", "SEG_END").replace("MM2C_READ_ANCHOR(SEG_RD, RDXQ)", "MM2C_READ_ANCHOR")
     v = "FAR" if far else "LEAN"
+    r = "_W" if wide else "_C"                       # the 32-bit x / q ring or the compact one (the default of the library where it applies)
     env = {"SCORE": "MM2C_SCORE_TAB" if tab else "MM2C_SCORE_CMP", "ADDF": "MM2C_ADDF_TAB" if tab else "MM2C_ADDF_CMP",
-           "SEG_LK": "MM2C_LK_" + v, "SEG_HF": "MM2C_HF_" + v, "SEG_TAIL": "MM2C_TAIL_" + v, "SEG_END": "MM2C_END_" + v}
+           "SEG_RD": "MM2C_RD_" + v, "SEG_LK": "MM2C_LK_" + v, "SEG_HF": "MM2C_HF_" + v, "SEG_TAIL": "MM2C_TAIL_" + v, "SEG_END": "MM2C_END_" + v, "SEG_DONE": '""',
+           "XQ1": "MM2C_XQ1" + r, "NEXT_XQ": "MM2C_NEXT_XQ" + r, "RFILTER": "MM2C_RFILTER" + r, "OLDADDR": "MM2C_OLDADDR" + r, "BACK": "MM2C_BACK" + r,
+           "OWNFILTER": "MM2C_OWNFILTER" + r, "FARFILTER": "MM2C_FARFILTER" + r, "RDXQ": "MM2C_RDXQ" + r}
     text = expand(body, env)
     out, cur = [], ("entry", [])
     for line in text.split("\n"):
@@ -126,10 +129,10 @@ def cut(instrs, until=None, after=None):
 
 
 if __name__ == "__main__":
-    tab, far = "--tab" in sys.argv, "--far" in sys.argv
-    B = dict(blocks(tab, far))
-    order = [n for n, _ in blocks(tab, far)]
-    print(f"# Instruction budget of the hand-written anchor loop (`scan_tile_asm_{'tab' if tab else 'cmp'}{'_far' if far else ''}`), from `tools/isa_budget.py`\n")
+    tab, far, wide = "--tab" in sys.argv, "--far" in sys.argv, "--wide" in sys.argv
+    B = dict(blocks(tab, far, wide))
+    order = [n for n, _ in blocks(tab, far, wide)]
+    print(f"# Instruction budget of the hand-written anchor loop (`scan_tile_asm_{'tab' if tab else 'cmp'}{'_far' if far else ''}{'' if wide else '_c'}`: {'32-bit' if wide else 'compact'} x / q ring), from `tools/isa_budget.py`\n")
     print("Classes as measured by `tools/ubench/issue_rate.hip` (`profiles/r2_issue_rate.md`): plain VALU ≈0.84 per SIMD and ns; VALU that involves the scalar side")
     print("(`v_cmp`, `v_readlane`/`v_writelane`, DPP, `v_cndmask` with an SGPR mask, `v_mbcnt`) and SALU ≈0.55; `ds_read` 0.29.\n")
     print("## Blocks between labels (straight-line instruction counts)\n")
