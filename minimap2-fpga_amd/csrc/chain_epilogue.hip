@@ -827,29 +827,33 @@ void epi_fused(EpiArgs A, int n_above)
 // ---- exclusive scans of the per-task chain / anchor counts -> compact output offsets ---------------------------------------
 __global__ __launch_bounds__(1024) void epi_offsets(EpiArgs A)
 {
-	// one workgroup: 1 024 tasks at a time, coalesced; scan inside the waves by shuffles, the sixteen wave totals through LDS, a running carry
-	// (eight times as many tasks per step, with all loads in flight together, took the same 0.2 ms)
+	// one workgroup per 1 024 tasks: it first adds up the counts of all the tasks before its own (coalesced, the loads of a step in flight together; the last
+	// workgroup reads 64 K counts), then scans its own inside the waves by shuffles and across them through LDS.  (One workgroup walking over all the tasks
+	// with a running carry took 0.19 ms for 65 536 tasks, whatever it did per step: 64 dependent steps.)
 	__shared__ int64_t s_u[16], s_b[16];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int64_t nt = A.n_tasks;
+	const int64_t nt = A.n_tasks, t0 = (int64_t)blockIdx.x * 1024;
+	int64_t pre_u = 0, pre_b = 0;
+	for (int64_t t = tid; t < t0; t += 1024) { pre_u += A.cnt_u[t]; pre_b += A.cnt_b[t]; }
+	for (int o = 32; o > 0; o >>= 1) { pre_u += __shfl_xor(pre_u, o); pre_b += __shfl_xor(pre_b, o); }
+	if (lane == 0) { s_u[wave] = pre_u; s_b[wave] = pre_b; }
+	__syncthreads();
 	int64_t carry_u = 0, carry_b = 0;
-	for (int64_t t0 = 0; t0 < nt; t0 += 1024) {
-		const int64_t t = t0 + tid;
-		const int64_t cu = t < nt ? A.cnt_u[t] : 0, cb = t < nt ? A.cnt_b[t] : 0;
-		int64_t iu = cu, ib = cb;                                                 // inclusive scan inside the wave
-		for (int o = 1; o < 64; o <<= 1) {
-			const int64_t yu = __shfl_up(iu, o), yb = __shfl_up(ib, o);
-			if (lane >= o) { iu += yu; ib += yb; }
-		}
-		if (lane == 63) { s_u[wave] = iu; s_b[wave] = ib; }
-		__syncthreads();
-		int64_t wu = 0, wb = 0, tot_u = 0, tot_b = 0;
-		for (int w = 0; w < 16; ++w) { const int64_t xu = s_u[w], xb = s_b[w]; if (w < wave) { wu += xu; wb += xb; } tot_u += xu; tot_b += xb; }
-		if (t < nt) { A.u_off[t] = carry_u + wu + iu - cu; A.b_off[t] = carry_b + wb + ib - cb; }
-		carry_u += tot_u; carry_b += tot_b;
-		__syncthreads();
+	for (int w = 0; w < 16; ++w) { carry_u += s_u[w]; carry_b += s_b[w]; }
+	__syncthreads();
+	const int64_t t = t0 + tid;
+	const int64_t cu = t < nt ? A.cnt_u[t] : 0, cb = t < nt ? A.cnt_b[t] : 0;
+	int64_t iu = cu, ib = cb;                                                    // inclusive scan inside the wave
+	for (int o = 1; o < 64; o <<= 1) {
+		const int64_t yu = __shfl_up(iu, o), yb = __shfl_up(ib, o);
+		if (lane >= o) { iu += yu; ib += yb; }
 	}
-	if (tid == 0) { A.u_off[nt] = carry_u; A.b_off[nt] = carry_b; }
+	if (lane == 63) { s_u[wave] = iu; s_b[wave] = ib; }
+	__syncthreads();
+	int64_t wu = 0, wb = 0, tot_u = 0, tot_b = 0;
+	for (int w = 0; w < 16; ++w) { const int64_t xu = s_u[w], xb = s_b[w]; if (w < wave) { wu += xu; wb += xb; } tot_u += xu; tot_b += xb; }
+	if (t < nt) { A.u_off[t] = carry_u + wu + iu - cu; A.b_off[t] = carry_b + wb + ib - cb; }
+	if (tid == 0 && t0 + 1024 >= nt) { A.u_off[nt] = carry_u + tot_u; A.b_off[nt] = carry_b + tot_b; }
 }
 
 // ---- kernel T: tasks with more than 64 chains and equal first-x values: the order radix_sort_128x leaves (chain.c:411) ----
@@ -879,6 +883,7 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 		run += __shfl(incl, 63);
 	}
 	if (run == 0) return;                                                        // distinct keys: the order is unique
+	if (A.debug_phases == 21) return;
 	__syncthreads();
 	for (int i = lane; i < nk; i += 64) rank_x[ord[i]] = sx[i];                  // back to rank order, as chain.c:407-410 fills w[]
 	__syncthreads();
@@ -889,6 +894,7 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 		uint8_t *g_dg = (uint8_t *)(stack + 2 * (nk / 64 + 2));
 		replay_passes<uint32_t, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, nullptr, lane, s_cur, s_lo, s_hi, &s_sp);
 	}
+	if (A.debug_phases == 22) return;
 	__syncthreads();
 	for (int i = lane; i < nk; i += 64) sx[i] = rank_x[ids[i]];                  // keys of the replayed arrangement
 	__syncthreads();
@@ -1020,7 +1026,7 @@ hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launch
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		nl += 2;
 	}
-	hipLaunchKernelGGL(epi_offsets, dim3(1), dim3(1024), 0, st, A);
+	hipLaunchKernelGGL(epi_offsets, dim3((nt + 1023) / 1024), dim3(1024), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(epi_tiesort, dim3(nt), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
