@@ -409,3 +409,75 @@ int64_t mm2o_collect_seed_hits_flags(int64_t n_m, const mm2o_match_t *m, const u
 	sort_128x(a, a + n_a);                                                       /* map.c:245 */
 	return n_a;
 }
+
+/* ---- collect_seed_hits_heap (map.c:149-213; selected by MM_F_HEAP_SORT: `--heap-sort`, main.c:245, and -x sr, options.c:125) ----
+ * The hit lists of the matches (each ascending) are merged through a binary heap keyed on the hit alone (heap_lt, map.c:80: a.x > b.x,
+ * a min-heap without a tie rule; ks_heapmake / ks_heapdown of ksort.h:43-60), forward-strand anchors are written from the front, reverse-strand
+ * ones from the back and turned around afterwards (map.c:201-211).  The result is ascending in x like the radix-sorted list; the two differ in
+ * the order among anchors with EQUAL x (one reference position hit by several query minimizers), which here is whatever order the heap pops
+ * equal keys in -- so the heap itself is restated, operation by operation. */
+typedef struct { uint64_t x, y; } heap_ent_t;                                  /* x = the hit, y = match index << 32 | position in its list */
+
+static void heap_down(size_t i, size_t n, heap_ent_t *l)                       /* ksort.h:43-53 with heap_lt */
+{
+	size_t k = i;
+	heap_ent_t tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && l[k].x > l[k + 1].x) ++k;
+		if (l[k].x > tmp.x) break;
+		l[i] = l[k]; i = k;
+	}
+	l[i] = tmp;
+}
+
+int64_t mm2o_collect_seed_hits_heap(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, int32_t flag,
+                                    const int32_t *ref_rank, const int32_t *ref_len, int32_t q_lo, int32_t q_eq, mm2o_anchor_t *a)
+{
+	int64_t i, j, n_a = 0, n_for = 0, n_rev = 0;
+	size_t heap_size = 0;
+	heap_ent_t *heap = (heap_ent_t *)malloc((size_t)(n_m > 0 ? n_m : 1) * sizeof(heap_ent_t));
+	for (i = 0; i < n_m; ++i) n_a += m[i].n;
+	for (i = 0; i < n_m; ++i)                                                   /* map.c:162-168 */
+		if (m[i].n > 0) { heap[heap_size].x = hits[m[i].cr_off]; heap[heap_size].y = (uint64_t)i << 32; ++heap_size; }
+	if (heap_size > 1) { size_t k; for (k = (heap_size >> 1) - 1; k != (size_t)(-1); --k) heap_down(k, heap_size, heap); }   /* ks_heapmake, ksort.h:54-59 */
+	while (heap_size > 0) {                                                     /* map.c:170-198 */
+		const mm2o_match_t *q = &m[heap->y >> 32];
+		const uint64_t r = heap->x;
+		const int32_t rpos = (uint32_t)r >> 1;
+		int is_self;
+		if (!skip_seed(flag, r, q, qlen, ref_rank, ref_len, q_lo, q_eq, &is_self)) {
+			mm2o_anchor_t *p;
+			if ((r & 1) == (q->q_pos & 1)) {
+				p = &a[n_for++];
+				p->x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
+			} else {
+				p = &a[n_a - (++n_rev)];
+				p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - (int32_t)((q->q_pos >> 1) + 1 - q->q_span) - 1);
+			}
+			p->y |= (uint64_t)(q->seg_tandem >> 1) << 48;
+			if (q->seg_tandem & 1) p->y |= 1ULL << 42;
+			if (is_self) p->y |= 1ULL << 43;
+		}
+		if ((uint32_t)heap->y < q->n - 1) {                                     /* the match's next hit takes the root */
+			++heap[0].y;
+			heap[0].x = hits[m[heap[0].y >> 32].cr_off + (uint32_t)heap[0].y];
+		} else {
+			heap[0] = heap[heap_size - 1];
+			--heap_size;
+		}
+		if (heap_size > 0) heap_down(0, heap_size, heap);
+	}
+	free(heap);
+	for (j = 0; j < n_rev >> 1; ++j) {                                          /* map.c:201-206 */
+		const mm2o_anchor_t t = a[n_a - 1 - j];
+		a[n_a - 1 - j] = a[n_a - (n_rev - j)];
+		a[n_a - (n_rev - j)] = t;
+	}
+	if (n_a > n_for + n_rev) {                                                  /* map.c:207-210 */
+		memmove(a + n_for, a + n_a - n_rev, (size_t)n_rev * sizeof(mm2o_anchor_t));
+		n_a = n_for + n_rev;
+	}
+	return n_a;
+}

@@ -96,6 +96,10 @@ int64_t mm2o_collect_seed_hits(int64_t n_m, const mm2o_match_t *m, const uint64_
 #define MM2O_F_REV_ONLY 0x200000
 int64_t mm2o_collect_seed_hits_flags(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, int32_t flag,
                                      const int32_t *ref_rank, const int32_t *ref_len, int32_t q_lo, int32_t q_eq, mm2o_anchor_t *a);
+/* collect_seed_hits_heap (map.c:149-213; MM_F_HEAP_SORT: --heap-sort, -x sr): same arguments and result, the order among anchors with equal x is the
+ * one the reference's binary heap pops them in */
+int64_t mm2o_collect_seed_hits_heap(int64_t n_m, const mm2o_match_t *m, const uint64_t *hits, int32_t qlen, int32_t flag,
+                                    const int32_t *ref_rank, const int32_t *ref_len, int32_t q_lo, int32_t q_eq, mm2o_anchor_t *a);
 
 #ifdef __cplusplus
 }

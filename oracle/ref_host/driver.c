@@ -66,6 +66,7 @@ int main(int argc, char *argv[])
 		mo.flag |= MM_F_ALL_CHAINS | MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_NO_LJOIN;
 		mo.min_chain_score = 100; mo.pri_ratio = 0.0f; mo.max_gap = 10000; mo.max_chain_skip = 25; mo.bw = 2000;
 	}
+	if (getenv("MM2_HEAP_SORT")) mo.flag |= MM_F_HEAP_SORT;   /* main.c:245 --heap-sort=yes (collect_seed_hits_heap, map.c:149-213) */
 	io.flag |= MM_I_NO_SEQ;                              /* main.c:286-287: no -d, no CIGAR */
 	r = mm_idx_reader_open(argv[1], &io, 0);
 	if (!r) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }

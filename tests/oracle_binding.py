@@ -59,6 +59,8 @@ def load():
         lib.mm2o_collect_seed_hits.argtypes = [C.c_int64, vp, vp, C.c_int32, vp]
         lib.mm2o_collect_seed_hits_flags.restype = C.c_int64
         lib.mm2o_collect_seed_hits_flags.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]
+        lib.mm2o_collect_seed_hits_heap.restype = C.c_int64
+        lib.mm2o_collect_seed_hits_heap.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp]
         _lib = lib
     return _lib
 
@@ -158,9 +160,10 @@ MATCH_DTYPE = np.dtype([("cr_off", "<i8"), ("n", "<u4"), ("q_pos", "<u4"), ("q_s
 F_NO_DIAG, F_NO_DUAL, F_FOR_ONLY, F_REV_ONLY = 0x001, 0x002, 0x100000, 0x200000      # minimap.h:8-9,28-29
 
 
-def collect_seed_hits(matches, hits, qlen, flag=0, ref_rank=None, ref_len=None, q_lo=0, q_eq=0):
+def collect_seed_hits(matches, hits, qlen, flag=0, ref_rank=None, ref_len=None, q_lo=0, q_eq=0, heap=False):
     """collect_seed_hits (map.c:215-247) of one read: matches (MATCH_DTYPE), hit pool (uint64) -> sorted anchors uint64 [n, 2].
-    flag / ref_rank / ref_len / q_lo / q_eq: skip_seed (map.c:122-147), names carried by ranks (oracle/chain_oracle.c)"""
+    flag / ref_rank / ref_len / q_lo / q_eq: skip_seed (map.c:122-147), names carried by ranks (oracle/chain_oracle.c);
+    heap: collect_seed_hits_heap (map.c:149-213, MM_F_HEAP_SORT) instead -- the same anchors, another order among equal x"""
     m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
     h = np.ascontiguousarray(hits, dtype=np.uint64)
     if m.size and int((m["cr_off"] + m["n"]).max()) > h.size:
@@ -170,6 +173,7 @@ def collect_seed_hits(matches, hits, qlen, flag=0, ref_rank=None, ref_len=None, 
     rl = np.ascontiguousarray(ref_len, dtype=np.int32) if ref_len is not None else None
     if rr is not None and h.size and int((h >> np.uint64(32)).max()) >= rr.size:
         raise ValueError("a hit names a reference sequence beyond ref_rank")
-    n = load().mm2o_collect_seed_hits_flags(m.size, _ptr(m), _ptr(h), int(qlen), int(flag), _ptr(rr) if rr is not None else None,
+    fn = load().mm2o_collect_seed_hits_heap if heap else load().mm2o_collect_seed_hits_flags
+    n = fn(m.size, _ptr(m), _ptr(h), int(qlen), int(flag), _ptr(rr) if rr is not None else None,
                                             _ptr(rl) if rl is not None else None, int(q_lo), int(q_eq), _ptr(a))
     return a[:n]

@@ -303,6 +303,28 @@ def test_seed_hits_oracle_with_skip_seed_equals_the_reference_all_vs_all_anchor_
     assert n_self > 20 and n_drop > 30000
 
 
+def test_seed_hits_heap_oracle_equals_the_reference_anchor_lists():
+    """mm2o_collect_seed_hits_heap (collect_seed_hits_heap, map.c:149-213, with the binary heap of ksort.h:43-60 restated operation by operation)
+    against the anchor lists the reference's own map.o produced for the reads of ref_seed_hits.npz under MM_F_HEAP_SORT (--heap-sort=yes;
+    tests/golden/make_ref_heap_fixtures.py): the same anchors as the radix-sorted lists, in four reads at other places among equal x; and under
+    ava-ont flags the heap form keeps exactly the anchors the radix form keeps"""
+    d, h = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz")), np.load(os.path.join(GOLDEN, "ref_seed_hits_heap.npz"))
+    assert int(h["n_reads"]) == int(d["n_reads"])
+    n_moved = 0
+    for k in range(int(d["n_reads"])):
+        a = ob.collect_seed_hits(d[f"r{k}_matches"], d[f"r{k}_hits"], int(d[f"r{k}_qlen"]), heap=True)
+        ref = h[f"r{k}_anchors_heap"]
+        assert np.array_equal(a, ref), f"read {k}: heap-merged anchors differ from the reference's"
+        n_moved += int((ref != d[f"r{k}_anchors"]).any(axis=1).sum())
+    assert n_moved > 2000
+    v = np.load(os.path.join(GOLDEN, "ref_seed_hits_ava.npz"))
+    for k in range(int(v["n_reads"])):
+        args = (v[f"r{k}_matches"], v[f"r{k}_hits"], int(v[f"r{k}_qlen"]), int(v["flag"]), v["ref_rank"], v["ref_len"], int(v[f"r{k}_qlo"]), int(v[f"r{k}_qeq"]))
+        a, b = ob.collect_seed_hits(*args, heap=True), ob.collect_seed_hits(*args)
+        key = lambda t: np.sort(np.ascontiguousarray(t).view([("x", "<u8"), ("y", "<u8")]).ravel(), order=("x", "y"))
+        assert a.shape == b.shape and np.array_equal(key(a), key(b)) and np.array_equal(a[:, 0], b[:, 0]), k
+
+
 def test_matches_from_anchors_expand_back_into_the_same_anchors():
     """synth.matches_from_anchors (the seed-hit input of bench.py and tools/seed_probe.py): collect_seed_hits of the derived matches gives the
     anchors of the stream again (as a multiset, sorted by x; the order among equal x is the sort's)"""
