@@ -48,6 +48,7 @@ struct SeedArgs {
 	// names as ranks: per reference sequence the rank of its name and its length, per read q_lo / q_eq (include/mm2chain.h)
 	int32_t skip_flag = 0;
 	const int32_t *d_ref_rank = nullptr, *d_ref_len = nullptr, *d_q_lo = nullptr, *d_q_eq = nullptr;
+	int32_t heap_order = 0;                      // 1: the order among equal x that collect_seed_hits_heap leaves (map.c:149-213, MM_F_HEAP_SORT) instead of radix_sort_128x's
 	int32_t *d_count = nullptr;                  // per read: anchors kept (nullptr: all, the plan's offsets are exact)
 	int64_t *d_out_off = nullptr;                // n_reads + 1: where the packed result of each read starts (written by seed_offsets)
 	const int32_t *d_qlen;

@@ -178,6 +178,13 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
 	return 0;
 }
 
+int mm2c_seedplan_set_heap_sort(mm2c_seedplan_t *pl, int on)
+{
+	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
+	pl->S.heap_order = on ? 1 : 0;
+	return 0;
+}
+
 int mm2c_seedplan_run_device_n(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches, int64_t n_matches, const uint64_t *d_hits, int64_t n_hits,
                                const int32_t *d_qlen, int64_t n_qlen, void *d_anchors, int64_t n_anchors, void *stream)
 {

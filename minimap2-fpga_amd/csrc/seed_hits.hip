@@ -50,6 +50,38 @@ __device__ __forceinline__ ReadGeom read_geom(const SeedArgs &A, int read)
 	return g;
 }
 
+// one hit of a match as an anchor (map.c:222-243 / :175-188): false when skip_seed (map.c:122-147; names as ranks, see mm2chain.h) drops it
+__device__ __forceinline__ bool hit_anchor(const SeedArgs &A, uint64_t r, uint32_t q_pos, uint32_t q_span, uint32_t segt, int qlen, int q_lo, int q_eq, ulonglong2 &a)
+{
+	const uint32_t rpos = (uint32_t)r >> 1;
+	const bool fwd = (r & 1) == (q_pos & 1);
+	bool keep = true, is_self = false;
+	if (A.skip_flag) {
+		if (A.d_ref_rank && (A.skip_flag & (0x001 | 0x002))) {
+			const int rid = (int)(r >> 32);
+			const int rr = A.d_ref_rank[rid];
+			const int cmp = rr < q_lo ? 1 : (q_eq && rr == q_lo) ? 0 : -1;
+			if ((A.skip_flag & 0x001) && cmp == 0 && A.d_ref_len[rid] == qlen) {   // MM_F_NO_DIAG
+				if (rpos == (q_pos >> 1)) keep = false;                 // the diagonal
+				if (fwd) is_self = true;
+			}
+			if ((A.skip_flag & 0x002) && cmp > 0) keep = false;         // MM_F_NO_DUAL: every pair once
+		}
+		if (fwd ? (A.skip_flag & 0x200000) : (A.skip_flag & 0x100000)) keep = false;   // MM_F_REV_ONLY / MM_F_FOR_ONLY
+	}
+	if (fwd) {                                                      // forward strand, map.c:232-234
+		a.x = (r & 0xffffffff00000000ULL) | rpos;
+		a.y = (uint64_t)q_span << 32 | q_pos >> 1;
+	} else {                                                        // reverse strand, map.c:235-238
+		a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+		a.y = (uint64_t)q_span << 32 | (uint32_t)((uint32_t)qlen - ((q_pos >> 1) + 1 - q_span) - 1);
+	}
+	a.y |= (uint64_t)(segt >> 1) << 48;                             // MM_SEED_SEG_SHIFT, map.c:239
+	if (segt & 1) a.y |= 1ULL << 42;                                // MM_SEED_TANDEM, map.c:240
+	if (is_self) a.y |= 1ULL << 43;                                 // MM_SEED_SELF, map.c:241
+	return keep;
+}
+
 // ---- kernel 1: expansion (map.c:222-243) ----------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 {
@@ -89,33 +121,7 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 				int lo = 0, hi = 63;                                            // last match of the chunk with start <= t
 				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid - 1; }
 				const uint64_t r = A.d_hits[s_cr[lo] + (t - s_start[lo])];
-				const uint32_t q_pos = s_qpos[lo], q_span = s_span[lo], segt = s_segt[lo];
-				const uint32_t rpos = (uint32_t)r >> 1;
-				const bool fwd = (r & 1) == (q_pos & 1);
-				bool is_self = false;
-				if (A.skip_flag) {                                              // skip_seed, map.c:122-147 (names as ranks, see mm2chain.h)
-					if (A.d_ref_rank && (A.skip_flag & (0x001 | 0x002))) {
-						const int rid = (int)(r >> 32);
-						const int rr = A.d_ref_rank[rid];
-						const int cmp = rr < q_lo ? 1 : (q_eq && rr == q_lo) ? 0 : -1;
-						if ((A.skip_flag & 0x001) && cmp == 0 && A.d_ref_len[rid] == qlen) {   // MM_F_NO_DIAG
-							if (rpos == (q_pos >> 1)) keep = false;                 // the diagonal
-							if (fwd) is_self = true;
-						}
-						if ((A.skip_flag & 0x002) && cmp > 0) keep = false;         // MM_F_NO_DUAL: every pair once
-					}
-					if (fwd ? (A.skip_flag & 0x200000) : (A.skip_flag & 0x100000)) keep = false;   // MM_F_REV_ONLY / MM_F_FOR_ONLY
-				}
-				if (fwd) {                                                      // forward strand, map.c:232-234
-					a.x = (r & 0xffffffff00000000ULL) | rpos;
-					a.y = (uint64_t)q_span << 32 | q_pos >> 1;
-				} else {                                                        // reverse strand, map.c:235-238
-					a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-					a.y = (uint64_t)q_span << 32 | (uint32_t)((uint32_t)qlen - ((q_pos >> 1) + 1 - q_span) - 1);
-				}
-				a.y |= (uint64_t)(segt >> 1) << 48;                             // MM_SEED_SEG_SHIFT, map.c:239
-				if (segt & 1) a.y |= 1ULL << 42;                                // MM_SEED_TANDEM, map.c:240
-				if (is_self) a.y |= 1ULL << 43;                                 // MM_SEED_SELF, map.c:241
+				keep = hit_anchor(A, r, s_qpos[lo], s_span[lo], s_segt[lo], qlen, q_lo, q_eq, a);
 			}
 			const uint64_t km = __ballot(keep);                                 // kept hits stay in hit order (the order collect_seed_hits fills a[])
 			if (keep) {
@@ -467,6 +473,67 @@ __global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
 	wave_sort_anchors(tmp, un, out, na, tid, s_cur);
 }
 
+// ---- kernel 3': the order collect_seed_hits_heap leaves (map.c:149-213; MM_F_HEAP_SORT) -----------------------------------------------------
+// That function merges the matches' hit lists through a binary heap keyed on the hit alone: the same anchors in the same ascending order of x as the
+// radix-sorted list, except among anchors with EQUAL x, which come out in whatever order the heap pops equal keys -- a function of the heap's whole
+// history, so for the reads that have such anchors (has_ties, from seed_sort) the heap is replayed operation by operation (ksort.h:43-60 with heap_lt,
+// map.c:80) by one lane, heap in LDS for up to HEAP_CAP matches (else in the read's scratch).  Forward-strand anchors are written in pop order, reverse-strand
+// ones collected in pop order and appended (what map.c:201-210 leaves).  Every other read already has the order the heap gives: it is unique.
+constexpr int HEAP_CAP = 2048;
+
+__global__ __launch_bounds__(64) void seed_heap(SeedArgs A)
+{
+	__shared__ uint64_t s_hx[HEAP_CAP];
+	__shared__ uint32_t s_hm[HEAP_CAP], s_hk[HEAP_CAP];
+	__shared__ int s_nfor, s_nrev;
+	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
+	const int lane = (int)threadIdx.x;
+	const ReadGeom g = read_geom(A, read);
+	const int64_t m0 = A.d_match_off[read];
+	const int nm = (int)(A.d_match_off[read + 1] - m0);
+	const Match *m = A.d_matches + m0;
+	const int qlen = A.d_qlen[read];
+	const int q_lo = A.d_q_lo ? A.d_q_lo[read] : 0, q_eq = A.d_q_eq ? A.d_q_eq[read] : 0;
+	ulonglong2 *out = A.d_anchors + g.o0, *rev = A.unsorted + g.a0;              // (the expansion-order copy is not needed any more)
+	// heap entries: the hit, the match, the position in the match's list
+	uint64_t *hx = s_hx; uint32_t *hm = s_hm, *hk = s_hk;
+	if (nm > HEAP_CAP) { hx = (uint64_t *)(A.scratch + g.a0); hm = (uint32_t *)(hx + nm); hk = hm + nm; }   // 16 bytes per match <= 16 bytes per anchor: matches without a hit take no room ...
+	if (lane == 0) {
+		int hs = 0;
+		if (nm > HEAP_CAP) { int live = 0; for (int i = 0; i < nm; ++i) live += m[i].n > 0; hm = (uint32_t *)(hx + live); hk = hm + live; }   // ... because the arrays are sized by the live ones
+		for (int i = 0; i < nm; ++i)                                            // map.c:162-168
+			if (m[i].n > 0) { hx[hs] = A.d_hits[m[i].cr_off]; hm[hs] = (uint32_t)i; hk[hs] = 0; ++hs; }
+		auto down = [&](int i, int n) {                                         // ks_heapdown, ksort.h:43-53, heap_lt(a, b) = a.x > b.x
+			const uint64_t tx = hx[i]; const uint32_t tm = hm[i], tk = hk[i];
+			int k = i;
+			while ((k = (k << 1) + 1) < n) {
+				if (k != n - 1 && hx[k] > hx[k + 1]) ++k;
+				if (hx[k] > tx) break;
+				hx[i] = hx[k]; hm[i] = hm[k]; hk[i] = hk[k]; i = k;
+			}
+			hx[i] = tx; hm[i] = tm; hk[i] = tk;
+		};
+		for (int i = (hs >> 1) - 1; i >= 0; --i) down(i, hs);                   // ks_heapmake, ksort.h:54-59
+		int n_for = 0, n_rev = 0;
+		while (hs > 0) {                                                        // map.c:170-198
+			const Match q = m[hm[0]];
+			ulonglong2 a;
+			if (hit_anchor(A, hx[0], q.q_pos, q.q_span, q.seg_tandem, qlen, q_lo, q_eq, a)) {
+				if ((a.x >> 63) == 0) out[n_for++] = a; else rev[n_rev++] = a;
+			}
+			if (hk[0] + 1 < q.n) { ++hk[0]; hx[0] = A.d_hits[q.cr_off + hk[0]]; }
+			else { --hs; hx[0] = hx[hs]; hm[0] = hm[hs]; hk[0] = hk[hs]; }
+			if (hs > 0) down(0, hs);
+		}
+		s_nfor = n_for; s_nrev = n_rev;
+	}
+	__syncthreads();
+	const int n_for = s_nfor, n_rev = s_nrev;
+	for (int i = lane; i < n_rev; i += 64) out[n_for + i] = rev[i];
+	if (lane == 0 && n_for + n_rev != g.na) A.status[read] = 1;                  // cannot happen: the expansion kept exactly these hits
+}
+
 } // namespace
 
 int seed_tie_lds_max() { return TIE_CAP3; }
@@ -488,6 +555,11 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	hipLaunchKernelGGL(seed_sort, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (n_launches) *n_launches += 2;
+	if (A.heap_order) {                                                          // collect_seed_hits_heap: its own order among equal x instead of the radix sort's
+		hipLaunchKernelGGL(seed_heap, dim3(nr), dim3(64), 0, st, A);
+		if (n_launches) ++*n_launches;
+		return hipGetLastError();
+	}
 	// the grid is in order of decreasing read length: each class covers a contiguous range of blocks, the others exit at once
 	const bool use[5] = { true, A.biggest > TIE_CAP0, A.biggest > TIE_CAP1, A.biggest > TIE_MW_HI, A.biggest > TIE_CAP3 };
 	if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;                 // fork

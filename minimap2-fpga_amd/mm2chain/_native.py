@@ -78,6 +78,7 @@ C_SYMBOLS = {
                                              C.c_void_p]),
     "mm2c_seedplan_run_device_skip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                 C.c_int64, C.c_void_p, C.c_void_p]),
+    "mm2c_seedplan_set_heap_sort": (C.c_int, [C.c_void_p, C.c_int]),
     "mm2c_seedplan_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mm2c_seedplan_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_seed_hits_batch_host": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -325,6 +325,10 @@ class SeedPlan:
                                                        anchors.numel() // 2, off.data_ptr(), st), "mm2c_seedplan_run_device_skip")
         return anchors, off
 
+    def set_heap_sort(self, on=True):
+        """MM_F_HEAP_SORT (--heap-sort, -x sr): later runs leave the order of collect_seed_hits_heap (map.c:149-213) among anchors with equal x"""
+        N.check(self.lib.mm2c_seedplan_set_heap_sort(self.handle, 1 if on else 0), "mm2c_seedplan_set_heap_sort")
+
     def check(self):
         """waits for the run; raises if a read's hit counts did not add up to its anchor range; returns the number of reads with equal x"""
         n = C.c_int64(0)

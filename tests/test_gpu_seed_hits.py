@@ -288,3 +288,81 @@ def test_all_vs_all_seed_hits_with_skip_seed_equal_the_reference_and_chain_on_th
             n_chains += u_ref.size
         assert n_chains > 20
         plan.close(); sp.close()
+
+
+def _run_heap_plan(reads, skip=None):
+    """reads through a seed plan with mm2c_seedplan_set_heap_sort(1); skip = (flag, ref_rank, ref_len, [q_lo], [q_eq]) for the skip_seed entry.
+    Returns per-read anchor arrays."""
+    import mm2chain
+    mo, m, h, ql = _batch(reads)
+    cap = np.concatenate([[0], np.cumsum([int(r[1]["n"].sum()) for r in reads])]).astype(np.int64)
+    sp = mm2chain.SeedPlan(mo, cap)
+    sp.set_heap_sort(True)
+    d_m = torch.from_numpy(m.view(np.uint8).copy()).cuda(); d_h = torch.from_numpy(h.view(np.int64).copy()).cuda(); d_q = torch.from_numpy(ql).cuda()
+    if skip is None:
+        a = sp.run(d_m, d_h, d_q); sp.check()
+        off = cap
+    else:
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).astype(np.int32)).cuda()
+        a, off = sp.run_skip(d_m, d_h, d_q, skip[0], dev(skip[1]), dev(skip[2]), dev(skip[3]), dev(skip[4])); sp.check()
+        off = off.cpu().numpy()
+    a = a.cpu().numpy().view(np.uint64)
+    out = [a[off[k]:off[k + 1]] for k in range(len(reads))]
+    # the plan goes back to the radix sort's order when the switch is turned off
+    sp.set_heap_sort(False)
+    if skip is None:
+        a2 = sp.run(d_m, d_h, d_q); sp.check()
+        assert np.array_equal(a2.cpu().numpy().view(np.uint64)[:cap[1]], ob.collect_seed_hits(reads[0][1], reads[0][2], reads[0][0]))
+    sp.close()
+    return out
+
+
+def test_heap_sort_anchor_lists_of_the_reference_map_o():
+    """MM_F_HEAP_SORT (--heap-sort, main.c:245; -x sr, options.c:125): collect_seed_hits_heap (map.c:149-213) merges the matches' hit lists through a binary
+    heap, which leaves anchors with equal x in another order than radix_sort_128x.  Every read of ref_seed_hits.npz through a plan with
+    mm2c_seedplan_set_heap_sort against the anchor lists the reference's own map.o handed to mm_chain_dp under that flag
+    (tests/golden/ref_seed_hits_heap.npz, make_ref_heap_fixtures.py); in four of the reads anchors sit at other places than in the radix-sorted list"""
+    d, hp = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz")), np.load(os.path.join(GOLDEN, "ref_seed_hits_heap.npz"))
+    reads = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"]) for k in range(int(d["n_reads"]))]
+    got = _run_heap_plan(reads)
+    n_moved = 0
+    for k in range(len(reads)):
+        ref = hp[f"r{k}_anchors_heap"]
+        assert np.array_equal(got[k], ref), f"read {k}: anchors differ from the reference's heap-merged list"
+        n_moved += int((ref != d[f"r{k}_anchors"]).any(axis=1).sum())
+    assert n_moved > 2000
+
+
+def _sorted_lists(read):
+    """the hit lists of a random read in ascending order, as mm_idx_get hands them out (the heap merge presupposes it)"""
+    qlen, m, h = read
+    h = h.copy()
+    for k in range(m.size):
+        lo, n = int(m["cr_off"][k]), int(m["n"][k])
+        h[lo:lo + n] = np.sort(h[lo:lo + n])
+    return qlen, m, h
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_heap_sort_random_matches_against_the_oracle(seed):
+    """random matches with many equal x (small position ranges, duplicated hit lists), more matches than the LDS heap holds, reads without hits:
+    the replayed heap against the oracle's (mm2o_collect_seed_hits_heap), with and without skip_seed flags"""
+    rng = np.random.default_rng(900 + seed)
+    reads = [_sorted_lists(r) for r in (_random_read(rng, 700, 8, 2, 3000), _random_read(rng, 40, 3, 1, 50), _random_read(rng, 0, 0, 1, 10),
+                                        _random_read(rng, 300, 0, 1, 10), _random_read(rng, 1500, 5, 24, 1 << 27, dup_frac=0.3),
+                                        _random_read(rng, 2600, 3, 2, 400), _random_read(rng, 900, 6, 3, 1 << 26), _random_read(rng, 2000, 3, 2, 200))]
+    got = _run_heap_plan(reads)
+    n_moved = 0
+    for k, (qlen, m, h) in enumerate(reads):
+        ref = ob.collect_seed_hits(m, h, qlen, heap=True)
+        assert np.array_equal(got[k], ref), f"seed {seed}, read {k}: heap order differs from the oracle's"
+        n_moved += int((ref != ob.collect_seed_hits(m, h, qlen)).any(axis=1).sum())
+    assert n_moved > 500
+    # strand-restricted and all-vs-all flags: fewer anchors than hits (rid 0 .. 23 here; every read named like reference 1, of the read's length)
+    ref_rank, ref_len = np.arange(24, dtype=np.int32), np.full(24, 12000, np.int32)
+    for flag in (ob.F_FOR_ONLY, ob.F_NO_DIAG | ob.F_NO_DUAL):
+        q_lo, q_eq = np.ones(len(reads), np.int32), np.ones(len(reads), np.int32)
+        got = _run_heap_plan(reads, skip=(flag, ref_rank, ref_len, q_lo, q_eq))
+        for k, (qlen, m, h) in enumerate(reads):
+            ref = ob.collect_seed_hits(m, h, qlen, flag, ref_rank, ref_len, 1, 1, heap=True)
+            assert np.array_equal(got[k], ref), f"seed {seed}, flag {flag:#x}, read {k}: {got[k].shape[0]} anchors vs {ref.shape[0]}"

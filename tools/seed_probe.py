@@ -4,7 +4,8 @@ The matches are derived from the bench's synthetic anchor stream (one match per 
 so the anchors the GPU produces are that stream again and the DP that follows is the headline workload.
 usage: python tools/seed_probe.py [n_reads] [anchors_per_read] [profile]
        python tools/seed_probe.py [n_reads] --real-like [genome_mb]   (matches of simulated reads on a synthetic genome, computed on the spot by
-       oracle/_ref/seed_dump = the reference's own sketch/index objects; needs the prebuilt oracle/_ref)"""
+       oracle/_ref/seed_dump = the reference's own sketch/index objects; needs the prebuilt oracle/_ref)
+       --heap: the order of collect_seed_hits_heap (MM_F_HEAP_SORT) among equal x instead of radix_sort_128x's"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,6 +22,7 @@ profile = args_pos[2] if len(args_pos) > 2 else "mixed"
 distinct = min(n_reads, 512)
 QLEN = 1 << 20
 real_like = "--real-like" in sys.argv
+heap = "--heap" in sys.argv
 if not real_like:
     off1, a1 = synth.make_stream(profile, distinct, (per, per), seed=5)
     off1 = off1.numpy(); a1 = a1.numpy().view(np.uint64)
@@ -79,6 +81,8 @@ P = params.map_ont()
 d_m = torch.from_numpy(mt.view(np.uint8)).cuda(); d_h = torch.from_numpy(ht.view(np.int64)).cuda()
 d_q = torch.from_numpy(np.tile(np.array(qlens, np.int32), times)).cuda()
 sp = mm2chain.SeedPlan(mo, ao); cp = mm2chain.ChainPlan(P, ao)
+if heap:
+    sp.set_heap_sort(True)
 d_a = torch.empty((total, 2), dtype=torch.int64, device="cuda")
 d_f = torch.empty(total, dtype=torch.int32, device="cuda"); d_p = torch.empty_like(d_f)
 for it in range(3):
@@ -94,7 +98,7 @@ ok = True
 got = d_a[: int(ao[4])].cpu().numpy().view(np.uint64)
 for k in range(4):
     mk = ms[k].copy(); mk["cr_off"] -= ao[k]
-    ok = ok and np.array_equal(got[ao[k]:ao[k + 1]], ob.collect_seed_hits(mk, hs[k], qlens[k]))
+    ok = ok and np.array_equal(got[ao[k]:ao[k + 1]], ob.collect_seed_hits(mk, hs[k], qlens[k], heap=heap))
 # CPU baseline beside it: the oracle's collect_seed_hits (expansion + radix_sort_128x restated) on one host core, distinct reads only
 t0 = time.perf_counter(); n_cpu = 0
 for k in range(min(distinct, 256)):
