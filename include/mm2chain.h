@@ -253,7 +253,8 @@ int mm2c_seedplan_run_device_skip(mm2c_seedplan_t *plan, const mm2c_match_t *d_m
 /* MM_F_HEAP_SORT (minimap.h:30; --heap-sort, main.c:245; set by -x sr, options.c:125): the following runs of the plan leave the anchors as
  * collect_seed_hits_heap does (map.c:149-213) -- the same anchors, ascending in x, but anchors with EQUAL x in the order the reference's binary heap pops
  * them instead of the order radix_sort_128x leaves.  Works with and without skip_seed. */
-int mm2c_seedplan_set_heap_sort(mm2c_seedplan_t *plan, int on);
+int mm2c_seedplan_set_heap_sort(mm2c_seedplan_t *plan, int on);   /* mm2c_tune("heap_sort", 1): the default of the seed plans created afterwards, those of
+                                                                    * mm2c_seed_hits_batch_host / mm2c_seed_chain_batch_host / _pool included (a host that maps with MM_F_HEAP_SORT) */
 int mm2c_seedplan_check(mm2c_seedplan_t *plan, int64_t *n_reads_with_ties);   /* waits; MM2C_E_ARG if a read's counts disagreed */
 int mm2c_seedplan_last_ms(mm2c_seedplan_t *plan, float *ms);
 /* host buffers in, anchors out (computes the anchor offsets itself): anchor_off[n_reads+1], anchors with room for the sum of all n */

@@ -509,6 +509,11 @@ int mm2c_tune(const char *key, int value)
 		G.far_thr10 = value;
 		return 0;
 	}
+	if (strcmp(key, "heap_sort") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "heap_sort must be 0 or 1");
+		G.heap_sort = value;
+		return 0;
+	}
 	if (strcmp(key, "wide_share_threshold") == 0) {
 		if (value < 0 || value > 100) return fail(MM2C_E_ARG, "wide_share_threshold is a percentage");
 		G.wide_pct = value;

@@ -85,6 +85,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 		biggest = std::max(biggest, h_anchor_off[r + 1] - h_anchor_off[r]);
 	}
 	mm2c_seedplan *pl = new mm2c_seedplan();
+	pl->S.heap_order = G.heap_sort ? 1 : 0;              // the process-wide default (mm2c_tune("heap_sort")): the host-batch entries make their seed plans themselves
 	pl->n_reads = n_reads;
 	pl->total = n_reads ? h_anchor_off[n_reads] - h_anchor_off[0] : 0;
 	pl->n_matches = n_reads ? h_match_off[n_reads] - h_match_off[0] : 0;

@@ -366,3 +366,20 @@ def test_heap_sort_random_matches_against_the_oracle(seed):
         for k, (qlen, m, h) in enumerate(reads):
             ref = ob.collect_seed_hits(m, h, qlen, flag, ref_rank, ref_len, 1, 1, heap=True)
             assert np.array_equal(got[k], ref), f"seed {seed}, flag {flag:#x}, read {k}: {got[k].shape[0]} anchors vs {ref.shape[0]}"
+
+
+def test_heap_sort_through_the_host_batch_entry():
+    """mm2c_tune("heap_sort", 1): the seed plans the host-batch entries create themselves leave the heap order too (a host that maps with MM_F_HEAP_SORT)"""
+    import mm2chain
+    d, hp = np.load(os.path.join(GOLDEN, "ref_seed_hits.npz")), np.load(os.path.join(GOLDEN, "ref_seed_hits_heap.npz"))
+    reads = [(int(d[f"r{k}_qlen"]), d[f"r{k}_matches"], d[f"r{k}_hits"]) for k in range(int(d["n_reads"]))]
+    mo, m, h, ql = _batch(reads)
+    mm2chain.tune("heap_sort", 1)
+    try:
+        ao, a = mm2chain.seed_hits_batch(mo, m, h, ql)
+    finally:
+        mm2chain.tune("heap_sort", 0)
+    for k in range(len(reads)):
+        assert np.array_equal(a[ao[k]:ao[k + 1]], hp[f"r{k}_anchors_heap"]), k
+    ao, a = mm2chain.seed_hits_batch(mo, m, h, ql)
+    assert all(np.array_equal(a[ao[k]:ao[k + 1]], d[f"r{k}_anchors"]) for k in range(len(reads)))
