@@ -38,6 +38,7 @@ struct Global {
 	// tuning knobs: written by mm2c_tune / mm2c_init under `mu`, read by compute entries on other threads (atomics: no torn or stale-forever reads)
 	std::atomic<int> ring_class{3};
 	std::atomic<int> far_thr10{7};                      // ... from this many tenths of an expected far tile per anchor
+	std::atomic<int> noskip_loop{1};                    // max_skip >= max_iter: through the hand-written loop with max_skip = max_iter - 1 (same results)
 	std::atomic<int> heap_sort{0};                      // seed plans created from now on leave collect_seed_hits_heap's order among equal x (MM_F_HEAP_SORT)
 	std::atomic<int> wide_pct{40};                      // plans: tasks with the 32-bit ring hold more than this % of the anchors -> no task takes the compact ring
 	std::atomic<int> split_streams{1};                  // plans: the instantiations a batch is split over (32-bit / compact ring) run side by side on two streams

@@ -45,6 +45,8 @@ struct LaunchArgs {
 	                            // task needs the 32-bit x / q ring (its q values span more than the compact ring can tell apart, chain_dp_tile.h Lds<>)
 	hipStream_t side = nullptr; // with ev_fork / ev_join: when the batch is split over the 32-bit and the compact instantiations, the 32-bit ones run on this stream
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // beside the compact one (two launches one after the other each end with the GPU part empty)
+	int noskip_loop = 1;        // calls whose max-skip exit cannot fire (max_skip >= max_iter) run with max_skip = max_iter - 1 through the hand-written loop (0: the instantiations
+	                            // without the max-skip machinery, C++ loop; mm2c_tune("noskip_loop"), the parity tests run both)
 	int compact = 1;            // 0: never the compact x / q ring (mm2c_tune("compact_ring", 0); the parity tests run both)
 	unsigned long long *d_cls_stat = nullptr;   // CLS_STAT_SLOTS sets of four counters, zero on entry (chain_cls_settle), or nullptr
 	int wide_pct = 40;          // when the tasks that need the 32-bit x / q ring hold more than this share of the batch's anchors, every task takes it

@@ -725,14 +725,21 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 
 int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }   // 3, 4: the tile kernel
 
-hipError_t launch_chain_dp(const LaunchArgs &L, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin, LaunchInfo *info)
+hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin, LaunchInfo *info)
 {
+	if (L_in.n_tasks <= 0) return hipSuccess;
+	LaunchArgs L = L_in;
+	// The early exit of chain.c:231 can never fire when the skip counter cannot exceed max_skip inside one window: a window holds at most max_iter candidates and the
+	// nearest one is never stamped, so the counter stays below max_iter.  Such calls (the V2 scalars of run_chaining_on_hw: max_skip = INT_MAX, max_iter = 1024) used to
+	// take the instantiations without the max-skip machinery, which have no hand-written loop; with max_skip = max_iter - 1 the machinery is compiled in and runs, still
+	// cannot fire, and the hand-written loop serves them (same f / p, V2 scalars: mixed 47.3 -> 44.3 ms per 1.6e8 anchors, dense 85.4 -> 67.5).
+	const bool want_gen = L.P.is_cdna || L.P.n_segs > 1 || (L.P.flags & KF_FORCE_GENERAL);
+	const bool loop_ok = L.P.gap_scale == 1.0f || L_in.force_tab || (L.P.bw <= 511 && L.P.gap_scale > -20.f && L.P.gap_scale < 20.f);   // gap cost computed or from the table
+	if (L.noskip_loop && (int64_t)L.P.max_skip >= (int64_t)L.P.max_iter && L.P.max_iter >= 1 && L.ring_class >= 3 && !want_gen && L.P.bw >= 0 && L.P.max_dq - 1 >= L.P.bw && loop_ok)
+		L.P.max_skip = L.P.max_iter - 1;
 	const KParams &P = L.P;
-	if (L.n_tasks <= 0) return hipSuccess;
-	// the early exit can never fire when the skip counter cannot exceed max_skip inside one window
 	const bool skip = (int64_t)P.max_skip < (int64_t)P.max_iter;
 	const bool gs1 = P.gap_scale == 1.0f;
-	const bool want_gen = P.is_cdna || P.n_segs > 1 || (P.flags & KF_FORCE_GENERAL);
 	const int R = chain_ring_anchors(L.ring_class);
 	const bool tile = L.ring_class >= 3;                   // second-generation kernel: 448 anchors before the current tile without global memory
 	// the general variant (segment ids / cDNA) has no hand-written loop in the tile kernel and is faster in the first-generation one (headline

@@ -509,6 +509,11 @@ int mm2c_tune(const char *key, int value)
 		G.far_thr10 = value;
 		return 0;
 	}
+	if (strcmp(key, "noskip_loop") == 0) {
+		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "noskip_loop must be 0 or 1");
+		G.noskip_loop = value;
+		return 0;
+	}
 	if (strcmp(key, "heap_sort") == 0) {
 		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "heap_sort must be 0 or 1");
 		G.heap_sort = value;
@@ -716,7 +721,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
 	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
 	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32 * mm2c::CLS_STAT_SLOTS, st));
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct; L.noskip_loop = G.noskip_loop;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	if (G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of

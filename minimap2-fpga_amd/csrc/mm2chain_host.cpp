@@ -141,7 +141,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_pbase = (const int32_t *)(c->d_in + o_pb) + s0; L.d_status = (int32_t *)(c->d_in + o_stat) + s0;
 			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-			L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring;
+			L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
 			// each compute stream downloads its own chunk (a separate download stream behind an event turned the copies into blit kernels that
 			// held up the next upload: profiles/r3_e2e.md)
@@ -172,7 +172,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_status = (int32_t *)(c->d_in + o_stat);
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
 	if (staged) {
@@ -424,7 +424,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
 		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
-		L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring;
+		L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
 		if (mp > 0 && mp <= (size_t)INT32_MAX) {
 			char *b = w.d_work;
 			L.cut.max_pieces = (int64_t)mp; L.cut.seg_min = G.seg_min; L.cut.min_anchors = G.plan_cut_min;

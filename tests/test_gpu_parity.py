@@ -153,7 +153,7 @@ def test_far_lookback_in_partial_tail_tiles(max_skip, far_ring, knobs):
     v = []
     f, p = gpu_batch(P, off, a, variant=v)
     assert_same(f, p, f_ref, p_ref, off, f"partial tail tiles, max_skip={max_skip}, far_ring={far_ring}: {v[0]}")
-    assert "FAR=1" in v[0] and ("loop=asm" in v[0]) == (max_skip < 5000), v
+    assert "FAR=1" in v[0] and "loop=asm" in v[0], v          # (max_skip >= max_iter too: it runs with max_skip = max_iter - 1)
 
 
 @pytest.mark.parametrize("far_ring", [1, 2, 0])
@@ -706,7 +706,7 @@ def _ref_cl_groups():
     return z, out
 
 
-def test_hip_equals_the_references_own_device_kernel():
+def test_hip_equals_the_references_own_device_kernel(knobs):
     """f[] / p[] the REFERENCE'S OWN device kernel produced (device/minimap2_opencl.cl compiled for the host and called like
     run_chaining_on_hw does; tests/golden/ref_cl_kernel_fp.npz, generator beside it) against the HIP path, element by element:
     through the reference's C++ symbol run_chaining_on_hw (chain_hardware.h:68) and through a device-resident plan with the V2 scalars"""
@@ -720,10 +720,15 @@ def test_hip_equals_the_references_own_device_kernel():
         assert ret == 0
         assert_same(f, p, z[f"c{k}_f"], z[f"c{k}_p"], None, f"run_chaining_on_hw, case {k} {z[f'c{k}_name']}")
     for (mdx, mdy, bw), (off, a, f_ref, p_ref) in groups.items():
-        v = []
-        f, p = gpu_batch(params.make_params(mdx, mdy, bw, INT32_MAX, 1024, 1.0, 0, 1, -1, mm2chain.MM2C_F_IGNORE_SEG), off, a, variant=v)
-        assert_same(f, p, f_ref, p_ref, off, f"plan with V2 scalars {(mdx, mdy, bw)}")
-        assert "SKIP=0" in v[0] and "loop=c++" in v[0], v
+        # V2 scalars: max_skip >= max_iter, the early exit cannot fire -- by default through the hand-written loop with max_skip = max_iter - 1 (the counter cannot
+        # pass it), with the knob off through the instantiations without the max-skip machinery (C++ loop)
+        for via_loop in (1, 0):
+            knobs("noskip_loop", via_loop)
+            v = []
+            f, p = gpu_batch(params.make_params(mdx, mdy, bw, INT32_MAX, 1024, 1.0, 0, 1, -1, mm2chain.MM2C_F_IGNORE_SEG), off, a, variant=v)
+            assert_same(f, p, f_ref, p_ref, off, f"plan with V2 scalars {(mdx, mdy, bw)}, noskip_loop={via_loop}")
+            assert ("SKIP=1" in v[0] and "loop=asm" in v[0]) if via_loop else ("SKIP=0" in v[0] and "loop=c++" in v[0]), v
+        knobs("noskip_loop", 1)
         # and the stock CPU semantics (V1) restricted to what V2 can express: same vectors
         f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=INT32_MAX, max_iter=1024), off, a)
         assert_same(f, p, f_ref, p_ref, off, f"plan with V1 kernel, max_skip = inf, max_iter = 1024, {(mdx, mdy, bw)}")
@@ -734,7 +739,7 @@ def knobs():
     """tuning knobs a test changes, put back afterwards (results never depend on them; the instantiation that runs does)"""
     import mm2chain
     yield mm2chain.tune
-    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
+    for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
                      ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256)):
         mm2chain.tune(key, val)
 
