@@ -73,7 +73,7 @@ const char *mm2c_last_error(void);            /* thread-local message of the las
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
 /* tuning knobs (key, value): "ring_class" 3 = the tile-aligned DP kernel (default; env MM2C_RING_CLASS; the segment / cDNA variant runs in the
  * first-generation kernel, which is faster for it), 4 = the tile kernel for every variant, 0/1/2 = the first-generation kernel with
- * 256/512/1024 anchors of LDS ring per task; "far_ring" 1 = plans give tasks whose scans are expected to go far beyond the 448-anchor
+ * 256/512/1024 anchors of LDS ring per task; "far_ring" 1 = plans give tasks with the 32-bit LDS ring (see "compact_ring") whose scans are expected to go far beyond the 448-anchor
  * LDS ring of the tile kernel an instantiation with a ring twice as long (chosen per task by the prepass; default; env MM2C_FAR_RING), 0 = never,
  * 2 = every task; "epi_fused" 1 = the device epilogue keeps the per-anchor state of tasks of up to
  * 7 680 anchors in LDS (default; env MM2C_EPI_FUSED), 0 = in HBM for every task; "compact_ring" 1 = tasks whose query positions span at most 65535 - min(max_dist_x, max_dist_y) (reads of up to about 55-60 kb) run
