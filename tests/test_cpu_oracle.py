@@ -342,3 +342,35 @@ def test_matches_from_anchors_expand_back_into_the_same_anchors():
             assert np.all(got[1:, 0] >= got[:-1, 0])
             key = lambda z: z[np.lexsort((z[:, 1], z[:, 0]))]
             assert np.array_equal(key(got), key(t)), (profile, k)
+
+
+def test_compact_ring_arithmetic_is_exact_within_its_bound():
+    """The tile kernel's compact x / q ring keeps the low 16 bits of x and q (chain_dp_tile.h, Lds<>): inside a window (0 <= x_i - x_j <= max_dist_x < 2^16)
+    the differences of the low halves mod 2^16 must give the filter of chain.c:202-205 the same verdict, and the same dr / dq for the pairs that pass, as the
+    full-width arithmetic -- for every task whose q values span at most 65535 - max_dq; one more and a pair can alias (the bound is tight).  NumPy restatement
+    of both sides on random windows, no GPU."""
+    rng = np.random.default_rng(5)
+    for max_dist_x, max_dist_y, bw in ((5000, 5000, 500), (10000, 10000, 2000), (65535, 20000, 3000), (700, 60, 10)):
+        max_dq = min(max_dist_x, max_dist_y)
+        bound = 65535 - max_dq
+        for trial in range(40):
+            n = 400
+            x = np.sort(rng.integers(0, 3 * max_dist_x + 2, n)) + int(rng.integers(0, 1 << 31)) + (int(rng.integers(0, 1 << 30)) << 32)   # rid / strand bits above
+            span = bound if trial % 2 else int(rng.integers(0, bound + 1))
+            q = int(rng.integers(-(1 << 31), (1 << 31) - span)) + rng.integers(0, span + 1, n)
+            q[0], q[1] = q.min(), q.min() + span                     # the span is really reached
+            i, j = np.triu_indices(n, 1)
+            i, j = j, i                                              # j < i
+            in_w = x[i] - x[j] <= max_dist_x                         # the window of chain.c:192
+            i, j = i[in_w], j[in_w]
+            dr, dq = x[i] - x[j], q[i] - q[j]
+            ok = (dr > 0) & (dq > 0) & (dq <= max_dq) & (np.abs(dr - dq) <= bw)
+            dr16 = ((x[i] & 0xffff) - 1 - (x[j] & 0xffff)) & 0xffff  # dr - 1 and dq - 1 as the 16-bit subtractions leave them, zero-extended
+            dq16 = ((q[i] & 0xffff) - 1 - (q[j] & 0xffff)) & 0xffff
+            dd16 = np.abs(dr16 - dq16)
+            ok16 = (dr16 != 0xffff) & (dq16 <= max_dq - 1) & (dd16 <= bw)   # dr == 0 never reaches the filter (equal-x runs are masked): tested here as -1
+            assert np.array_equal(ok, ok16), (max_dist_x, trial)
+            assert np.array_equal(dr16[ok], dr[ok] - 1) and np.array_equal(dq16[ok], dq[ok] - 1)
+        # one beyond the bound: a pair with dq = -(bound + 1) passes the 16-bit test as dq = max_dq
+        qi, qj = 0, bound + 1
+        assert ((qi & 0xffff) - 1 - (qj & 0xffff)) & 0xffff == max_dq - 1
