@@ -87,6 +87,32 @@ def plan_predict_totals(mm2chain, P, off1, a1):
     return r
 
 
+KFD_NODES = os.environ.get("MM2C_BENCH_KFD_NODES", "/sys/class/kfd/kfd/topology/nodes")      # (the variable: tests point it at a made-up tree)
+
+
+def count_gpu_nodes(base=None):
+    """GPUs of this node WITHOUT starting a GPU runtime in this process: the KFD topology nodes that have SIMDs (a CPU node has simd_count 0).
+    None when there is no topology to read (no amdgpu driver, or sysfs not visible).  torch.cuda.device_count() is not used for this: without
+    amdsmi it falls back to hipGetDeviceCount, and the launcher parent would then sit on a runtime context on every GPU while the ranks run."""
+    base = base or KFD_NODES
+    try:
+        nodes = sorted(os.listdir(base))
+    except OSError:
+        return None
+    n, readable = 0, 0
+    for d in nodes:
+        try:
+            with open(os.path.join(base, d, "properties")) as fh:
+                readable += 1
+                for line in fh:
+                    k, _, v = line.strip().partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            continue
+    return n if readable else None
+
+
 def launch_ranks(n):
     """What `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py ...` would do, for the bare `python bench.py --gpus n`:
     n child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1.  Rank 0's JSON line goes to
@@ -94,10 +120,11 @@ def launch_ranks(n):
     import socket
     import subprocess
     if os.environ.get("MM2C_BENCH_ONE_DEVICE") != "1" and os.environ.get("MM2C_BENCH_REHEARSE_NO_GPU") != "1":
-        have = torch.cuda.device_count()                        # counting devices does not initialise the GPU
-        if have < n:
-            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        have = count_gpu_nodes()                                # from the KFD topology in sysfs: this process never starts a GPU runtime
+        if have is not None and have < n:
+            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s) ({KFD_NODES})", file=sys.stderr)
             return 2
+        # (no topology to read: no pre-check -- a rank that cannot select its device ends with an error and takes the others with it)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(n):
@@ -165,12 +192,20 @@ def main():
             dist.init_process_group("gloo")
         tot, _, mx = sharding.allreduce_counters(1000 * (rank + 1), 0, 1000 + rank)
         per = sharding.gather_elapsed_ns(1000 + rank)
-        if rank == 0:
+        fake = os.environ.get("MM2C_BENCH_FAKE_BUS_IDS", "").split(",")          # tests: what each rank "sits on"
+        me = {"rank": rank, "ordinal": dev_index, "pci_bus_id": fake[rank] if rank < len(fake) and fake[rank] else f"rehearsal:{rank}", "arch": "none"}
+        devices = [json.loads(t) for t in sharding.gather_strings(json.dumps(me))]
+        bad = sharding.placement_problems(args.gpus, dist.get_world_size() if world > 1 else 1, devices, shared_device_ok=os.environ.get("MM2C_BENCH_ONE_DEVICE") == "1")
+        if rank == 0 and not bad:
             print(json.dumps({"metric": "anchors/sec chained", "value": None, "unit": "anchors/s", "n_gpus": world, "world_size_seen": world,
                               "rehearsal": "launcher and rank plumbing only: no GPU, no chaining work", "counters_sum": tot, "max_ns": mx,
-                              "per_rank_ns": per, "requested_gpus": args.gpus}))
+                              "per_rank_ns": per, "requested_gpus": args.gpus, "devices": devices}))
         if world > 1:
             dist.destroy_process_group()
+        if bad:
+            if rank == 0:
+                print("bench.py: " + "; ".join(bad), file=sys.stderr)
+            sys.exit(3)
         return
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -188,6 +223,17 @@ def main():
     mm2chain.init(torch.cuda.current_device())
     if args.ring_class is not None:
         mm2chain.tune("ring_class", args.ring_class)
+    # ---- who runs where: every rank's device (HIP ordinal, PCI bus id, architecture) on every rank; a run whose ranks are not the GPUs that were
+    # asked for, or whose ranks share a card, prints no figure and ends with code 3 on every rank (the rehearsal knob for one shared card aside)
+    ident = dict(mm2chain.device_identity(), rank=rank)
+    devices = [json.loads(t) for t in sharding.gather_strings(json.dumps(ident))]
+    bad = sharding.placement_problems(args.gpus, dist.get_world_size() if world > 1 else 1, devices, shared_device_ok=os.environ.get("MM2C_BENCH_ONE_DEVICE") == "1")
+    if bad:
+        if rank == 0:
+            print("bench.py: " + "; ".join(bad), file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
     P = params.map_ont()                                       # max_iter = 5000, max_skip = 25 (options.c:29-30)
     q_span, locus = 15, None
     if args.preset == "asm20":                                 # options.c:113-122: k = 19; cleaner, longer chains
@@ -302,7 +348,7 @@ def main():
     achieved = total * ALGO_BYTES_PER_ANCHOR / (k_avg_ms * 1e-3) / 1e9
     out = {
         "metric": "anchors/sec chained", "value": tot_anchors / wall, "unit": "anchors/s",
-        "n_gpus": world, "world_size_seen": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
+        "n_gpus": world, "world_size_seen": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None), "devices": devices,
         "per_rank_ms_per_step": [ns / 1e6 / args.steps for ns in per_rank_ns], "slowest_rank": int(np.argmax(per_rank_ns)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"synthetic ONT anchor stream ({args.profile}), {args.anchors_per_read} anchors/read, "

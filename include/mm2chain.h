@@ -71,6 +71,10 @@ int  mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int6
 void mm2c_shutdown(void);                     /* not while another thread is inside a compute entry */
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */
 int  mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes);
+/* which physical device the calling thread's library device is: its HIP ordinal, PCI bus id ("0000:c1:00.0") and architecture name.  A multi-GPU
+ * launcher prints one per rank and refuses to report a scaling figure when two ranks sit on the same card (bench.py); the reference's counterpart is
+ * the device list of hardware_init (chain_hardware.cpp:278-330: platform / device enumeration before the queues are made). */
+int  mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *arch, size_t arch_len);
 /* tuning knobs (key, value): "ring_class" 3 = the tile-aligned DP kernel (default; env MM2C_RING_CLASS; the segment / cDNA variant runs in the
  * first-generation kernel, which is faster for it), 4 = the tile kernel for every variant, 0/1/2 = the first-generation kernel with
  * 256/512/1024 anchors of LDS ring per task; "far_ring" 1 = plans give tasks with the 32-bit LDS ring (see "compact_ring") whose scans are expected to go far beyond the 448-anchor

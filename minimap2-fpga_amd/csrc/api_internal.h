@@ -187,7 +187,7 @@ void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
 void release_seed_aux();                            // mm2chain_seeds.cpp
 // a pooled set of helper streams (distinct priorities = hardware queues of their own) and fork / join events, kept between plans (mm2chain_seeds.cpp)
-struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; };
+struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; uint64_t epoch = 0; };   // epoch: G.epoch when the set was made (a set of an earlier one is destroyed, not pooled)
 hipError_t aux_acquire(int device, AuxSet *out);
 void aux_release(const AuxSet &a);
 // for callers that have already waited for the stream(s) the plan ran on: no device-wide wait (chunks of a pipelined batch overlap)

@@ -332,7 +332,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // B2 general: prefix max by DPP -> lanes that raise the best (nm), skip events (se); closed form when every nm precedes every se,
 // else the max-plus scan n <- max(n + d, 0) over the lanes.
 // Wait states the assembler does not insert for inline asm (gfx940): VALU write -> DPP read of that VGPR: 2 (s_nop 1); VALU write ->
-// v_readlane of it: s_nop 0 kept for safety; LDS results: s_waitcnt lgkmcnt(0); global results: s_waitcnt vmcnt(0).
+// v_readlane of it: s_nop 0 kept for safety; SDWA write with dst_sel != DWORD (the compact ring's 16-bit subtractions) -> VALU read of that
+// VGPR: 1 (met by instruction order, see MM2C_FILTER2); LDS results: s_waitcnt lgkmcnt(0); global results: s_waitcnt vmcnt(0).
 // Registers the block touches beyond its operands: VCC and SCC (declared clobbers); M0 (the lane select of v_writelane) and EXEC (the masked
 // stamp stores of the `far` instantiation).  clang refuses both on a clobber list ("reserved registers"): M0 is safe because the compiler loads it
 // right before each of its own uses and never keeps a value in it across a statement; EXEC is saved on entry and that value -- not a literal
@@ -345,7 +346,9 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	MM2C_DPP_STEP(R, "row_shr:4 row_mask:0xf bank_mask:0xf") MM2C_DPP_STEP(R, "row_shr:8 row_mask:0xf bank_mask:0xf") \
 	MM2C_DPP_STEP(R, "row_bcast:15 row_mask:0xa bank_mask:0xf") MM2C_DPP_STEP(R, "row_bcast:31 row_mask:0xc bank_mask:0xf")
 #define MM2C_FILTER(X, Q) "v_sub_u32 %[dr], %[xi1], " X "\n\t" "v_sub_u32 %[dq], %[qi1], " Q "\n\t"
-#define MM2C_FILTER2 "v_sad_u32 %[dd], %[dr], %[dq], 0\n\t" "v_sub_u32_e64 %[u1], %[dq], %[mdqbw] clamp\n\t" "v_max_u32 %[u1], %[u1], %[dd]\n\t" \
+// (order: the saturating subtraction on dq first, then |dr - dq| -- with the compact ring dq and dr come out of SDWA instructions with dst_sel:WORD_0, and gfx940 / gfx950
+// need one wait state between such a write and a VALU read of the register; the compact filters write dq, then dr, so that each is read two instructions after its write)
+#define MM2C_FILTER2 "v_sub_u32_e64 %[u1], %[dq], %[mdqbw] clamp\n\t" "v_sad_u32 %[dd], %[dr], %[dq], 0\n\t" "v_max_u32 %[u1], %[u1], %[dd]\n\t" \
 	"v_cmp_ge_u32 vcc, %[bw], %[u1]\n\t"
 // x / q of an older tile and f - FBIAS / p of a scored one arrive as pairs (one ds_read_b64 each).  Their halves are used one by one, and the
 // operand syntax of inline assembly cannot name half of a 64-bit operand: the four values live in FIXED registers (MM2C_R_X .. MM2C_R_P) that the
@@ -373,9 +376,9 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 // zeros).  The anchor's own x - 1 and q - 1 travel as ONE packed word too (xi1: low halves of x - 1 | q - 1 << 16; one v_readfirstlane per anchor less), the own
 // tile is filtered from its packed word (the operand tx: what the tile wrote into the ring), and a tile from memory (fx, fq: 32-bit loads) by its low halves
 #define MM2C_SUB16(D, S0SEL, V, S1SEL) "v_sub_u16_sdwa " D ", %[xi1], " V " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" S0SEL " src1_sel:" S1SEL "\n\t"
-#define MM2C_RFILTER_C MM2C_SUB16("%[dr]", "WORD_0", MM2C_R_X, "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", MM2C_R_X, "WORD_1")
-#define MM2C_OWNFILTER_C MM2C_SUB16("%[dr]", "WORD_0", "%[tx]", "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", "%[tx]", "WORD_1")
-#define MM2C_FARFILTER_C MM2C_SUB16("%[dr]", "WORD_0", "%[fx]", "WORD_0") MM2C_SUB16("%[dq]", "WORD_1", "%[fq]", "WORD_0")
+#define MM2C_RFILTER_C MM2C_SUB16("%[dq]", "WORD_1", MM2C_R_X, "WORD_1") MM2C_SUB16("%[dr]", "WORD_0", MM2C_R_X, "WORD_0")
+#define MM2C_OWNFILTER_C MM2C_SUB16("%[dq]", "WORD_1", "%[tx]", "WORD_1") MM2C_SUB16("%[dr]", "WORD_0", "%[tx]", "WORD_0")
+#define MM2C_FARFILTER_C MM2C_SUB16("%[dq]", "WORD_1", "%[fq]", "WORD_0") MM2C_SUB16("%[dr]", "WORD_0", "%[fx]", "WORD_0")
 #define MM2C_RDXQ_C "v_readfirstlane_b32 %[xi1], %[tx1]\n\t"
 #define MM2C_OLDADDR_W "v_add_u32 %[vb], 0x400, %[addr]\n\t"
 #define MM2C_OLDADDR_C "v_add_lshl_u32 %[vb], %[addr], %[c200], 1\n\t"
@@ -872,6 +875,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	static_assert(!C16 || (SKIP && !GEN && (GS1 || TAB)), "the compact ring belongs to the variants of the hand-written loop");
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
 	static_assert(NF <= NX, "the f / p ring holds a prefix of the tiles of the x / q ring");
+	static_assert(64 * (NX - 1) < 1024, "bef (anchors of older tiles inside the ring window) travels in the 10-bit field bits 15-24 of the per-anchor word");
 	typedef Lds<NX, NF, GEN, TAB, C16> LY;
 	constexpr int SN = LY::SN;
 	constexpr bool ASMV = SKIP && !GEN && (GS1 || TAB);        // the hand-written scan covers this variant ...

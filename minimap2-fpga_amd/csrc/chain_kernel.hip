@@ -675,14 +675,19 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 	const bool fork = c16 && L.side != nullptr && L.ev_fork != nullptr && L.ev_join != nullptr;
 	hipStream_t sw = fork ? L.side : st;
 	hipError_t e = hipSuccess;
-	if (fork) { e = hipEventRecord(L.ev_fork, st); if (e == hipSuccess) e = hipStreamWaitEvent(sw, L.ev_fork, 0); }
+	bool forked = false;                                   // the side stream has been made to wait for `st`: it is joined again whatever fails in between
+	if (fork) { e = hipEventRecord(L.ev_fork, st); if (e == hipSuccess) { e = hipStreamWaitEvent(sw, L.ev_fork, 0); forked = e == hipSuccess; } }
 	if (e == hipSuccess) e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, mask != 0, wide, mask);
 	if constexpr (!GEN && SKIP)
 		if (e == hipSuccess && classes) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, true, wide | 1, mask); if (n_launches) ++*n_launches; }
-	if (fork && e == hipSuccess) e = hipEventRecord(L.ev_join, sw);
+	bool joined = false;
+	if (forked) joined = hipEventRecord(L.ev_join, sw) == hipSuccess;
 	if constexpr (SKIP && !GEN && (GS1 || TAB))
 		if (e == hipSuccess && c16) { e = launch_tile_nx<MM2C_CNX, MM2C_CNF, SKIP, GEN, GS1, FAR, TAB, true>(L, d_avg, st, only_flagged, true, 0, 2); if (n_launches) ++*n_launches; }
-	if (fork && e == hipSuccess) e = hipStreamWaitEvent(st, L.ev_join, 0);
+	if (forked) {
+		const hipError_t ej = joined ? hipStreamWaitEvent(st, L.ev_join, 0) : hipStreamSynchronize(sw);   // no event to wait on: the host waits for the side stream instead
+		if (e == hipSuccess) e = joined ? ej : hipErrorUnknown;
+	}
 	return e;
 }
 

@@ -363,9 +363,20 @@ int mm2c_init(int device_ordinal)
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (G.ready) return 0;
 	// the pipelines of the host-buffer entries run an upload stream and three compute streams side by side; with the runtime's default of four
-	// hardware queues per process two of them can land on one queue and then take turns (profiles/r3_e2e.md).  Only effective when this is the
-	// process's first contact with the runtime; a host that starts HIP itself sets GPU_MAX_HW_QUEUES in its environment.
-	(void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+	// hardware queues per process two of them can land on one queue and then take turns (profiles/r3_e2e.md).  The runtime reads GPU_MAX_HW_QUEUES
+	// when it starts, and the environment is the host's, not the library's, to change (setenv is not safe against getenv in the host's other
+	// threads and would alter every HIP user of the process): the host exports GPU_MAX_HW_QUEUES=16 before its first HIP call (INTEGRATION.md C;
+	// bench.py and oracle/ref_host's drivers do).  Without it the pipelines still work -- their streams differ in priority where the device
+	// offers that (create_partner_stream) -- and the library says so once.
+	{
+		const char *q = getenv("GPU_MAX_HW_QUEUES");
+		static bool told = false;
+		if ((!q || atoi(q) < 8) && !told && getenv("MM2C_QUIET") == nullptr) {
+			told = true;
+			fprintf(stderr, "[mm2chain] GPU_MAX_HW_QUEUES is %s: the upload / compute streams of the host-batch pipelines may share a hardware queue "
+			                "(export GPU_MAX_HW_QUEUES=16 before the process's first HIP call)\n", q ? q : "unset (runtime default 4)");
+		}
+	}
 	int n_dev = 0;
 	hipError_t e = hipGetDeviceCount(&n_dev);
 	if (e != hipSuccess || n_dev <= 0)
@@ -486,6 +497,23 @@ int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_byt
 	if (name && name_len) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
 	if (cu_count) *cu_count = prop.multiProcessorCount;
 	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+	return 0;
+}
+
+int mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *arch, size_t arch_len)
+{
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	const int dev = cur_device();
+	if (ordinal) *ordinal = dev;
+	if (pci_bus_id && bus_len) {
+		pci_bus_id[0] = 0;
+		HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, (int)std::min<size_t>(bus_len, 64), dev));
+	}
+	if (arch && arch_len) {
+		hipDeviceProp_t prop;
+		HIP_TRY(hipGetDeviceProperties(&prop, dev));
+		snprintf(arch, arch_len, "%s", prop.gcnArchName);
+	}
 	return 0;
 }
 

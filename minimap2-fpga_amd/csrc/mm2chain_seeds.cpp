@@ -32,9 +32,9 @@ hipError_t aux_acquire(int device, AuxSet *out)
 	{
 		std::lock_guard<std::mutex> lk(g_aux_mu);
 		for (size_t i = 0; i < g_aux_free.size(); ++i)
-			if (g_aux_free[i].device == device) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return hipSuccess; }
+			if (g_aux_free[i].device == device && g_aux_free[i].epoch == G.epoch) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return hipSuccess; }
 	}
-	AuxSet a; a.device = device;
+	AuxSet a; a.device = device; a.epoch = G.epoch;
 	hipError_t e = hipSuccess;
 	// helper streams on hardware queues of their own: different priorities never share a queue (see create_partner_stream)
 	int least = 0, greatest = 0;
@@ -52,9 +52,18 @@ hipError_t aux_acquire(int device, AuxSet *out)
 	return hipSuccess;
 }
 
+static void aux_destroy(const AuxSet &a)
+{
+	DeviceScope on(a.device);
+	for (auto &st : a.aux) if (st) (void)hipStreamDestroy(st);
+	for (auto &ev : a.fork) if (ev) (void)hipEventDestroy(ev);
+}
+
 void aux_release(const AuxSet &a)
 {
 	if (a.device < 0) return;
+	// a plan that outlived mm2c_shutdown() brings back handles of the library's previous life: they are destroyed here, never handed to a plan of the next one
+	if (a.epoch != G.epoch || !G.ready) { aux_destroy(a); return; }
 	std::lock_guard<std::mutex> lk(g_aux_mu);
 	g_aux_free.push_back(a);
 }
@@ -62,11 +71,7 @@ void aux_release(const AuxSet &a)
 void release_seed_aux()                       // mm2c_shutdown
 {
 	std::lock_guard<std::mutex> lk(g_aux_mu);
-	for (AuxSet &a : g_aux_free) {
-		DeviceScope on(a.device);
-		for (auto &st : a.aux) if (st) (void)hipStreamDestroy(st);
-		for (auto &ev : a.fork) if (ev) (void)hipEventDestroy(ev);
-	}
+	for (AuxSet &a : g_aux_free) aux_destroy(a);
 	g_aux_free.clear();
 }
 }

@@ -42,6 +42,7 @@ C_SYMBOLS = {
     "mm2c_shutdown": (None, []),
     "mm2c_last_error": (C.c_char_p, []),
     "mm2c_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "mm2c_device_identity": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "mm2c_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mm2c_split_model": (C.c_int, [C.c_char_p] + [C.POINTER(C.c_float)] * 5),
     "mm2c_params_map_ont": (None, [C.POINTER(Params)]),

@@ -74,6 +74,14 @@ def device_info():
     return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
 
+def device_identity():
+    """{"ordinal", "pci_bus_id", "arch"} of the calling thread's library device (mm2c_device_identity)"""
+    lib = N.load()
+    o = C.c_int(-1); bus = C.create_string_buffer(64); arch = C.create_string_buffer(256)
+    N.check(lib.mm2c_device_identity(C.byref(o), bus, 64, arch, 256), "mm2c_device_identity")
+    return {"ordinal": o.value, "pci_bus_id": bus.value.decode(), "arch": arch.value.decode()}
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

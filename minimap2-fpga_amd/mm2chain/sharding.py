@@ -55,3 +55,35 @@ def gather_elapsed_ns(elapsed_ns, device=None):
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return [int(t[0]) for t in out]
+
+
+def gather_strings(text, device=None, width=160):
+    """every rank's short string (device identity: ordinal | PCI bus id | arch), in rank order, on every rank"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [str(text)]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    raw = str(text).encode()[:width]
+    mine = torch.zeros(width, dtype=torch.uint8)
+    mine[: len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    mine = mine.to(dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [bytes(t.cpu().tolist()).rstrip(b"\0").decode() for t in out]
+
+
+def placement_problems(requested_gpus, world_size, identities, shared_device_ok=False):
+    """What is wrong with a multi-GPU run's placement, as a list of sentences (empty: nothing): the ranks that came up are not the GPUs that were
+    asked for, or two ranks report the same PCI bus id (they share a card: the figure would not be an N-GPU figure).  identities: one
+    {"rank", "ordinal", "pci_bus_id", "arch"} per rank."""
+    bad = []
+    if int(world_size) != int(requested_gpus):
+        bad.append(f"--gpus {requested_gpus} but the process group has {world_size} rank(s)")
+    if len(identities) != int(world_size):
+        bad.append(f"{len(identities)} device identities for {world_size} rank(s)")
+    seen = {}
+    for d in identities:
+        b = d.get("pci_bus_id", "")
+        if b in seen and not shared_device_ok:
+            bad.append(f"ranks {seen[b]} and {d.get('rank')} both run on the device at PCI bus id {b!r}")
+        seen.setdefault(b, d.get("rank"))
+    return bad

@@ -90,6 +90,50 @@ def test_bench_gpus_n_starts_n_ranks():
         assert out["counters_sum"] == 1000 * n * (n + 1) // 2 and out["per_rank_ns"] == [1000 + k for k in range(n)] and out["max_ns"] == 1000 + n - 1
 
 
+def _bench_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_bench_refuses_a_run_whose_ranks_are_not_the_gpus_asked_for(tmp_path):
+    """The multi-GPU line must not carry a figure when (a) the process group is not --gpus ranks, (b) two ranks report the same PCI bus id
+    (they share a card), or (c) the node shows fewer GPUs than asked for -- counted from the KFD topology in sysfs, so the launcher parent never
+    starts a GPU runtime (cf. the reference's device enumeration before it makes its queues, chain_hardware.cpp:278-330).  No GPU here: the
+    rehearsal knob makes each rank do the rendezvous and the gathers only, with made-up bus ids."""
+    import json, subprocess, sys
+    from mm2chain import sharding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ids = lambda *b: [{"rank": k, "ordinal": k, "pci_bus_id": x, "arch": "gfx950"} for k, x in enumerate(b)]
+    assert sharding.placement_problems(2, 2, ids("0000:05:00.0", "0000:15:00.0")) == []
+    assert any("both run on" in m for m in sharding.placement_problems(2, 2, ids("0000:05:00.0", "0000:05:00.0")))
+    assert sharding.placement_problems(2, 2, ids("0000:05:00.0", "0000:05:00.0"), shared_device_ok=True) == []
+    assert any("--gpus 8" in m for m in sharding.placement_problems(8, 2, ids("a", "b")))
+    assert any("identities" in m for m in sharding.placement_problems(2, 2, ids("a")))
+    bench = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"]
+    # (b) two ranks on one card: no line, code 3; allowed only under the one-device rehearsal knob
+    r = subprocess.run(bench + ["--gpus", "2"], env=_bench_env(MM2C_BENCH_REHEARSE_NO_GPU="1", MM2C_BENCH_FAKE_BUS_IDS="0000:05:00.0,0000:05:00.0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "both run on" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stderr[-1500:])
+    r = subprocess.run(bench + ["--gpus", "2"], env=_bench_env(MM2C_BENCH_REHEARSE_NO_GPU="1", MM2C_BENCH_FAKE_BUS_IDS="0000:05:00.0,0000:05:00.0", MM2C_BENCH_ONE_DEVICE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert [d["rank"] for d in out["devices"]] == [0, 1] and out["devices"][0]["pci_bus_id"] == "0000:05:00.0"
+    # (a) a launcher that started one rank for --gpus 2
+    r = subprocess.run(bench + ["--gpus", "2"], env=_bench_env(MM2C_BENCH_REHEARSE_NO_GPU="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "--gpus 2" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stderr[-1500:])
+    # (c) the node count comes from the KFD topology: a made-up tree with one CPU node and two GPU nodes
+    for k, simd in enumerate((0, 256, 256)):
+        d = tmp_path / "nodes" / str(k); d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    sys.path.insert(0, root)
+    import bench as bench_mod
+    assert bench_mod.count_gpu_nodes(str(tmp_path / "nodes")) == 2 and bench_mod.count_gpu_nodes(str(tmp_path / "absent")) is None
+    r = subprocess.run(bench + ["--gpus", "3"], env=_bench_env(MM2C_BENCH_KFD_NODES=str(tmp_path / "nodes")), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "shows 2 GPU" in r.stderr, (r.returncode, r.stderr[-1500:])
+
+
 def test_in_process_device_split_covers_and_balances():
     """mm2c_split_tasks (the split the host-batch entries use when mm2c_init_devices configured several devices; cf. the reference's
     per-kernel queue scaffolding chain_hardware.cpp:9-23): with a fake device count, every task lands in exactly one contiguous range, in
