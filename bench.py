@@ -58,7 +58,7 @@ def host_cores():
     return cores
 
 
-def measured_traffic(profile, total_anchors):
+def measured_traffic(profile, total_anchors, preset="map-ont"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
     (profiles/traffic.json: FETCH_SIZE + 8 B per anchor for the half-counted dwordx4 anchor loads + WRITE_SIZE, separate
     --pmc passes).  PMC counters cannot be read from inside this process, so the value is the profiled one, scaled by
@@ -66,7 +66,7 @@ def measured_traffic(profile, total_anchors):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         import hashlib
-        rec = json.load(open(path))[profile]
+        rec = json.load(open(path))[profile if preset == "map-ont" else f"{preset}:{profile}"]   # keyed by stream profile, other presets as preset:profile
         h = hashlib.sha256()
         for fn in ("chain_dp_tile.h", "chain_wave.h", "chain_kernel.hip", "chain_kernel.h"):
             h.update(open(os.path.join(ROOT, "minimap2-fpga_amd", "csrc", fn), "rb").read())
@@ -75,6 +75,74 @@ def measured_traffic(profile, total_anchors):
         return rec["hbm_bytes_per_launch"] * (total_anchors / rec["anchors_per_launch"])
     except Exception:
         return None
+
+
+def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=90.0):
+    """BASELINE.json's second metric, end-to-end map-ont wall-clock (the reference's pipeline: main.c:406-410 -> mm_map_file, map.c:526-620), on a
+    config-3 stand-in (hg38 is not available offline): tools/make_synth_genome.py writes a synthetic genome with planted repeats and simulated ONT
+    reads, and three hosts built over the reference's own non-path objects (oracle/ref_host/Makefile -> oracle/_ref/) map them with the same -t / -K:
+    mm2_refhost chains on the CPU threads (the stated baseline), mm2_batchhost is INTEGRATION.md path C (matches in, chains out, one library call per
+    mini-batch), mm2_gpuhost is path B (one synchronous library call per read through mm_chain_dp).  Wall seconds around each process, the PAF
+    of all three must be byte-identical.  Bounded: each run under `timeout`, the whole leg skipped once `budget_s` is used up.  N = 1, outside the timed region."""
+    import hashlib
+    import re
+    import subprocess
+    import tempfile
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    exes = {"cpu_chaining": "mm2_refhost", "batched_gpu": "mm2_batchhost", "per_read_gpu": "mm2_gpuhost"}
+    for e in exes.values():
+        if not os.path.exists(os.path.join(ref_dir, e)):
+            return {"skipped": f"oracle/_ref/{e} is not there: the hosts are built from the reference's own objects by __graft_entry__.build() where /root/reference exists"}
+    t_all = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="mm2c_e2e_") as w:
+        pre = os.path.join(w, "syn")
+        t0 = time.perf_counter()
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synth_genome.py"), pre, "--genome-mb", str(genome_mb), "--reads", str(reads)],
+                              stdout=subprocess.DEVNULL)
+        out = {"workload": f"map-ont, synthetic {genome_mb} Mb genome with planted repeats (4 sequences), {reads} simulated ONT reads (10 kb, 10 % error), "
+                           f"-t {threads}, mini-batches of {mini_batch} bases (-K)", "stand_in_for": "BASELINE config 3 (hg38 + 100k ONT reads: not available offline)",
+               "threads": threads, "reads": reads, "genome_mb": genome_mb, "generate_s": round(time.perf_counter() - t0, 2), "hosts": {}}
+        md5s = {}
+        for name, exe in exes.items():
+            if time.perf_counter() - t_all > budget_s:
+                out["hosts"][name] = {"skipped": f"the leg's budget of {budget_s:.0f} s was used up"}
+                continue
+            env = dict(os.environ, MM2_MINI_BATCH=str(mini_batch), MM2C_QUIET="1")
+            paf = os.path.join(w, name + ".paf")
+            t0 = time.perf_counter()
+            with open(paf, "wb") as fo:
+                r = subprocess.run(["timeout", "-k", "10", "120", os.path.join(ref_dir, exe), "-t", str(threads), pre + ".ref.fa", pre + ".reads.fa"],
+                                   stdout=fo, stderr=subprocess.PIPE, env=env)
+            wall = time.perf_counter() - t0
+            err = r.stderr.decode(errors="replace")
+            h = hashlib.md5(open(paf, "rb").read()).hexdigest()
+            rec = {"exe": "oracle/_ref/" + exe, "wall_s": round(wall, 3), "rc": r.returncode, "paf_md5": h, "paf_lines": sum(1 for _ in open(paf, "rb"))}
+            m = re.search(r"stages \(summed over mini-batches, they overlap\): (.*)", err)
+            if m:
+                rec["host_stage_sums"] = m.group(1).strip()
+            m = re.search(r"inside the library \(mm2c_get_stage_stats\): (.*)", err)
+            if m:
+                rec["library_stage_stats"] = m.group(1).strip()
+            m = re.search(r"(\d+) reads, (\d+) anchors; ([0-9.]+) s in the batched GPU calls", err)
+            if m:
+                rec["anchors"] = int(m.group(2)); rec["gpu_calls_s"] = float(m.group(3))
+            m = re.search(r"GPU chaining: (.*)", err)
+            if m:
+                rec["per_read_calls"] = m.group(1).strip()
+            if r.returncode != 0:
+                rec["stderr_tail"] = err[-400:]
+            out["hosts"][name] = rec
+            md5s[name] = h if r.returncode == 0 else None
+        done = [v for v in md5s.values() if v]
+        out["paf_identical"] = bool(len(done) == len(exes) and len(set(done)) == 1)
+        cpu = out["hosts"].get("cpu_chaining", {}).get("wall_s")
+        for k in ("batched_gpu", "per_read_gpu"):
+            wk = out["hosts"].get(k, {}).get("wall_s")
+            if cpu and wk and out["hosts"][k].get("rc") == 0:
+                out[k + "_vs_cpu_chaining"] = round(wk / cpu, 3)          # < 1: faster than the CPU-chaining host
+        out["what"] = ("wall seconds around each process (index + FASTA reading + seeding + chaining + alignment-free post-processing + PAF output; process and HIP start-up included), "
+                       "same FASTA files, same -t and -K")
+    return out
 
 
 def plan_predict_totals(mm2chain, P, off1, a1):
@@ -170,6 +238,10 @@ def main():
                          "sharding.shard_tasks (longest first, on anchors per task) and gathered into a rank-local CSR batch; "
                          "value = anchors of the whole batch / max-over-ranks time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end map-ont leg (three host processes over a synthetic genome, about half a minute)")
+    ap.add_argument("--e2e-reads", type=int, default=40000)
+    ap.add_argument("--e2e-genome-mb", type=float, default=25.0)
+    ap.add_argument("--e2e-mini-batch", type=int, default=50_000_000, help="-K of the three hosts (bases per mini-batch)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -359,7 +431,7 @@ def main():
                    "parallelism": f"read-sharded x{world}" + (" (one batch, tasks dealt longest-first)" if args.strong else "")},
         "verified_vs_oracle": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(args.profile, total), "kernel": "chain_dp_tile", "kernel_ms_avg": k_avg_ms,
+                     "traffic": measured_traffic(args.profile, total, args.preset), "kernel": "chain_dp_tile", "kernel_ms_avg": k_avg_ms,
                      "prepass_kernel_ms_avg": float(np.mean(prepass_ms)),
                      "algorithmic_bytes_per_launch": total * ALGO_BYTES_PER_ANCHOR},
     }
@@ -474,8 +546,19 @@ def main():
                                "sample": f"first {n_s} reads of the same batch x {reps} passes ({reps * int(off_np[n_s])} anchors), "
                                          f"{cores} threads, tasks round-robin, {s_all:.1f} s wall",
                                "value_1thread": int(off_np[n1]) / s_one}
+    # ---- end to end (BASELINE.json's second metric): after everything else, the GPU memory of this process given back first
+    if world == 1 and not args.strong and not args.no_e2e and not args.no_secondary and args.preset == "map-ont":
+        try:
+            del d_f, d_p, anchors
+            plan.close(); plan = None
+            mm2chain.tune("trim", 0)
+            torch.cuda.empty_cache()
+            out["e2e_map_ont"] = e2e_map_ont(host_cores(), args.e2e_reads, args.e2e_genome_mb, args.e2e_mini_batch)
+        except Exception as e:
+            out["e2e_map_ont"] = {"error": repr(e)}
     print(json.dumps(out))
-    plan.close()
+    if plan is not None:
+        plan.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -145,6 +145,9 @@ int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
  * "chain_dp_tile<NX=8,NF=2,SKIP=1,GEN=0,GS1=1,FAR=1,TAB=0> loop=asm classes=1 cut=0" (loop=asm: the hand-written per-tile loop, loop=c++: its
  * C++ restatement; chain_dp_wave<...>: the first-generation kernel).  For tests and logs: results never depend on the instantiation. */
 int mm2c_plan_last_variant(mm2c_plan_t *plan, char *buf, size_t len);
+/* the same text for the last DP launch of a host-buffer entry (mm2c_chain_task_host, mm2c_chain_batch_host, mm2c_mm_chain_dp_batch_host), process-wide:
+ * those entries give their passes the prepass classes too, so tasks whose q values allow it take the compact ring there as in plans */
+int  mm2c_last_host_variant(char *buf, size_t len);
 int mm2c_plan_last_prepass_ms(mm2c_plan_t *plan, float *ms);
 
 /*

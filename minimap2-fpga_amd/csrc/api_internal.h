@@ -119,6 +119,7 @@ struct ThreadCtx {
 	hipStream_t st3 = nullptr, st_up = nullptr;   // ... its third compute stream and its upload stream
 	std::vector<hipEvent_t> evs;               // ... and its events (one per chunk in flight), kept for the next call
 	hipEvent_t ev = nullptr;
+	mm2c::LaunchInfo last_info = {};           // which instantiation the context's last DP launch chose (copied to the process-wide record, mm2c_last_host_variant)
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
 	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
 	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
@@ -134,6 +135,15 @@ struct ThreadCtx {
 		*this = ThreadCtx();
 	}
 };
+
+// "chain_dp_tile<...> loop=asm ... compact=1": the text of mm2c_plan_last_variant / mm2c_last_host_variant
+inline void format_variant(const mm2c::LaunchInfo &I, char *buf, size_t len)
+{
+	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
+	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16);
+	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
+}
+void note_host_variant(const mm2c::LaunchInfo &I);   // mm2chain_host.cpp
 
 int get_thread_ctx(ThreadCtx **out);
 // context of the big-batch entries: the worker of a split batch gets the context of its device slot (as get_thread_ctx); every other caller gets

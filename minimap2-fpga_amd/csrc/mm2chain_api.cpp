@@ -836,10 +836,7 @@ int mm2c_plan_last_variant(mm2c_plan_t *pl, char *buf, size_t len)
 {
 	if (!pl || !buf || len == 0) return fail(MM2C_E_ARG, "NULL argument");
 	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
-	const mm2c::LaunchInfo &I = pl->info;
-	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
-	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16);
-	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
+	format_variant(pl->info, buf, len);
 	return 0;
 }
 

@@ -69,16 +69,20 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
 	HIP_TRY(hipSetDevice(c == combiner_ctx() ? G.device : cur_device()));   // the context's stream and arenas belong to that device
-	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
-	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
-	             o_stat = align16(o_avg + (size_t)n_seg * 4), in_bytes = align16(o_stat + (size_t)n_seg * 4);
-	const size_t meta_bytes = in_bytes - o_off;
-	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
 	// chunk size of the two-stream pipeline: "pipeline_chunk_anchors" (a chunk that fills the GPU on its own) for batches many times that size;
 	// a batch of a few chunks' worth is cut into about eight pieces of at least 4 Mi anchors instead, whose kernels overlap on the two streams --
 	// the upload of a piece then hides behind the kernels of the one before (one pass over 2 * 10^7 anchors: 1.44 G anchors/s, PCIe and kernels in series)
 	const int64_t pipe_chunk = std::max<int64_t>(std::min<int64_t>(G.pipeline_chunk_anchors, total / std::max<int64_t>(G.pipeline_pieces, 1)),
 	                                             std::min<int64_t>(G.pipeline_chunk_anchors, G.pipeline_min_chunk));
+	// the prepass classes (which LDS ring a piece takes: chain_window_start -> chain_cls_settle -> the instantiations of chain_dp_tile), as plans have them:
+	// one byte per piece + one zeroed set of counter blocks per launch (a pipelined batch settles its classes chunk by chunk)
+	const size_t cstat_bytes = 32 * (size_t)mm2c::CLS_STAT_SLOTS, max_launches = (size_t)(total / std::max<int64_t>(pipe_chunk, 1)) + 2;
+	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
+	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
+	             o_stat = align16(o_avg + (size_t)n_seg * 4), o_cls = align16(o_stat + (size_t)n_seg * 4), o_cstat = align16(o_cls + (size_t)n_seg),
+	             in_bytes = align16(o_cstat + cstat_bytes * max_launches);
+	const size_t meta_bytes = in_bytes - o_off;
+	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
 	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
 	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
@@ -88,7 +92,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	memcpy(hm + (o_ord - o_off), order.data(), (size_t)n_seg * 4);
 	memcpy(hm + (o_pb - o_off), pbase.data(), (size_t)n_seg * 4);
 	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
-	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);
+	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);           // status, classes, class counters
 	if (staged) {
 		size_t at = o_a;
 		for (int r = 0; r < n_req; ++r) {
@@ -142,7 +146,12 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
 			L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
-			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr));
+			if ((size_t)k < max_launches) {
+				L.d_cls = (uint8_t *)(c->d_in + o_cls) + s0; L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat + cstat_bytes * (size_t)k);
+				L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
+			}
+			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr, k == 0 ? &c->last_info : nullptr));
+			if (k == 0) note_host_variant(c->last_info);
 			// each compute stream downloads its own chunk (a separate download stream behind an event turned the copies into blit kernels that
 			// held up the next upload: profiles/r3_e2e.md)
 			HIP_TRY(hipMemcpyAsync(dst_f + a0, L.d_f + a0, (size_t)(a1 - a0) * 4, hipMemcpyDeviceToHost, st));
@@ -173,8 +182,11 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
+	L.d_cls = (uint8_t *)(c->d_in + o_cls); L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat);
+	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 	int nl = 0;
-	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr));                                                          // cf. chain_hardware.cpp:156
+	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
+	note_host_variant(c->last_info);
 	if (staged) {
 		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
 		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
@@ -199,6 +211,16 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	G.tasks += (uint64_t)n_tasks_all; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.segments += (uint64_t)n_seg;
 	G.passes += 1;
 	return 0;
+}
+
+// which instantiation the last DP launch of a host-buffer entry chose, process-wide (the parity tests assert that these entries reach the compact ring)
+static std::mutex g_variant_mu;
+static mm2c::LaunchInfo g_last_host_info = {};
+static bool g_have_host_info = false;
+void note_host_variant(const mm2c::LaunchInfo &I)
+{
+	std::lock_guard<std::mutex> lk(g_variant_mu);
+	g_last_host_info = I; g_have_host_info = true;
 }
 
 // Combiner for small synchronous calls (the reference's call pattern: up to n_threads host threads, each blocking in
@@ -388,7 +410,8 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		if (!w.st) HIP_TRY(&w == &c->whole[1] ? create_partner_stream(&w.st) : hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
 		w.k0 = k0; w.k1 = k1; w.busy = true;
 		// upload arena: [anchors | offsets | order | status]; pinned mirror of the metadata + room for the offsets that come back
-		const size_t o_off = align16(tot * 16), o_ord = align16(o_off + (nt + 1) * 8), o_stat = align16(o_ord + nt * 4), in_bytes = align16(o_stat + nt * 4);
+		const size_t o_off = align16(tot * 16), o_ord = align16(o_off + (nt + 1) * 8), o_stat = align16(o_ord + nt * 4), o_cls = align16(o_stat + nt * 4),
+		             o_clstat = align16(o_cls + nt), in_bytes = align16(o_clstat + 32 * (size_t)mm2c::CLS_STAT_SLOTS);   // ... | status | class per task | class counters (all zero on entry)
 		const size_t meta_bytes = in_bytes - o_off;
 		w.o_hres = align16(meta_bytes);
 		if ((r = grow_device(&w.d_in, &w.cap_in, in_bytes))) return r;
@@ -409,7 +432,8 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		const size_t mp = extra > 0 ? nt + (size_t)extra : 0;
 		const size_t o_epi = align16(tot * 16), epi_bytes = layout_epilogue(E, nullptr, tot, nt, tmp);
 		const size_t o_cut = align16(o_epi + epi_bytes), o_cstat = o_cut + 256, o_chc = align16(o_cstat + mp * 4), o_cstart = align16(o_chc + nt * 4),
-		             o_cend = align16(o_cstart + mp * 8), o_cpb = align16(o_cend + mp * 8), o_cavg = align16(o_cpb + mp * 4), work_bytes = align16(o_cavg + mp * 4);
+		             o_cend = align16(o_cstart + mp * 8), o_cpb = align16(o_cend + mp * 8), o_cavg = align16(o_cpb + mp * 4), o_ccls = align16(o_cavg + mp * 4),
+		             work_bytes = align16(o_ccls + mp);
 		if ((r = grow_device(&w.d_work, &w.cap_work, work_bytes))) return r;
 		layout_epilogue(E, w.d_work + o_epi, tot, nt, tmp);
 		const size_t o_boff = align16((nt + 1) * 8);
@@ -425,14 +449,18 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
 		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
 		L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
+		L.d_cls = (uint8_t *)(w.d_in + o_cls); L.d_cls_stat = (unsigned long long *)(w.d_in + o_clstat);       // the prepass classes, as plans have them
+		L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 		if (mp > 0 && mp <= (size_t)INT32_MAX) {
 			char *b = w.d_work;
 			L.cut.max_pieces = (int64_t)mp; L.cut.seg_min = G.seg_min; L.cut.min_anchors = G.plan_cut_min;
 			L.cut.d_count = (int32_t *)(b + o_cut); L.cut.d_status = (int32_t *)(b + o_cstat); L.cut.d_has_cut = (int32_t *)(b + o_chc);
 			L.cut.d_start = (int64_t *)(b + o_cstart); L.cut.d_end = (int64_t *)(b + o_cend); L.cut.d_pbase = (int32_t *)(b + o_cpb); L.cut.d_avg = (float *)(b + o_cavg);
+			L.cut.d_cls = (uint8_t *)(b + o_ccls);
 			HIP_TRY(hipMemsetAsync(b + o_cut, 0, o_cstart - o_cut, w.st));          // count, status, has_cut
 		}
-		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr));
+		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr, &c->last_info));
+		note_host_variant(c->last_info);
 		E.n_tasks = (int64_t)nt; E.total = (int64_t)tot; E.d_off = L.d_offsets; E.d_order = L.d_order;
 		E.d_a = (const ulonglong2 *)w.d_in; E.d_f = d_f; E.d_p = d_p; E.min_cnt = min_cnt; E.min_sc = min_sc;
 		E.debug_phases = epilogue_debug_phases();
@@ -475,6 +503,15 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 	}
 	G.tasks += (uint64_t)n_tasks; G.anchors += (uint64_t)total; G.launches += (uint64_t)nl; G.passes += (uint64_t)n_chunks;
 	return rc;
+}
+
+int mm2c_last_host_variant(char *buf, size_t len)
+{
+	if (!buf || len == 0) return fail(MM2C_E_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(g_variant_mu);
+	if (!g_have_host_info) return fail(MM2C_E_ARG, "no host-buffer entry has launched the DP yet");
+	format_variant(g_last_host_info, buf, len);
+	return 0;
 }
 
 int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,

@@ -74,6 +74,13 @@ def device_info():
     return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
 
+def last_host_variant():
+    """which DP instantiation the last host-buffer entry launched ("chain_dp_tile<...> loop=asm ... compact=1")"""
+    buf = C.create_string_buffer(256)
+    N.check(N.load().mm2c_last_host_variant(buf, 256), "mm2c_last_host_variant")
+    return buf.value.decode()
+
+
 def device_identity():
     """{"ordinal", "pci_bus_id", "arch"} of the calling thread's library device (mm2c_device_identity)"""
     lib = N.load()

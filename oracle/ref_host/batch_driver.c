@@ -346,6 +346,7 @@ int main(int argc, char *argv[])
 	if (argc < 3) { fprintf(stderr, "usage: %s [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
 	mm_realtime0 = realtime();
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);   /* the host's own environment, before its first HIP call: the library's pipelines want a hardware queue per stream */
 	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
 	t_init = realtime() - mm_realtime0;
 	defaults(&io, &mo);

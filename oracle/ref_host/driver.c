@@ -54,6 +54,7 @@ int main(int argc, char *argv[])
 	if (argc < 3) { fprintf(stderr, "usage: %s [-x ava-ont] [-t threads] <ref.fa> <query.fa>\n", argv[0]); return 1; }
 	mm_verbose = 1;
 #ifdef MM2_GPU_CHAINING
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);   /* the host's own environment, before its first HIP call: the library's pipelines want a hardware queue per stream */
 	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
 #endif
 	if (getenv("MM2_PRINT_SEEDS")) mm_dbg_flag |= MM_DBG_PRINT_SEED;   /* main.c:193 --print-seeds */

@@ -211,6 +211,43 @@ def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, w
     assert f"compact={compact}" in v[0] and "loop=asm" in v[0], v
 
 
+@pytest.mark.parametrize("entry", ["task", "batch", "mm_chain_dp_batch"])
+def test_host_buffer_entries_take_the_compact_ring(entry, knobs):
+    """The entries that move anchors and f / p (or chains) across PCIe -- mm2c_chain_task_host (the extended run_chaining_on_hw, chain.c:103),
+    mm2c_chain_batch_host, its chunked pipeline and mm2c_mm_chain_dp_batch_host -- give their passes the prepass classes as plans do, so the
+    tasks whose q values allow it run the compact-ring instantiation there too (round 3: these entries launched without the class array and kept
+    the 32-bit rings).  Same corner tasks as the plan test: q shifted, aliased mod 2^16, spans at and one beyond the bound."""
+    import mm2chain
+    from helpers import respan_q
+    from mm2chain import params, synth
+    P = params.map_ont()
+    max_dq = min(P.max_dist_x, P.max_dist_y)
+    rng = np.random.default_rng(78)
+    knobs("wide_share_threshold", 100)                       # the split between compact and 32-bit tasks always stands
+    tasks = []
+    for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("colinear", 2500, None), ("mixed", 700, None), ("sparse", 500, None), ("mixed", 1, None)]):
+        base = synth.make_stream(prof, 1, n, seed=990 + k, locus=locus)[1].numpy().view(np.uint64)
+        for mode in (0, 1, 2, 3, 4, 5, 7):
+            tasks.append(respan_q(rng, base, max_dq, mode))
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    if entry == "task":
+        for k in range(len(tasks)):
+            t = tasks[k]
+            f1, p1 = mm2chain.chain_task(P, t, ob.avg_qspan(t), tid=k)
+            assert_same(f1, p1, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"task host, task {k}")
+            assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+    elif entry == "batch":
+        f, p = mm2chain.chain_batch_host(P, off, a)
+        assert_same(f, p, f_ref, p_ref, off, entry)
+        assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+    else:
+        res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a)
+        _assert_chains(res, P, 3, 40, off, a, "whole-function batch entry with the compact ring")
+        assert "compact=1" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+
+
 def test_ava_ont_and_asm20_shapes():
     from mm2chain import params
     for P, span in ((params.ava_ont(), 15), (params.asm20(), 19)):
@@ -966,6 +1003,7 @@ def test_big_host_batch_is_pipelined_in_chunks():
     finally:
         mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
     assert_same(f, p, f_ref, p_ref, off, "big pageable batch, pipelined")
+    assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()   # the chunks have the prepass classes
     f, p = mm2chain.chain_batch_host(P, off, a)
     assert_same(f, p, f_ref, p_ref, off, "big pageable batch")
     pa = mm2chain.PinnedArray(a.shape, np.uint64); pf = mm2chain.PinnedArray(f.shape, np.int32); pp = mm2chain.PinnedArray(p.shape, np.int32)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condenses a gpurun_out/prof/<tag> directory (written by tools/profile.sh) into profiles/<name>.md and updates
-profiles/traffic.json.  usage: tools/summarize_profile.py <prof dir> <name> <bench profile> <anchors per launch>"""
+profiles/traffic.json.  usage: tools/summarize_profile.py <prof dir> <name> <bench profile> <anchors per launch> [preset]
+(the traffic entry is keyed by the stream profile for map-ont and by preset:profile for the other presets, as bench.py looks it up)"""
 import collections
 import csv
 import glob
@@ -9,6 +10,7 @@ import os
 import sys
 
 src, name, bench_profile, anchors = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+preset = sys.argv[5] if len(sys.argv) > 5 else "map-ont"
 
 
 def kernel_sha():
@@ -23,7 +25,7 @@ def kernel_sha():
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_md = os.path.join(root, "profiles", name + ".md")
 
-lines = [f"# rocprofv3 summary `{name}` (bench.py --profile {bench_profile}, {anchors} anchors per launch)", "",
+lines = [f"# rocprofv3 summary `{name}` (bench.py --preset {preset} --profile {bench_profile}, {anchors} anchors per launch)", "",
          "Command: `tools/profile.sh` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 ...`, "
          "then one `rocprofv3 --pmc <set> --kernel-trace` run per counter set.", "", "## kernel stats (--kernel-trace --stats)", "",
          "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
@@ -79,7 +81,7 @@ if traffic:
               f"| total | **{rd_raw + 8 + wr:.1f}** (algorithmic 24; upper bound with the whole FETCH_SIZE doubled: {2 * rd_raw + wr:.1f}) |", ""]
     tj = os.path.join(root, "profiles", "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
-    allt[bench_profile] = traffic
+    allt[bench_profile if preset == "map-ont" else f"{preset}:{bench_profile}"] = traffic
     json.dump(allt, open(tj, "w"), indent=1)
 open(out_md, "w").write("\n".join(lines) + "\n")
 print("wrote", out_md)
