@@ -77,7 +77,7 @@ def measured_traffic(profile, total_anchors, preset="map-ont"):
         return None
 
 
-def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=90.0):
+def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0):
     """BASELINE.json's second metric, end-to-end map-ont wall-clock (the reference's pipeline: main.c:406-410 -> mm_map_file, map.c:526-620), on a
     config-3 stand-in (hg38 is not available offline): tools/make_synth_genome.py writes a synthetic genome with planted repeats and simulated ONT
     reads, and three hosts built over the reference's own non-path objects (oracle/ref_host/Makefile -> oracle/_ref/) map them with the same -t / -K:
@@ -239,9 +239,9 @@ def main():
                          "value = anchors of the whole batch / max-over-ranks time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end map-ont leg (three host processes over a synthetic genome, about half a minute)")
-    ap.add_argument("--e2e-reads", type=int, default=40000)
-    ap.add_argument("--e2e-genome-mb", type=float, default=25.0)
-    ap.add_argument("--e2e-mini-batch", type=int, default=50_000_000, help="-K of the three hosts (bases per mini-batch)")
+    ap.add_argument("--e2e-reads", type=int, default=120000)
+    ap.add_argument("--e2e-genome-mb", type=float, default=50.0)
+    ap.add_argument("--e2e-mini-batch", type=int, default=100_000_000, help="-K of the three hosts (bases per mini-batch)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:

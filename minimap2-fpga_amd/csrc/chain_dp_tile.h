@@ -428,6 +428,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_cmp_le_i32 vcc, %[lo0], " MM2C_R_P "\n\t" \
 	"s_andn2_b64 %[mask], vcc, %[mk]\n\t"      /* (exec = valid: vcc is already confined to the lanes that passed) */ \
 	"s_cbranch_scc0 Lmk_%=\n\t" \
+	MM2C_LC(MM2C_LB_FARSTAMP) \
 	"s_add_i32 %[t0], %[icnt1], %[c]\n\t" \
 	"v_mov_b32 %[u1], %[t0]\n\t" \
 	"v_lshlrev_b32 %[u2], 2, " MM2C_R_P "\n\t" \
@@ -445,7 +446,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
 	"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
 	"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
-	"s_cbranch_scc1 Ldone_%=\n" \
+	MM2C_LC_BR_SCC1("Ldone_%=", MM2C_LB_BRKA) \
+	"\n" \
 	"Lret_%=:\n\t" \
 	"s_bitcmp1_b32 %[pk], 28\n\t" \
 	"s_cbranch_scc0 Lloop_%=\n\t" \
@@ -455,11 +457,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_bcnt1_i32_b64 %[t0], %[marked]\n\t" \
 	"s_add_u32 %[nskip], %[nskip], %[t0]\n\t" \
 	"s_cmp_gt_i32 %[nskip], %[maxskip]\n\t" \
-	"s_cbranch_scc1 Ldone_%=\n" \
+	MM2C_LC_BR_SCC1("Ldone_%=", MM2C_LB_BRKA) \
+	"\n" \
 	"Lret_%=:\n\t" \
 	"s_branch Lloop_%=\n"
 #define MM2C_END_FAR(SCORE, FARFILTER) \
 	"Lend_%=:\n\t" \
+	MM2C_LC(MM2C_LB_END) \
 	"s_bitcmp1_b32 %[pk], 30\n\t" \
 	"s_cbranch_scc0 Ldone_%=\n\t" \
 	"s_bitset1_b32 %[pk], 28\n\t" \
@@ -472,6 +476,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_add_i32 %[s16], %[icnt1], %[c]\n\t" \
 	"v_mov_b32 %[s16v], %[s16]\n" \
 	"Lfloop_%=:\n\t" \
+	MM2C_LC(MM2C_LB_FLOOP) \
 	"s_add_u32 %[d], %[d], 1\n\t" \
 	"s_sub_u32 %[n], %[n], 1\n\t" \
 	"s_cbranch_scc1 Lfpart_%=\n\t" \
@@ -481,6 +486,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_mov_b64 %[valid], vcc\n\t" \
 	"s_branch Lfold_%=\n" \
 	"Lfpart_%=:\n\t" \
+	MM2C_LC(MM2C_LB_FPART) \
 	"s_mov_b32 %[n], 0\n\t" \
 	"s_cmp_eq_u32 %[part], 0\n\t" \
 	"s_cbranch_scc1 Ldone_%=\n\t" \
@@ -492,6 +498,7 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 	"s_cbranch_scc0 Ldone_%=\n" \
 	"Lfold_%=:\n\t" \
+	MM2C_LC(MM2C_LB_FOLD) \
 	"s_lshl_b32 %[t0], %[d], 6\n\t" \
 	"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 	"v_add_u32 %[u2], %[base], %[rl]\n\t" \
@@ -516,7 +523,8 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 	"v_cmp_eq_u32 vcc, %[s16], %[vb]\n\t" \
 	"s_branch Lmk2_%=\n"
 #define MM2C_END_LEAN(SCORE, FARFILTER) \
-	"Lend_%=:\n"
+	"Lend_%=:\n\t" \
+	MM2C_LC(MM2C_LB_END)
 
 #define MM2C_READ_ANCHOR(SEG_RD, RDXQ) \
 	"v_readfirstlane_b32 %[pk], %[tw]\n\t" \
@@ -571,11 +579,61 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #ifndef MM2C_PROBE_LOOP
 #define MM2C_PROBE_LOOP ""
 #endif
+// Label counters (-DMM2C_LABEL_COUNT: minimap2-fpga_amd/variants/labelcount.so, never the shipped library): MM2C_LC(bit) adds one to lane `bit` of the
+// per-wave register `lc` wherever the block passes -- at the labels of the assembly and on the fall-through side of the branches that pick a fold -- so that the
+// GPU test tests/test_gpu_labels.py can show that the parity inputs drive every path of the REAL instruction sequence (the kernel adds `lc` to
+// g_label_hits after every call; mm2c_debug_label_hits reads the table).  It touches no register the loop uses: exec is parked in `pr` and put back,
+// VCC and SCC are left alone (v_add_u32 has no carry out on gfx9), and the s_nop keeps a DPP instruction that follows away from the exec write.
+#ifdef MM2C_LABEL_COUNT
+#define MM2C_LC(BIT) "s_mov_b64 %[pr], exec\n\t" "s_mov_b64 exec, " BIT "\n\t" "v_add_u32 %[lc], 1, %[lc]\n\t" "s_mov_b64 exec, %[pr]\n\t" "s_nop 4\n\t"
+#define MM2C_LC_BR_SCC1(LABEL, BIT) "s_cbranch_scc0 8f\n\t" MM2C_LC(BIT) "s_branch " LABEL "\n" "8:\n\t"
+#define MM2C_LC_PARAM , int &lc
+#define MM2C_LC_ARG , lc_v
+#define MM2C_LC_OPERAND , [lc] "+v"(lc), [pr] "=&s"(pr)
+__device__ unsigned long long g_label_hits[8 * 32];   // row = compact << 2 | table << 1 | far, column = label bit
+#else
+#define MM2C_LC(BIT) ""
+#define MM2C_LC_BR_SCC1(LABEL, BIT) "s_cbranch_scc1 " LABEL "\n\t"
+#define MM2C_LC_PARAM
+#define MM2C_LC_ARG
+#define MM2C_LC_OPERAND
+#endif
+#define MM2C_LB_K "0x1"
+#define MM2C_LB_OWN "0x2"
+#define MM2C_LB_LOOP "0x4"
+#define MM2C_LB_OLD "0x8"
+#define MM2C_LB_HF "0x10"
+#define MM2C_LB_FARSTAMP "0x20"
+#define MM2C_LB_BRKA "0x40"
+#define MM2C_LB_FG "0x80"
+#define MM2C_LB_PART "0x100"
+#define MM2C_LB_PARTPASS "0x200"
+#define MM2C_LB_IMP "0x400"
+#define MM2C_LB_B0 "0x800"
+#define MM2C_LB_SLOW2 "0x1000"
+#define MM2C_LB_SLOW "0x2000"
+#define MM2C_LB_B1 "0x4000"
+#define MM2C_LB_B1M "0x8000"
+#define MM2C_LB_B2 "0x10000"
+#define MM2C_LB_B2CLOSED "0x20000"
+#define MM2C_LB_LI "0x40000"
+#define MM2C_LB_LICLOSED "0x80000"
+#define MM2C_LB_CFB "0x100000"
+#define MM2C_LB_GEN "0x200000"
+#define MM2C_LB_BK "0x400000"
+#define MM2C_LB_TK "0x800000"
+#define MM2C_LB_AF "0x1000000"
+#define MM2C_LB_END "0x2000000"
+#define MM2C_LB_FLOOP "0x4000000"
+#define MM2C_LB_FPART "0x8000000"
+#define MM2C_LB_FOLD "0x10000000"
+#define MM2C_LB_DONE "0x20000000"
+#define MM2C_LB_SPEC "0x40000000"
 #define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, OWNFILTER, FARFILTER, RDXQ, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
-                                    int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v) \
+                                    int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v MM2C_LC_PARAM) \
 { \
 	typedef Lds<NX, NF, false, TABV, C16V> LY; \
 	typedef Lds<NX, NF, false, true, C16V> LYT; \
@@ -593,6 +651,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		MM2C_READ_ANCHOR(SEG_RD, RDXQ) \
 		"s_mov_b64 exec, %[ex]\n" \
 		"Lk_%=:\n\t" \
+		MM2C_LC(MM2C_LB_K) \
 		MM2C_PROBE_LK \
 		"s_mov_b32 %[bestj], -1\n\t" \
 		"s_cmp_lt_i32 %[pk], 0\n\t" \
@@ -613,6 +672,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		OWNFILTER MM2C_FILTER2 \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lloop_%=\n\t" \
+		MM2C_LC(MM2C_LB_OWN) \
 		"s_mov_b32 %[d], 0\n\t" \
 		"v_add_u32 " MM2C_R_F ", -14, %[own_f]\n\t" \
 		"v_mov_b32 " MM2C_R_P ", %[own_p]\n\t" \
@@ -620,6 +680,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SCORE \
 		"s_branch Lhf_%=\n" \
 		"Lloop_%=:\n\t" \
+		MM2C_LC(MM2C_LB_LOOP) \
 		MM2C_PROBE_LOOP \
 		"s_sub_u32 %[n], %[n], 1\n\t" \
 		"s_cbranch_scc1 Lpart_%=\n\t" \
@@ -629,6 +690,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b64 %[valid], vcc\n\t" \
 		"s_sub_i32 %[d], %[nfull], %[n]\n" \
 		"Lold_%=:\n\t" \
+		MM2C_LC(MM2C_LB_OLD) \
 		OLDADDR                                        /* the running address is two tiles further on: back to this tile's (in units of 8-byte slots) */ \
 		"v_and_b32 %[u2], %[FMASK], %[vb]\n\t"          /* its slot in the f / p ring */ \
 		"v_bfe_u32 %[vb], %[vb], 3, %[SBITS]\n\t"       /* its slot in the stamp ring */ \
@@ -638,6 +700,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SCORE \
 		"s_waitcnt lgkmcnt(0)\n" \
 		"Lhf_%=:\n\t" \
+		MM2C_LC(MM2C_LB_HF) \
 		SEG_HF \
 		"Lmk_%=:\n\t"                                  /* exec = the lanes that passed the filters, until the fold has looked at the scores */ \
 		"s_waitcnt lgkmcnt(0)\n\t" \
@@ -650,6 +713,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b64 exec, %[ex]\n\t" \
 		SEG_TAIL \
 		"Lfg_%=:\n\t" \
+		MM2C_LC(MM2C_LB_FG) \
 		"s_lshl_b32 %[t0], %[d], 6\n\t" \
 		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
 		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
@@ -664,6 +728,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_add_u32 " MM2C_R_F ", -14, " MM2C_R_F "\n\t" \
 		"s_branch Lhf_%=\n" \
 		"Lpart_%=:\n\t" \
+		MM2C_LC(MM2C_LB_PART) \
 		"s_mov_b32 %[n], 0\n\t" \
 		"s_cmp_eq_u32 %[part], 0\n\t" \
 		"s_cbranch_scc1 Lend_%=\n\t" \
@@ -674,10 +739,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b32 %[part], 0\n\t" \
 		"s_and_b64 %[valid], vcc, %[mask]\n\t" \
 		"s_cbranch_scc0 Lend_%=\n\t" \
+		MM2C_LC(MM2C_LB_PARTPASS) \
 		"s_add_i32 %[d], %[nfull], 1\n\t" \
 		BACK \
 		"s_branch Lold_%=\n" \
 		"Limp_%=:\n\t" \
+		MM2C_LC(MM2C_LB_IMP) \
 		"s_ff1_i32_b64 %[t0], %[valid]\n\t" \
 		"v_readfirstlane_b32 %[t1], %[sc]\n\t"          /* the first lane that passed = the lowest active lane */ \
 		"s_cmp_gt_i32 %[t1], %[best]\n\t" \
@@ -685,6 +752,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_cmp_lt_i32 vcc, %[t1], %[sc]\n\t" \
 		"s_cbranch_vccnz Lslow2_%=\n\t" \
 		"s_mov_b64 exec, %[ex]\n\t" \
+		MM2C_LC(MM2C_LB_B0) \
 		"s_mov_b32 %[best], %[t1]\n\t" \
 		"s_lshl_b32 %[t1], %[d], 6\n\t" \
 		"s_sub_i32 %[bestj], %[i063], %[t1]\n\t"   /* i0 + 63 - 64 d - lane */ \
@@ -699,8 +767,10 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc1 Ldone_%=\n\t" \
 		"s_branch " LNEXT "\n" \
 		"Lslow2_%=:\n\t" \
+		MM2C_LC(MM2C_LB_SLOW2) \
 		"v_cmp_lt_i32 vcc, %[best], %[sc]\n" \
 		"Lslow_%=:\n\t" \
+		MM2C_LC(MM2C_LB_SLOW) \
 		"s_mov_b64 exec, %[ex]\n\t"                     /* the general folds work on all lanes: the lanes that did not pass get the sentinel score */ \
 		"v_cndmask_b32_e64 %[sc], %[sent], %[sc], %[valid]\n\t" \
 		"s_lshl_b32 %[t0], %[d], 6\n\t" \
@@ -712,12 +782,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_bcnt1_i32_b64 %[t0], vcc\n\t" \
 		"s_cmp_eq_u32 %[t0], 1\n\t" \
 		"s_cbranch_scc0 Lb1m_%=\n\t" \
+		MM2C_LC(MM2C_LB_B1) \
 		"s_ff1_i32_b64 %[t0], vcc\n\t" \
 		"v_readlane_b32 %[best], %[sc], %[t0]\n\t" \
 		"s_add_i32 %[t1], %[base], 63\n\t" \
 		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
 		"s_branch Lret_%=\n" \
 		"Lb1m_%=:\n\t" \
+		MM2C_LC(MM2C_LB_B1M) \
 		"v_mov_b32 %[va], %[sc]\n\t" \
 		MM2C_DPP_PREFIX_MAX("%[va]") \
 		"s_nop 0\n\t" \
@@ -729,6 +801,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_sub_i32 %[bestj], %[t1], %[t0]\n\t" \
 		"s_branch Lret_%=\n" \
 		"Lb2_%=:\n\t" \
+		MM2C_LC(MM2C_LB_B2) \
 		"v_mov_b32 %[va], %[sc]\n\t" \
 		MM2C_DPP_PREFIX_MAX("%[va]") \
 		"v_bfrev_b32 %[vb], 1\n\t" \
@@ -738,12 +811,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"v_cmp_gt_i32_e64 %[nm], %[sc], %[vb]\n\t" \
 		"s_andn2_b64 %[se], %[marked], %[nm]\n\t" \
 		"s_cbranch_scc1 Lli_%=\n\t" \
+		MM2C_LC(MM2C_LB_B2CLOSED) \
 		"s_bcnt1_i32_b64 %[t0], %[nm]\n\t" \
 		"s_sub_i32 %[nskip], %[nskip], %[t0]\n\t" \
 		"s_max_i32 %[nskip], %[nskip], 0\n\t" \
 		"s_mov_b32 %[last], 63\n\t" \
 		"s_branch Ltk_%=\n" \
 		"Lli_%=:\n\t" \
+		MM2C_LC(MM2C_LB_LI) \
 		"s_flbit_i32_b64 %[t0], %[nm]\n\t" \
 		"s_sub_i32 %[t0], 63, %[t0]\n\t" \
 		"s_ff1_i32_b64 %[t1], %[se]\n\t" \
@@ -756,10 +831,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_add_i32 %[t1], %[nskip], %[t0]\n\t" \
 		"s_cmp_le_i32 %[t1], %[maxskip]\n\t" \
 		"s_cbranch_scc0 Lcfb_%=\n\t" \
+		MM2C_LC(MM2C_LB_LICLOSED) \
 		"s_mov_b32 %[nskip], %[t1]\n\t" \
 		"s_mov_b32 %[last], 63\n\t" \
 		"s_branch Ltk_%=\n" \
 		"Lcfb_%=:\n\t" \
+		MM2C_LC(MM2C_LB_CFB) \
 		"s_sub_i32 %[t0], %[maxskip], %[nskip]\n\t" \
 		"s_max_i32 %[t0], %[t0], 0\n\t" \
 		"s_mov_b64 vcc, %[se]\n\t" \
@@ -771,6 +848,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_sub_i32 %[last], %[last], 1\n\t" \
 		"s_branch Ltk_%=\n" \
 		"Lgen_%=:\n\t" \
+		MM2C_LC(MM2C_LB_GEN) \
 		"s_mov_b64 vcc, %[se]\n\t" \
 		"v_mbcnt_lo_u32_b32 %[vc], vcc_lo, 0\n\t" \
 		"v_mbcnt_hi_u32_b32 %[vc], vcc_hi, %[vc]\n\t" \
@@ -794,9 +872,11 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_mov_b32 %[last], 63\n\t" \
 		"s_branch Ltk_%=\n" \
 		"Lbk_%=:\n\t" \
+		MM2C_LC(MM2C_LB_BK) \
 		"s_ff1_i32_b64 %[last], %[nm]\n\t" \
 		"s_sub_i32 %[last], %[last], 1\n" \
 		"Ltk_%=:\n\t" \
+		MM2C_LC(MM2C_LB_TK) \
 		"s_cmp_lt_i32 %[last], 0\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n\t" \
 		"v_readlane_b32 %[t0], %[va], %[last]\n\t" \
@@ -808,11 +888,13 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_add_i32 %[t0], %[base], 63\n\t" \
 		"s_sub_i32 %[bestj], %[t0], %[t1]\n" \
 		"Laf_%=:\n\t" \
+		MM2C_LC(MM2C_LB_AF) \
 		"s_cmp_eq_u32 %[last], 63\n\t" \
 		"s_cbranch_scc1 Lret_%=\n\t" \
 		"s_branch Ldone_%=\n" \
 		SEG_END(SCORE, FARFILTER) \
 		"Ldone_%=:\n\t" \
+		MM2C_LC(MM2C_LB_DONE) \
 		SEG_DONE \
 		"s_mov_b64 exec, %[oh]\n\t"               /* commit into lane L (lane L - 1, the next anchor's, is written too: its own commit follows) ... */ \
 		"v_mov_b32 %[own_f], %[best]\n\t" \
@@ -824,6 +906,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_cbranch_scc0 Lk_%=\n\t" \
 		"s_branch Lexit_%=\n" \
 		"Lspec_%=:\n\t" \
+		MM2C_LC(MM2C_LB_SPEC) \
 		"s_bitcmp1_b32 %[pk], 29\n\t" \
 		"s_cbranch_scc1 Ldone_%=\n" \
 		"Lexit_%=:\n\t" \
@@ -834,7 +917,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), [oh] "=&s"(oh), \
 		  [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
-		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND \
+		  [own_f] "+v"(own_f), [own_p] "+v"(own_p) MM2C_PROBE_OPERAND MM2C_LC_OPERAND \
 		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [c200] "s"(0x200), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [addr2] "v"(addr2), [lomc] "v"(lomc), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
@@ -865,7 +948,12 @@ MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_c, true, true, MM2C_RING_C, MM2C_SCORE
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
 // C16: the compact x / q ring (Lds<>), for the variants with the hand-written loop; the launcher picks it per task (cls bit 1 clear)
 template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
-__global__ void __launch_bounds__(64, (C16 && Lds<NX, NF, GEN, TAB, C16>::BYTES <= 6144 ? 7 : 1))   // the compact ring leaves room for 7 waves per SIMD: at most 72 VGPRs then (it came out at 73)
+#ifdef MM2C_LABEL_COUNT
+#define MM2C_WAVES_PER_SIMD(C16V, BYTES) 1
+#else
+#define MM2C_WAVES_PER_SIMD(C16V, BYTES) ((C16V) && (BYTES) <= 6144 ? 7 : 1)
+#endif
+__global__ void __launch_bounds__(64, MM2C_WAVES_PER_SIMD(C16, (Lds<NX, NF, GEN, TAB, C16>::BYTES)))   // the compact ring leaves room for 7 waves per SIMD: at most 72 VGPRs then (it came out at 73)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
@@ -933,6 +1021,9 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	bool t_ready = false;                                     // t[0 .. i0) has been zeroed (wave-uniform)
 	const bool no_pairs = !GEN && (P.max_dq <= 0 || P.bw < 0);   // chain.c:203 / chain.c:205 (dd >= 0 > bw) let nothing through
 
+#ifdef MM2C_LABEL_COUNT
+	int lc_v = 0;                                             // lane b: how often the hand-written loop passed label b since the last flush
+#endif
 	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
 	int cur_st = (rl < n) ? st[rl] - st_sub : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
@@ -1011,17 +1102,24 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v MM2C_LC_ARG)
 				if (C16) {
 					// the compact forms take packed words where the 32-bit ones take x and q: the tile's own {x, q} halves and the anchors' {x - 1, q - 1} halves
 #define MM2C_CALLC(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_xq, own_xq1, own_xq, own_xq1, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v)
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v MM2C_LC_ARG)
 					if (FAR && tile_far) k = TAB ? MM2C_CALLC(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_far_c, lo_l);
 					else k = TAB ? MM2C_CALLC(scan_tile_asm_tab_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_c, lo_l);
 #undef MM2C_CALLC
 				} else if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
 				else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
 #undef MM2C_CALL
+#ifdef MM2C_LABEL_COUNT
+				{	// this call's label hits go to the row of the instantiation that ran: compact << 2 | table << 1 | far
+					const int row = (C16 ? 4 : 0) | (TAB ? 2 : 0) | ((FAR && tile_far) ? 1 : 0);
+					if (lane < 32 && lc_v != 0) atomicAdd(&g_label_hits[row * 32 + lane], (unsigned long long)(unsigned)lc_v);
+					lc_v = 0;
+				}
+#endif
 				k = __builtin_amdgcn_readfirstlane(k);
 				if (k >= cnt) break;
 			}

@@ -75,6 +75,8 @@ struct LaunchInfo {
 };
 
 int chain_ring_anchors(int ring_class);
+// label counters of the hand-written loop (builds with -DMM2C_LABEL_COUNT only; hipErrorNotSupported otherwise): 8 rows (compact << 2 | table << 1 | far) x 32 labels
+hipError_t label_hits_read(unsigned long long *out /* 256 */, bool reset);
 // chain.c:53-78 for a CSR batch: per-anchor sub-part counts, per-task totals (any output may be nullptr)
 hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_offsets, const int32_t *d_order, const void *d_anchors,
                           uint8_t *d_num_subparts, int64_t *d_total_subparts, int64_t *d_total_trip, hipStream_t st);

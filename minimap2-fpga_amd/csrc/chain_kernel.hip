@@ -728,6 +728,22 @@ hipError_t launch_predict(int32_t max_dist_x, int64_t n_tasks, const int64_t *d_
 	return hipGetLastError();
 }
 
+hipError_t label_hits_read(unsigned long long *out, bool reset)
+{
+#ifdef MM2C_LABEL_COUNT
+	hipError_t e = hipDeviceSynchronize();
+	if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_label_hits), sizeof(unsigned long long) * 256);
+	if (e == hipSuccess && reset) {
+		static const unsigned long long zero[256] = {};
+		e = hipMemcpyToSymbol(HIP_SYMBOL(g_label_hits), zero, sizeof(zero));
+	}
+	return e;
+#else
+	(void)out; (void)reset;
+	return hipErrorNotSupported;
+#endif
+}
+
 int chain_ring_anchors(int ring_class) { return ring_class == 0 ? 256 : ring_class == 1 ? 512 : ring_class == 2 ? 1024 : 64 * (MM2C_NX - 1); }   // 3, 4: the tile kernel
 
 hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launches, hipEvent_t ev_dp_begin, LaunchInfo *info)

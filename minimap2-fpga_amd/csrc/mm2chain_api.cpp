@@ -500,6 +500,16 @@ int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_byt
 	return 0;
 }
 
+int mm2c_debug_label_hits(unsigned long long *hits, int reset)
+{
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!hits) return fail(MM2C_E_ARG, "hits is NULL");
+	const hipError_t e = mm2c::label_hits_read(hits, reset != 0);
+	if (e == hipErrorNotSupported) return fail(MM2C_E_ARG, "this library was not built with -DMM2C_LABEL_COUNT (minimap2-fpga_amd/variants/labelcount.so is)");
+	HIP_TRY(e);
+	return 0;
+}
+
 int mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *arch, size_t arch_len)
 {
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
