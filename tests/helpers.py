@@ -86,3 +86,21 @@ def respan_q(rng, task, max_dq, mode):
         q = int(q.min()) + (q - int(q.min())) % 60000
     t[:, 1] = hi | (q.astype(np.uint64) & np.uint64(0xffffffff))
     return t
+
+
+def fold_driver_tasks(rng, shapes=((3000, 4, 0.05, 0.15), (2600, 3, 0.0, 0.3), (1500, 12, 0.2, 0.15), (4000, 6, 0.1, 0.05), (900, 40, 0.0, 0.2))):
+    """Tasks written for the rare exits of the fold (chain.c:226-233): branching chains (query positions that follow x with jumps), runs of equal x, per-anchor
+    spans, and -- where the anchors are about 3 apart in x -- windows of well over 960 anchors, i.e. beyond a ring of 16 tiles.  shapes: (anchors, largest step
+    in x, share of anchors with the x of their predecessor, share of query jumps).  Used with max_skip 1 / 3 / 25 by the GPU parity test of the same name's
+    family and by the CPU test that keeps the model's label counters warm."""
+    tasks = []
+    for n, step_hi, dup, jump in shapes:
+        step = np.where(rng.random(n) < dup, 0, rng.integers(1, step_hi + 1, n))
+        pos = (1 << 22) + np.cumsum(step)
+        q = 50 + np.cumsum(np.where(rng.random(n) < jump, rng.integers(-300, 300, n), rng.integers(0, 2 * step_hi, n)))
+        span = np.where(rng.random(n) < 0.7, 15, rng.integers(8, 40, n))
+        x = (np.uint64(1) << np.uint64(32)) | pos.astype(np.uint64)
+        y = (span.astype(np.uint64) << np.uint64(32)) | (np.maximum(q, 1).astype(np.uint64) & np.uint64(0xffffffff))
+        o = np.argsort(x, kind="stable")
+        tasks.append(np.stack((x[o], y[o]), 1))
+    return tasks

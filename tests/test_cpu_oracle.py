@@ -161,6 +161,39 @@ def test_tile_formulation_model_equals_oracle(profile):
                 st["own_pass"] + st["ring_pass"] + st["far_pass"]
 
 
+def test_model_of_the_hand_written_loop_reaches_every_label():
+    """The NumPy model of the tile kernel's control flow (tests/tile_model.py), in the 32-bit and in the compact ring form, equals the oracle on the inputs
+    written for the rare exits of the fold, and those inputs drive every sub-path the assembly has a label for (chain.c:226-233: new maximum, skip event, the
+    `break` in fold A, in the closed forms and inside the max-plus scan; deep f / p, partly covered tiles, look-back and stamps beyond the ring) -- a label that
+    goes cold fails here, on the CPU.  The real instruction sequence is counted on the GPU with the same inputs among the others (tests/test_gpu_labels.py,
+    profiles/r4_label_hits.md)."""
+    from helpers import fold_driver_tasks
+    from tile_model import chain_tile_model, LABEL_KEYS
+    rng = np.random.default_rng(4242)
+    tasks = fold_driver_tasks(rng, shapes=((1100, 4, 0.05, 0.15), (2000, 3, 0.0, 0.3), (700, 12, 0.2, 0.15), (500, 40, 0.0, 0.2)))
+    off, a = _stream("mixed", 2, 700, seed=5)                 # noise around a chain: scans that run to the end of their window (partly covered tiles, lone candidates)
+    tasks += [a[off[0]:off[1]], a[off[1]:off[2]]]
+    off, a = _stream("dense", 1, 1600, seed=8, locus=5000)    # noise in one window of 1 600 anchors: scans that go on beyond a ring of 16 tiles
+    tasks.append(a)
+    tot = {}
+    for form, (compact, NX) in {"32-bit ring of 8 tiles": (False, 8), "compact ring of 16 tiles": (True, 16)}.items():
+        S = dict.fromkeys(LABEL_KEYS, 0)
+        for max_skip in (1, 3, 25):
+            par = P(max_skip=max_skip)
+            for t in tasks:
+                avg = ob.avg_qspan(t)
+                f, p, _ = ob.chain_fpv(par, t, avg)
+                st = {}
+                fm, pm = chain_tile_model(par, t, avg, NX=NX, stats=st, compact=compact)
+                assert np.array_equal(f, fm) and np.array_equal(p, pm), (form, max_skip)
+                for k in LABEL_KEYS:
+                    S[k] += st[k]
+        tot[form] = S
+        cold = [k for k in LABEL_KEYS if S[k] < 3]
+        assert not cold, f"{form}: sub-paths of the fold the driver inputs no longer reach: {cold}"
+    assert tot["32-bit ring of 8 tiles"]["far_pass"] > 100 and tot["compact ring of 16 tiles"]["far_pass"] > 100
+
+
 def test_fpga_literal_equals_v1_with_v2_parameters():
     """device/minimap2_opencl.cl emulated literally == chain.c loop with max_skip=inf, max_iter=1024"""
     off, a = _stream("dense", 2, 2500, seed=8, locus=9000)

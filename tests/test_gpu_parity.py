@@ -136,6 +136,29 @@ def test_tile_kernel_paths(max_skip, gap_scale, bw):
     assert bw <= 0 or int((p_ref >= 0).sum()) > a.shape[0] // 3   # (a negative max_skip: the first skip event ends a scan; bw < 0: nothing chains)
 
 
+@pytest.mark.parametrize("compact,gap_scale", [(1, 0.8), (1, 1.0), (0, 0.8), (0, 1.0)])
+def test_drive_every_fold_of_the_hand_written_loop(compact, gap_scale, knobs):
+    """Inputs written for the rare exits of the fold (chain.c:226-233 as the hand-written loop restates it): with max_skip 1 and 3 on branching chains the
+    `break` fires in every form -- in fold A, in the closed forms (B0, Lcfb) and inside the max-plus scan (Lbk) -- and with anchors 3 apart in x the windows
+    (max_dist_x 5000: > 1 600 anchors) reach beyond the ring of 16 tiles, so the `far` instantiation folds chunks from memory as well.  Four instantiation
+    families: compact / 32-bit ring x gap cost computed / from the table (gap_scale 0.8).  tests/test_gpu_labels.py counts the labels these (and the other
+    parity inputs) reach in the real assembly; the table it printed before this test existed had four cold entries, all in the compact + table rows."""
+    from helpers import fold_driver_tasks
+    from mm2chain import params
+    knobs("compact_ring", compact)
+    rng = np.random.default_rng(4242 + 10 * compact + int(gap_scale * 10))
+    for max_skip in (1, 3, 25):
+        tasks = fold_driver_tasks(rng)
+        a = np.concatenate(tasks)
+        off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
+        P = params.make_params(max_skip=max_skip, gap_scale=gap_scale)
+        f_ref, p_ref = oracle_batch(P, off, a)
+        v = []
+        f, p = gpu_batch(P, off, a, variant=v)
+        assert_same(f, p, f_ref, p_ref, off, f"fold drivers, max_skip={max_skip} gap_scale={gap_scale} compact={compact}: {v[0]}")
+        assert "loop=asm" in v[0] and f"compact={compact}" in v[0] and f"TAB={int(gap_scale != 1.0)}" in v[0], v
+
+
 @pytest.mark.parametrize("max_skip,far_ring", [(25, 1), (1000, 1), (1000, 0), (25, 2), (INT32_MAX, 1)])
 def test_far_lookback_in_partial_tail_tiles(max_skip, far_ring, knobs):
     """the last tile of a task holds cnt < 64 anchors; when their windows reach beyond the LDS ring the `far` instantiation of the hand-written

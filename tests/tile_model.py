@@ -20,7 +20,14 @@ def _score(P, avg, dr1, dq1, dd, span_i):
     return s - gap
 
 
-def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
+LABEL_KEYS = ("lk", "own_pass", "lloop", "lold", "lfg", "lpart", "part_pass", "limp", "fold_b0", "lslow2", "lslow", "fold_b1", "lb1m", "lb2", "b2_no_skip_events", "lli",
+              "li_closed", "lcfb", "lgen", "lbk", "break_in_fold_a", "break_in_b0", "lend", "far_chunks", "far_pass", "far_stamp", "lspec")
+
+
+def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None, compact=False):
+    """compact: the x / q ring holds the low 16 bits of x and q (Lds<..., C16>), differences taken mod 2^16 and zero-extended, as the SDWA subtractions of the
+    compact instantiations do (the caller checks the task's q span, as the prepass does).  stats additionally receives the sub-paths of the fold by the names of
+    the assembly's labels (LABEL_KEYS; tests/test_cpu_oracle.py keeps them warm, tests/test_gpu_labels.py counts the real ones)."""
     a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
     n = a.shape[0]
     x64 = a[:, 0].astype(np.uint64)
@@ -43,20 +50,26 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
     lane = np.arange(64)
     S = dict(anchors=0, no_window=0, own_chunks=0, own_pass=0, ring_chunks=0, ring_pass=0, deep_fp=0, far_chunks=0, far_pass=0,
              fold_a=0, fold_b0=0, fold_b1=0, fold_b2_closed=0, fold_b2_scan=0, breaks=0, eq_run_anchors=0)
+    S.update(dict.fromkeys(LABEL_KEYS, 0), fold_b0=0, fold_b1=0, own_pass=0, far_chunks=0, far_pass=0)
+    CM = 0xffff
     for i0 in range(0, n, 64):
         cnt = min(64, n - i0)
         stamp_lo = i0 - 64 * (NX - 1)
         idx = i0 + 63 - lane                                                      # lane L holds anchor i0 + 63 - L
         m = idx < n
-        s_x[idx[m] % SN] = xlo[idx[m]]; s_q[idx[m] % SN] = q[idx[m]]; s_t[:] = 0   # one-byte stamps: the ring is wiped per tile
+        s_x[idx[m] % SN] = xlo[idx[m]] & CM if compact else xlo[idx[m]]
+        s_q[idx[m] % SN] = q[idx[m]] & CM if compact else q[idx[m]]
+        s_t[:] = 0                                                                # one-byte stamps: the ring is wiped per tile
         for k in range(cnt):
             i = i0 + k
             sp_i = span_override if span_override >= 0 else int(span[i])
             lo = i if max_dq <= 0 else min(int(st[i]), i)
             best, best_j, n_skip = sp_i, -1, 0
             S["anchors"] += 1
+            S["lk"] += 1
             if lo >= i:
                 S["no_window"] += 1
+                S["lspec"] += 1
                 f[i], p[i] = best, best_j
                 continue
             # equal-x run that ends at i (chain.c:202 `dr == 0`): those predecessors are dropped
@@ -65,6 +78,8 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                 e += 1
             if e:
                 S["eq_run_anchors"] += 1
+                if e > i - i0:
+                    S["lspec"] += 1                                                # the run reaches into the tile before: the C++ path takes the anchor
             s16 = 1 + (i & 63)
             broke = False
             base = i0
@@ -75,17 +90,24 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     base -= 64; continue
                 own = base == i0
                 ring = (not own) and base >= stamp_lo
+                part = bool((j < lo).any())
                 if own:
                     S["own_chunks"] += 1
                 elif ring:
                     S["ring_chunks"] += 1
+                    S["lpart" if part else "lloop"] += 1
                 else:
                     S["far_chunks"] += 1
                 jj = np.clip(j, 0, n - 1)
                 xj = xlo[jj] if not ring else s_x[j % SN]
                 qj = q[jj] if not ring else s_q[j % SN]
-                dr1 = ((xlo[i] - 1 - xj + 2**31) % 2**32) - 2**31
-                dq1 = ((q[i] - 1 - qj + 2**31) % 2**32) - 2**31
+                if compact:
+                    # low halves, differences mod 2^16, zero-extended: 0xffff stands for -1 (dr == 0 / dq == 0) and fails the filter like any other big value
+                    dr1 = (xlo[i] - 1 - xj) & CM
+                    dq1 = (q[i] - 1 - qj) & CM
+                else:
+                    dr1 = ((xlo[i] - 1 - xj + 2**31) % 2**32) - 2**31
+                    dq1 = ((q[i] - 1 - qj + 2**31) % 2**32) - 2**31
                 dd = np.abs(dr1 - dq1)
                 if fast_filter:
                     u = np.maximum(np.maximum((dq1 % 2**32) - (max_dq - 1 - P.bw), 0), dd)          # v_sub clamp, v_max_u32 (dq1 < 0 wraps to huge)
@@ -101,10 +123,12 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     fj, pj = f[jj], p[jj]
                 elif ring:
                     S["ring_pass"] += 1
+                    S["part_pass" if part else "lold"] += 1
                     if depth <= NF:
                         fj, pj = s_f[j % (64 * NF)], s_p[j % (64 * NF)]
                     else:
                         S["deep_fp"] += 1
+                        S["lfg"] += 1
                         fj, pj = f[jj], p[jj]
                 else:
                     S["far_pass"] += 1
@@ -116,6 +140,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                         s_t[pj[L] % SN] = s16
                     else:
                         t_glob[pj[L]] = i + 1
+                        S["far_stamp"] += 1
                 if own or ring:
                     marked = valid & (s_t[j % SN] == s16)
                 else:
@@ -129,11 +154,17 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     n_skip += int(marked.sum())
                     if marked.any() and n_skip > P.max_skip:                       # the break of chain.c:231; nothing before it changes the best
                         broke = True
+                        S["break_in_fold_a"] += 1
                     base -= 64
                     if broke:
                         S["breaks"] += 1
                     continue
+                S["limp"] += 1
                 l0 = int(np.argmax(valid))
+                if scv[l0] > best and (scv > scv[l0]).any():
+                    S["lslow2"] += 1
+                if not (scv[l0] > best and not (scv > scv[l0]).any()):
+                    S["lslow"] += 1
                 if scv[l0] > best and not (scv > scv[l0]).any():                   # fold B0: the first surviving lane is the only new maximum
                     S["fold_b0"] += 1
                     best, best_j = int(scv[l0]), base + 63 - l0
@@ -143,6 +174,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     if se.any() and n_skip > P.max_skip:                           # chain.c:231 is only reached by a skip event
                         broke = True
                         S["breaks"] += 1
+                        S["break_in_b0"] += 1
                     base -= 64
                     continue
                 incl = np.maximum.accumulate(scv)
@@ -152,17 +184,28 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                     best, best_j = int(scv[L]), base + 63 - L
                     base -= 64
                     continue
+                if not marked.any() and n_skip == 0:
+                    S["lb1m"] += 1                                                 # several candidates, nothing to count: prefix max only
+                else:
+                    S["lb2"] += 1
                 excl = np.concatenate(([INT_MIN], incl[:-1]))
                 nm = valid & (sc > np.maximum(best, excl))
                 se = marked & ~nm
                 if not se.any():
                     S["fold_b2_closed"] += 1
+                    if marked.any() or n_skip != 0:
+                        S["b2_no_skip_events"] += 1
                     n_skip = max(n_skip - int(nm.sum()), 0)
                 else:
                     last_nm = 63 - int(np.argmax(nm[::-1])) if nm.any() else -1
                     first_se = int(np.argmax(se))
                     closed = last_nm < first_se and max(n_skip - int(nm.sum()), 0) + int(se.sum()) <= P.max_skip
                     S["fold_b2_closed" if closed else "fold_b2_scan"] += 1
+                    S["lli"] += 1
+                    if last_nm < first_se:
+                        S["li_closed" if closed else "lcfb"] += 1
+                    else:
+                        S["lgen"] += 1
                     D = np.cumsum(se.astype(np.int64) - nm.astype(np.int64))
                     nl = D + np.maximum(n_skip, np.maximum.accumulate(-D))
                     brk = se & (nl > P.max_skip)
@@ -170,6 +213,8 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                         last = int(np.argmax(brk)) - 1
                         broke = True
                         S["breaks"] += 1
+                        if last_nm >= first_se:
+                            S["lbk"] += 1
                     else:
                         n_skip = int(nl[63])
                 if last >= 0:
@@ -178,6 +223,8 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None):
                         best = mc
                         best_j = base + 63 - int(np.argmax(valid & (sc == mc)))
                 base -= 64
+            if not broke and base + 63 < lo and i0 - lo > 0:
+                S["lend"] += 1                                                     # the window ran out (in the assembly: its ring part, Lend)
             f[i], p[i] = best, best_j
         sl = slice(i0, i0 + cnt)
         s_f[np.arange(i0, i0 + cnt) % (64 * NF)] = f[sl]; s_p[np.arange(i0, i0 + cnt) % (64 * NF)] = p[sl]
