@@ -52,6 +52,9 @@ struct Global {
 	std::atomic<int64_t> pipeline_pieces{8}, pipeline_min_chunk{4 << 20};   // host paths: a batch of a few chunks' worth is cut into about `pieces` chunks of at least `min_chunk` anchors
 	std::atomic<int64_t> cut_below_tasks{4096};         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
+	std::atomic<int> coop_waves{8};                     // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never)
+	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> coop_plans{0};                     // plans take the cooperative kernel too when they have few tasks (tests; default: the host-buffer entries only)
 	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
 	std::atomic<int> plan_cut_min{8192};                // ... tasks of at least this many anchors (the ones that make the tail of a batch)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL
@@ -139,7 +142,9 @@ struct ThreadCtx {
 // "chain_dp_tile<...> loop=asm ... compact=1": the text of mm2c_plan_last_variant / mm2c_last_host_variant
 inline void format_variant(const mm2c::LaunchInfo &I, char *buf, size_t len)
 {
-	if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
+	if (I.tile && I.coop) snprintf(buf, len, "chain_dp_coop<W=%d,NX=%d,NF=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=0 cut=0 compact=0 coop=%d", I.coop, I.nx, I.nf, I.gs1,
+	                               I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.coop);
+	else if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
 	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16);
 	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
 }

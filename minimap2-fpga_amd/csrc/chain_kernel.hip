@@ -66,6 +66,7 @@
 #define MM2C_CNF 2
 #endif
 #include "chain_dp_tile.h"
+#include "chain_dp_coop.h"
 
 namespace mm2c {
 
@@ -691,6 +692,20 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 	return e;
 }
 
+// ---- several waves per task (chain_dp_coop.h): passes too small to fill the GPU with one wave per task; the variants of the hand-written loop only
+constexpr int COOP_W = 8;
+static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged)
+{
+	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);
+	const dim3 grid((unsigned)L.n_tasks), block(64 * COOP_W);
+#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged)
+	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
+	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
+#undef MM2C_COOP
+	return hipGetLastError();
+}
+
 template <bool SKIP, bool FAR>
 static hipError_t launch_tile_sf(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool gen, bool gs1, bool tab, int only_flagged, int *nl)
 {
@@ -774,14 +789,18 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	static const bool force_tab_env = getenv("MM2C_FORCE_TAB") != nullptr;   // experiment switch: the table also for gap_scale == 1
 	const bool force_tab = force_tab_env || L.force_tab != 0;
 	const bool tab = tile && (!gs1 || force_tab) && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
+	// several waves per task: asked for by the caller for a pass of few tasks; the variants with the hand-written loop, tasks not cut on the device
+	const bool coop = L.coop_waves > 1 && tile && !want_gen && skip && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw && L.cut.max_pieces == 0;
 	if (info) {
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
+		info->coop = coop ? COOP_W : 0;
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
 		info->skip = skip; info->gen = want_gen; info->gs1 = gs1; info->far_ = t0 ? far_ : (tile ? far_old : far_); info->tab = t0 && tab && !want_gen;
 		info->asm_loop = t0 && skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // = ASM of chain_dp_tile
 		info->classes = t0 && use_classes(L, skip, want_gen);
 		info->c16 = t0 && compact_q_span(L, info->asm_loop != 0) != 0;
 		info->cut = L.cut.max_pieces > 0;
+		if (coop) { info->nx = COOP_NX; info->nf = COOP_NF; info->r = 64 * (COOP_NX - 1); info->far_ = (int64_t)P.max_iter > 64 * (COOP_NX - 1); info->classes = 0; info->c16 = 0; }
 	}
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
@@ -813,6 +832,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		const bool gen = want_gen || pass == 1;
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
+		if (coop && !gen) { e = launch_coop(L, d_avg, st, tab, flagged); if (n_launches) ++*n_launches; continue; }
 		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged, n_launches); if (n_launches) ++*n_launches; continue; }
 		if (tile) { e = launch_r<256>(L1, st, skip, gen, gs1, far_old, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {

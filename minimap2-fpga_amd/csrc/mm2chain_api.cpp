@@ -420,6 +420,8 @@ int mm2c_init(int device_ordinal)
 	if (ss) G.split_streams = std::max(0, std::min(2, atoi(ss)));
 	const char *wp = getenv("MM2C_WIDE_SHARE_THRESHOLD"); // % of the anchors in tasks that need the 32-bit ring from which every task takes it
 	if (wp) G.wide_pct = std::max(0, std::min(100, atoi(wp)));
+	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
+	if (cw) G.coop_waves = std::max(0, atoi(cw));
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
@@ -597,6 +599,20 @@ int mm2c_tune(const char *key, int value)
 		G.pipeline_min_chunk = value;
 		return 0;
 	}
+	if (strcmp(key, "coop_waves") == 0) {
+		if (value < 0 || value > 64) return fail(MM2C_E_ARG, "coop_waves must be 0 .. 64 (0 / 1: one wave per task always; otherwise the cooperative kernel's 8 waves)");
+		G.coop_waves = value;
+		return 0;
+	}
+	if (strcmp(key, "coop_plans") == 0) {
+		G.coop_plans = value != 0;
+		return 0;
+	}
+	if (strcmp(key, "coop_max_tasks") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "coop_max_tasks must be >= 0");
+		G.coop_max_tasks = value;
+		return 0;
+	}
 	if (strcmp(key, "plan_cut") == 0) {
 		if (value < 0 || value > 1) return fail(MM2C_E_ARG, "plan_cut must be 0 or 1");
 		G.plan_cut = value;
@@ -761,7 +777,9 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32 * mm2c::CLS_STAT_SLOTS, st));
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct; L.noskip_loop = G.noskip_loop;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
-	if (G.plan_cut && G.seg_min > 0) {
+	// a plan of few tasks: several waves per task instead of pieces cut on the device (chain_dp_coop.h; launch_chain_dp takes it for the variants of the hand-written loop)
+	L.coop_waves = (G.coop_plans && pl->n_tasks <= G.coop_max_tasks) ? G.coop_waves.load() : 0;   // (plans: only when asked for, mm2c_tune("coop_plans", 1))
+	if (L.coop_waves <= 1 && G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
 		// plan_cut_min anchors or more (they make the tail of the batch); a batch without any runs exactly as before.
 		int64_t extra = 0;

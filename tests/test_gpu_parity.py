@@ -159,6 +159,73 @@ def test_drive_every_fold_of_the_hand_written_loop(compact, gap_scale, knobs):
         assert "loop=asm" in v[0] and f"compact={compact}" in v[0] and f"TAB={int(gap_scale != 1.0)}" in v[0], v
 
 
+@pytest.mark.parametrize("case", ["profiles", "fold-drivers", "tile-paths", "compact-corners", "random-scalars", "ava-ont", "tiny-and-ragged"])
+def test_several_waves_per_task_equal_the_oracle(case, knobs):
+    """chain_dp_coop (csrc/chain_dp_coop.h): a workgroup of 8 waves per task.  Candidates are counted and the older tiles reduced in parallel; an anchor with at
+    most max_skip candidates in its window cannot take the `break` of chain.c:231, so its result is the plain maximum (nearest j on ties, chain.c:226); every
+    other anchor takes the exact scan (hand-written loop or C++).  Both kinds, the hand-over between them inside a tile, windows beyond the ring, equal-x runs,
+    per-anchor spans, max_skip from -1 to INT_MAX, the gap-cost table: same f / p as the oracle."""
+    from helpers import fold_driver_tasks, respan_q
+    from mm2chain import params, synth
+    knobs("coop_plans", 1)
+    rng = np.random.default_rng(515)
+    runs = []
+    if case == "profiles":
+        for prof in ("sparse", "mixed", "dense", "colinear"):
+            off, a = _stream(prof, 6, (200, 3000), seed=61)
+            runs += [(params.map_ont(), off, a), (params.make_params(max_skip=INT32_MAX, max_iter=1024), off, a)]
+    elif case == "fold-drivers":
+        tasks = fold_driver_tasks(rng)
+        for ms, gs in ((1, 1.0), (3, 0.8), (25, 1.0), (0, 1.0), (-1, 1.0), (300, 1.0)):
+            runs.append((params.make_params(max_skip=ms, gap_scale=gs), None, tasks))
+    elif case == "tile-paths":
+        tasks = []
+        for n, dup, dens in [(700, 0.0, 1), (900, 0.3, 1), (1300, 0.9, 2), (2500, 0.5, 6), (4000, 0.2, 10), (130, 0.97, 1), (3000, 0.0, 20)]:
+            step = np.where(rng.random(n) < dup, 0, rng.integers(1, 12 * dens + 2, n))
+            pos = (1 << 22) + np.cumsum(step)
+            q = 50 + np.cumsum(np.where(rng.random(n) < 0.15, rng.integers(-400, 400, n), rng.integers(0, 14 * dens, n)))
+            span = np.where(rng.random(n) < 0.5, 15, rng.integers(8, 40, n))
+            x = (np.uint64(1) << np.uint64(32)) | pos.astype(np.uint64)
+            y = (span.astype(np.uint64) << np.uint64(32)) | (np.maximum(q, 1).astype(np.uint64) & np.uint64(0xffffffff))
+            o = np.argsort(x, kind="stable")
+            tasks.append(np.stack((x[o], y[o]), 1))
+        for ms, gs, bw in ((25, 1.0, 500), (3, 1.0, 500), (25, 0.8, 500), (7, 1.0, 5000), (25, 1.0, 0), (25, 1.3, 600), (25, 1.0, -1), (1000, 1.0, 500)):
+            runs.append((params.make_params(max_skip=ms, gap_scale=gs, bw=bw), None, tasks))
+    elif case == "compact-corners":
+        P = params.map_ont()
+        tasks = []
+        for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("colinear", 2500, None), ("mixed", 1, None)]):
+            base = synth.make_stream(prof, 1, n, seed=770 + k, locus=locus)[1].numpy().view(np.uint64)
+            tasks += [respan_q(rng, base, 5000, mode) for mode in (0, 2, 4, 7)]
+        runs.append((P, None, tasks))
+    elif case == "random-scalars":
+        for seed in range(8):
+            r2 = np.random.default_rng(2000 + seed)
+            P = params.make_params(max_dist_x=int(r2.choice([50, 700, 5000, 100000])), max_dist_y=int(r2.choice([60, 700, 5000])), bw=int(r2.choice([0, 10, 500, 5000])),
+                                   max_skip=int(r2.choice([-1, 0, 1, 5, 25, 300, INT32_MAX])), max_iter=int(r2.choice([1, 63, 64, 65, 200, 1024, 5000, INT32_MAX])),
+                                   gap_scale=float(r2.choice([1.0, 1.0, 0.5, 2.25])))
+            runs.append((P, None, [_random_task(r2, int(r2.integers(1, 1500)), int(r2.integers(1, 4)), 1, bool(r2.integers(0, 2))) for _ in range(8)]))
+    elif case == "ava-ont":
+        off, a = _stream("mixed", 2, 6000, seed=62, locus=120000)
+        runs.append((params.ava_ont(), off, a))
+        off, a = _stream("dense", 2, 5000, seed=63, locus=9000)           # windows of 1 400 anchors: beyond the ring of 16 tiles
+        runs += [(params.map_ont(), off, a), (params.make_params(max_skip=INT32_MAX, max_iter=1024), off, a)]
+    else:
+        sizes = [1, 2, 63, 64, 65, 127, 128, 129, 1000, 0, 5, 4097]
+        tasks = [synth.make_stream("mixed", 1, max(n, 1), seed=900 + k)[1].numpy().view(np.uint64)[:n] for k, n in enumerate(sizes)]
+        runs.append((params.map_ont(), None, tasks))
+    for P, off, a in runs:
+        if off is None:
+            off = np.concatenate(([0], np.cumsum([t.shape[0] for t in a]))).astype(np.int64)
+            a = np.concatenate(a)
+        f_ref, p_ref = oracle_batch(P, off, a)
+        v = []
+        f, p = gpu_batch(P, off, a, variant=v)
+        assert_same(f, p, f_ref, p_ref, off, f"several waves per task, {case}, {params.as_dict(P)}: {v[0]}")
+        simple = P.gap_scale == 1.0 or P.bw <= 511
+        assert v[0].startswith("chain_dp_coop<W=8") == (simple and P.bw >= 0 and min(P.max_dist_x, P.max_dist_y) - 1 >= P.bw), (v, params.as_dict(P))
+
+
 @pytest.mark.parametrize("max_skip,far_ring", [(25, 1), (1000, 1), (1000, 0), (25, 2), (INT32_MAX, 1)])
 def test_far_lookback_in_partial_tail_tiles(max_skip, far_ring, knobs):
     """the last tile of a task holds cnt < 64 anchors; when their windows reach beyond the LDS ring the `far` instantiation of the hand-written
@@ -234,7 +301,7 @@ def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, w
     assert f"compact={compact}" in v[0] and "loop=asm" in v[0], v
 
 
-@pytest.mark.parametrize("entry", ["task", "batch", "mm_chain_dp_batch"])
+@pytest.mark.parametrize("entry", ["task", "batch", "mm_chain_dp_batch", "task-several-waves", "batch-several-waves"])
 def test_host_buffer_entries_take_the_compact_ring(entry, knobs):
     """The entries that move anchors and f / p (or chains) across PCIe -- mm2c_chain_task_host (the extended run_chaining_on_hw, chain.c:103),
     mm2c_chain_batch_host, its chunked pipeline and mm2c_mm_chain_dp_batch_host -- give their passes the prepass classes as plans do, so the
@@ -247,6 +314,10 @@ def test_host_buffer_entries_take_the_compact_ring(entry, knobs):
     max_dq = min(P.max_dist_x, P.max_dist_y)
     rng = np.random.default_rng(78)
     knobs("wide_share_threshold", 100)                       # the split between compact and 32-bit tasks always stands
+    coop = entry.endswith("several-waves")                   # a pass of few pieces takes chain_dp_coop by default; with it switched off, one wave per piece and the compact ring
+    knobs("coop_waves", 8 if coop else 0)
+    entry = entry.replace("-several-waves", "")
+    want = ("chain_dp_coop<W=8", "coop=8") if coop else ("compact=1", "loop=asm")
     tasks = []
     for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("colinear", 2500, None), ("mixed", 700, None), ("sparse", 500, None), ("mixed", 1, None)]):
         base = synth.make_stream(prof, 1, n, seed=990 + k, locus=locus)[1].numpy().view(np.uint64)
@@ -260,11 +331,11 @@ def test_host_buffer_entries_take_the_compact_ring(entry, knobs):
             t = tasks[k]
             f1, p1 = mm2chain.chain_task(P, t, ob.avg_qspan(t), tid=k)
             assert_same(f1, p1, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"task host, task {k}")
-            assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+            assert all(w in mm2chain.last_host_variant() for w in want), mm2chain.last_host_variant()
     elif entry == "batch":
         f, p = mm2chain.chain_batch_host(P, off, a)
         assert_same(f, p, f_ref, p_ref, off, entry)
-        assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+        assert all(w in mm2chain.last_host_variant() for w in want), mm2chain.last_host_variant()
     else:
         res = mm2chain.mm_chain_dp_batch(P, 3, 40, off, a)
         _assert_chains(res, P, 3, 40, off, a, "whole-function batch entry with the compact ring")
@@ -800,11 +871,12 @@ def knobs():
     import mm2chain
     yield mm2chain.tune
     for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
-                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256)):
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 0), ("coop_waves", 8), ("coop_max_tasks", 1024)):
         mm2chain.tune(key, val)
 
 
-@pytest.mark.parametrize("route", ["asm", "asm-32-bit-ring", "asm-tab", "asm-tab-32-bit-ring", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024"])
+@pytest.mark.parametrize("route", ["asm", "asm-32-bit-ring", "asm-tab", "asm-tab-32-bit-ring", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024",
+                                   "coop", "coop-tab", "coop-v2-scalars"])
 def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs):
     """The reference-produced vectors through the instantiations that carry the throughput.  With max_skip = 1023 and max_iter = 1024 the
     max-skip machinery of chain.c:226-233 is compiled in and runs (stamps, skip counter, the folds) but cannot fire: among at most 1024
@@ -820,14 +892,20 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
     if route == "asm-long-ring-only": knobs("far_ring", 2)
     if route == "asm-device-cut": knobs("plan_cut_min", 1000); knobs("seg_min", 64)
     if route.startswith("wave-"): knobs("ring_class", {"256": 0, "512": 1, "1024": 2}[route[5:]])
+    if route.startswith("coop"): knobs("coop_plans", 1)      # several waves per task (chain_dp_coop.h): what a lone run_chaining_on_hw call runs
+    if route == "coop-tab": knobs("force_tab", 1)
+    # coop-v2-scalars: the scalars of the reference symbol itself (max_skip = INT_MAX, max_iter = 1024), which the launcher maps onto max_skip = max_iter - 1
+    ms = INT32_MAX if route == "coop-v2-scalars" else 1023
     z, groups = _ref_cl_groups()
     assert (5000, 5000, 500) in groups and (10000, 10000, 2000) in groups
     n = 0
     for (mdx, mdy, bw), (off, a, f_ref, p_ref) in groups.items():
         v = []
-        f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=1023, max_iter=1024), off, a, variant=v)
+        f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=ms, max_iter=1024), off, a, variant=v)
         assert_same(f, p, f_ref, p_ref, off, f"{route}, scalars {(mdx, mdy, bw)}: {v[0]}")
-        if route.startswith("wave-"):
+        if route.startswith("coop"):
+            assert v[0].startswith("chain_dp_coop<W=8") and "FAR=1" in v[0] and "loop=asm" in v[0] and ("TAB=1" in v[0]) == (route == "coop-tab" and bw <= 511), v
+        elif route.startswith("wave-"):
             assert v[0].startswith(f"chain_dp_wave<R={route[5:]},SKIP=1"), v
         else:
             assert v[0].startswith("chain_dp_tile<") and "SKIP=1" in v[0] and "GEN=0" in v[0] and "FAR=1" in v[0] and "loop=asm" in v[0], v

@@ -80,6 +80,17 @@ def check(path, verbose=False):
         for name, lds in kernels_of(elf):
             # _ZN4mm2c13chain_dp_tileILi8ELi2ELb1ELb0ELb1ELb1ELb0ELb1EEEv...: <NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>
             m = re.match(r"_ZN4mm2c13chain_dp_tileILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])EEE", name)
+            mc = re.match(r"_ZN4mm2c13chain_dp_coopILi(\d+)ELb([01])ELb([01])ELb([01])EEE", name)
+            if mc:
+                # chain_dp_coop<W, GS1, FAR, TAB> (csrc/chain_dp_coop.h): the same hand-written loop over Lds<COOP_NX = 16, COOP_NF = 8, false, TAB, false>, with the
+                # per-anchor summaries (3 x 64 ints) behind the rings INSIDE the one LDS object
+                want = lds_bytes(16, 8, 0, int(mc.group(4)), 0) + 3 * 64 * 4
+                seen += 1
+                if verbose:
+                    print(f"{triple} chain_dp_coop<{','.join(mc.groups())}>: group segment {lds} B, rings + summaries {want} B")
+                if lds != want:
+                    bad.append((name, lds, want))
+                continue
             if not m:
                 continue
             nx, nf, _skip, gen, _gs1, _far, tab, c16 = (int(v) for v in m.groups())
