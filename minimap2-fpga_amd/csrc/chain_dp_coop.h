@@ -10,34 +10,35 @@
 //     computes the maximum of f[j] + score over the candidates, the nearest j winning ties (strict `>`, chain.c:226) -- an order-independent reduction.  That
 //     is every anchor of a V2 call (max_skip = INT_MAX, what run_chaining_on_hw computes) and the noise anchors of a V1 call, the ones whose scans run through
 //     their whole window; the anchors on a chain have many candidates, but their scans end after a tile or two.
-// So a workgroup of W waves shares the task's LDS rings, and per tile of 64 anchors:
-//   phase A, all waves, anchors dealt round robin: count the candidates of the anchor in its own tile and in the older tiles of its window (stopping as soon
-//            as the count passes max_skip) and reduce the older tiles' candidates to (best score, nearest index) -- summary per anchor in LDS;
-//   phase B, wave 0, anchor by anchor as before: an anchor whose count allows it folds its own-tile candidates (their f only becomes final here) as a plain
-//            maximum and merges the summary (the older tiles are farther: strict `>`); every other anchor -- too many candidates, a window that reaches
-//            beyond the ring, an equal-x run that reaches into the tile before -- takes the exact scan: the hand-written loop of chain_dp_tile (the anchors
-//            that take the short cut carry bit 31 of their tw word, "not for this loop") or its C++ restatement.
+// So a workgroup of W waves shares the task's LDS rings, and per tile of 64 anchors (lane L of every wave stands for the anchor i0 + 63 - L, as in chain_dp_tile):
+//   phase A, all waves, PAIRS dealt by candidate: a candidate j (its x, q, f as scalars) is scored against the 64 anchors of the tile at once, one anchor per
+//            lane -- filters, score, "inside this anchor's window" -- and each lane keeps the count of its candidates and the best (score, nearest index) among
+//            them.  The candidates of the older tiles (final f) go to the waves in units of 16; the own tile's 64 candidates have no final f yet, so for them
+//            the score WITHOUT f is stored as a 64 x 64 table in LDS.  Partial results per wave in LDS, merged by wave 0;
+//   phase B, wave 0, anchor by anchor as before: an anchor whose count allows the short cut starts from the older tiles' best (or its span) and gets its own-tile
+//            candidates PUSHED to it -- when anchor k becomes final, one table row + f[k] updates every later lane: a dependent chain of a few instructions per
+//            anchor instead of a chunk scan; every other anchor -- too many candidates, a window that reaches beyond the ring, an equal-x run that reaches into the
+//            tile before -- takes the exact scan: the hand-written loop of chain_dp_tile (the anchors that take the short cut carry bit 31 of their tw word,
+//            "not for this loop") or its C++ restatement.
 // Two workgroup barriers per tile; results bit-identical to chain_dp_tile (and so to chain.c:184-238): tests/test_gpu_parity.py runs the reference-kernel
 // vectors and the parity inputs through this kernel as another route.
 #ifndef MM2C_CHAIN_DP_COOP_H
 #define MM2C_CHAIN_DP_COOP_H
 #include "chain_dp_tile.h"
 
+#ifndef MM2C_COOP_PROBE
+#define MM2C_COOP_PROBE 0      // timing experiments (tools/probe_build.sh): 1 / 2 / 3 / 4 switch parts of the work off -- results are wrong then, never in the shipped library
+#endif
+
 namespace mm2c {
 
 constexpr int COOP_NX = 16, COOP_NF = 8;    // rings of the cooperative kernel: 960 anchors of look-back in LDS, f / p of the 8 nearest tiles beside them
 constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that must take the exact scan
 
-// wave-wide maximum of (score, index) with the larger index winning ties; every lane gets the result
-__device__ __forceinline__ void wave_max_pair(int &sc, int &j)
-{
-	long long key = ((long long)sc << 32) | (unsigned)j;             // lanes without a candidate: sc = SENT, the smallest key there is
-	for (int o = 32; o > 0; o >>= 1) {
-		const long long other = __shfl_xor(key, o);
-		key = other > key ? other : key;
-	}
-	sc = (int)(key >> 32); j = (int)(unsigned)key;
-}
+// LDS behind the rings: per anchor of the tile (= per lane) the best of the older tiles' candidates as one 64-bit key (score << 32 | index: the waves merge their
+// partial results with an LDS atomic maximum, equal scores -> the nearer index) and the candidate count (atomic add), then the own tile's table of pair scores
+// without f (64 x 64 ints, row = candidate, column = lane of the anchor)
+template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 64 * 8, PAIRS = CNTS + 64 * 4, BYTES = PAIRS + 64 * 64 * 4; };
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -50,9 +51,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	constexpr bool SKIP = true, GEN = false;
 	typedef Lds<NX, NF, GEN, TAB, false> LY;
 	constexpr int SN = LY::SN;
-	constexpr int SUM = LY::BYTES;                           // per anchor of the tile in progress: candidate count, best of the older tiles, its index
+	typedef CoopLds<W> CL;
 	const bool ASM = P.bw >= 0 && P.max_dq - 1 >= P.bw;     // the hand-written loop's three-instruction filter applies (every preset)
-	__shared__ __attribute__((aligned(16))) char lds[LY::BYTES + 3 * 64 * 4];   // the kernel's only LDS object: the assembly addresses the rings from 0
+	__shared__ __attribute__((aligned(16))) char lds[LY::BYTES + CL::BYTES];   // the kernel's only LDS object: the assembly addresses the rings from 0
 
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -95,7 +96,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v));
 	TileMem M;
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
-	int *const s_cnt = (int *)(lds + SUM), *const s_best = s_cnt + 64, *const s_j = s_cnt + 128;
+	long long *const s_key = (long long *)(lds + LY::BYTES + CL::KEYS);   // [lane] best (score, index) over the older tiles' candidates
+	int *const s_cnt = (int *)(lds + LY::BYTES + CL::CNTS);               // [lane] candidates in the whole window
+	int *const s_pair = (int *)(lds + LY::BYTES + CL::PAIRS);             // [candidate k of the own tile][lane]
 
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;
 	int seg0 = 0;
@@ -118,6 +121,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		const int stamp_lo = i0 - 64 * (NX - 1);
 		if (wv == 0) {
+			s_key[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt[lane] = 0;
 			for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 			const int o = (idx & (SN - 1)) * LY::XS;
 			*(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
@@ -157,129 +161,192 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 
 		__syncthreads();      // the rings hold x / q of this tile and f / p of the tiles before it (wave 0 wrote them); the summaries of the tile before have been read
 
-		// ---------------------------------------------------------------- phase A: candidate counts and the older tiles' best, anchors dealt to the waves
-		for (int k = wv; k < cnt; k += W) {
-			const int L = 63 - k, i = i0 + k;
-			const int lo = rdlane(lo_l, L), e = rdlane(e_l, L);
-			int c_tot = 0, b_old = SENT, j_old = -1;
-			if (i - lo > 0) {
-				if ((FAR && lo < stamp_lo) || e > k || no_pairs) c_tot = COOP_NEVER;     // window beyond the ring / equal-x run into the tile before: the exact scan
-				else {
-					const int xi1 = rdlane(own_x, L) - 1, qi1 = rdlane(own_q, L) - 1, span_i = rdlane(span_l, L);
-					X.xi1 = xi1; X.qi1 = qi1; X.span_i = span_i; X.span1_v = span_i - 1;
-					// own tile: anchors i-1-e .. max(lo, i0) sit in lanes L+1+e .. L+w (their f is not final yet: counted only)
-					const int w = min(k, i - lo);
-					if (w - e > 0) {
-						const mask_t m = (w - e >= 64 ? ~0ull : ((1ull << (w - e)) - 1)) << (L + 1 + e);
-						const int dr1 = xi1 - own_x, dq1 = qi1 - own_q;
-						mask_t same = ~0ull;
-						c_tot += (int)__builtin_popcountll(chunk_filter<GEN, false, false>(P, X, m, dr1, dq1, absdiff(dr1, dq1), 0, same));
+		// ---------------------------------------------------------------- phase A: every pair (candidate, anchor of this tile) once, a candidate per step, an anchor per lane
+		const int span1_l = span_l - 1;
+		// One pair (candidate with low word of x = xj, q = qj -> this lane's anchor): the filters chain.c:202-205 as the hand-written loop has them -- saturating
+		// subtraction against max_dq - 1 - bw, maximum with |dr - dq|, one compare with bw; dr == 0 (equal x) fails it too: dr - 1 is then 0xffffffff and either
+		// |dr - dq| or the subtraction is huge -- and the score without f[j] (chain.c:207-209,218; gap_scale 1 or the table).
+		auto pair_ok = [&](int dr1, int dq1, int dd) -> bool {
+			int m;
+			asm("v_max_u32 %0, %1, %2" : "=v"(m) : "v"(usat_sub(dq1, mdqbw_v)), "v"(dd));
+			return (unsigned)m <= (unsigned)X.bw_v;
+		};
+		auto pair_score0 = [&](int dr1, int dq1, int dd) -> int {
+			if (TAB) {
+				const int g = *(const int16_t *)(lds + LY::GAP + (min((unsigned)dd, 511u) << 1));
+				return min3i(dq1, dr1, span1_l) + g;
+			}
+			const int cz = __builtin_clz((unsigned)dd | 1u);
+			return min3i(dq1, dr1, span1_l) - 14 - (int)((float)dd * avg) + (cz >> 1);       // min(dq, dr, span) - (lin + (ilog2(dd) >> 1)): 1 - 15 = -14
+		};
+		{
+			int best_l = SENT, jb_l = -1, cnt_l = 0;
+			// ---- the older tiles: candidates i0 - 1 down to the start of the first anchor's window (st[] is monotone) or of the ring, in units of 8 dealt to the waves
+			// (an anchor with equal-x predecessors in an older tile never takes the short cut, so dr == 0 needs no thought here)
+			const int lo_first = rdlane(lo_l, 63);
+			const int jmin = max(max(lo_first, stamp_lo), 0);
+			const int n_units = (i0 - jmin + 7) >> 3;
+#if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
+			if (0)
+#endif
+			for (int u = wv; u < n_units; u += W) {
+				const int jl = i0 - 1 - 8 * u - (lane & 7);          // lanes 0 .. 7 fetch the unit's candidates
+				int xv = 0, qv = 0, fv = 0;
+				if (lane < 8 && jl >= jmin) {
+					const int2 xq = *(const int2 *)(lds + LY::XQ + (jl & (SN - 1)) * 8);
+					xv = xq.x; qv = xq.y;
+					if ((i0 >> 6) - (jl >> 6) <= NF) fv = ((const int2 *)(lds + LY::FP + ((jl << 3) & LY::FMASK)))->x + FBIAS;
+					else fv = __hip_atomic_load(&f[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				const int n_here = min(8, i0 - jmin - 8 * u);
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					if (t < n_here) {
+						const int j = i0 - 1 - 8 * u - t;
+						const int dr1 = tx1_l - rdlane(xv, t), dq1 = tq1_l - rdlane(qv, t);
+						const int dd = absdiff(dr1, dq1);
+						const bool ok = pair_ok(dr1, dq1, dd) && j >= lo_l;
+						const int sc = ok ? pair_score0(dr1, dq1, dd) + rdlane(fv, t) : SENT;
+						cnt_l += ok ? 1 : 0;
+						const bool take = sc > best_l;             // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
+						best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
 					}
-					// older tiles, nearest first; a count beyond max_skip settles it (the exact scan will run): stop there
-					const int before = i0 - lo;
-					int best_l = SENT, j_l = -1;
-					if (before > 0) {
-						const int n_full = before >> 6, part = before & 63;
-						int base = i0 - 64, depth = 1, addr = addr0;
-						for (int c = n_full + (part ? 1 : 0); c > 0 && (int64_t)c_tot <= (int64_t)P.max_skip; --c) {
-							int dr1, dq1;
-							ring_dr_dq<LY>(X, M, addr, dr1, dq1);
-							const int dd = absdiff(dr1, dq1);
-							mask_t same = ~0ull;
-							const mask_t in_w = (c == 1 && part) ? first_lanes(part) : ~0ull;
-							const mask_t valid = chunk_filter<GEN, false, false>(P, X, in_w, dr1, dq1, dd, 0, same);
-							if (valid != 0) {
-								c_tot += (int)__builtin_popcountll(valid);
-								int fj, pj;
-								ring_fp<LY, NF>(M, addr, depth, base, rl, fj, pj);
-								int sc;
-								if (TAB) {
-									const int g = *(const int16_t *)(lds + LY::GAP + (min((unsigned)dd, 511u) << 1));
-									sc = add3i(min3i(dq1, dr1, X.span1_v), fj, g);
-								} else sc = pair_score<GEN, GS1>(P, avg, dr1 + 1, dq1 + 1, dd, same, span_i) + fj;
-								if ((valid >> lane & 1) && sc > best_l) { best_l = sc; j_l = base + rl; }   // strict: a nearer tile keeps a tie (chain.c:226)
-							}
-							addr = (addr - LY::TILE) & (LY::RB - 1);
-							base -= 64; ++depth;
-						}
-					}
-					if ((int64_t)c_tot <= (int64_t)P.max_skip) { wave_max_pair(best_l, j_l); b_old = best_l; j_old = j_l; }
-					else c_tot = COOP_NEVER;
 				}
 			}
-			if (lane == 0) { s_cnt[k] = c_tot; s_best[k] = b_old; s_j[k] = j_old; }
+			// ---- the own tile: its candidates' f is not final, so the score without f goes to the table (SENT: not a candidate of this lane's anchor)
+#if MM2C_COOP_PROBE == 2 || MM2C_COOP_PROBE == 4
+			if (0)
+#endif
+			for (int k = wv; k < cnt; k += W) {
+				const int Lk = 63 - k;
+				const int dr1 = tx1_l - rdlane(own_x, Lk), dq1 = tq1_l - rdlane(own_q, Lk);
+				const int dd = absdiff(dr1, dq1);
+				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && i0 + k >= lo_l && lane < Lk;
+				cnt_l += ok ? 1 : 0;
+				s_pair[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd) : SENT;
+			}
+			if (BALLOT(cnt_l != 0) != 0) {
+				if (best_l != SENT) __hip_atomic_fetch_max(&s_key[lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt[lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 		}
 		__syncthreads();
 
 		// ---------------------------------------------------------------- phase B: wave 0 walks the tile's anchors; the other waves go on to the next barrier
+		// An anchor that takes the short cut only needs the maximum over its candidates, so its own-tile candidates are PUSHED to it: when anchor k is final, every
+		// later short-cut anchor of the tile (one per lane) scores the pair (k -> itself) and keeps the better of the two -- the dependent chain per anchor is
+		// read f[k], add, compare, instead of a whole chunk scan.  Candidates arrive in ascending j, the reference scans in descending j and keeps the first of
+		// equal scores (strict `>`, chain.c:226): so an equal score from a later (nearer) candidate replaces an earlier one, but never the anchor's own span
+		// (p = -1), which only a strictly better score beats.
 		if (wv == 0) {
-			const int c_l = rl < cnt ? s_cnt[rl] : 0, bo_l = rl < cnt ? s_best[rl] : SENT, jo_l = rl < cnt ? s_j[rl] : -1;   // lane L: the summary of anchor i0 + 63 - L
-			// the anchors that take the short cut: at most max_skip candidates in the whole window -> chain.c:231 cannot fire (max_skip < 0: only anchors without any)
-			const bool short_l = (int64_t)c_l <= (int64_t)P.max_skip && lo_l < idx && rl < cnt;
+			const long long key = s_key[lane];                  // this lane's anchor: best of the older tiles' candidates (score << 32 | index), candidates in the whole window
+			const int bo_l = (int)(key >> 32), jo_l = (int)(unsigned)key, c_l = s_cnt[lane];
+			// the anchors that take the short cut: at most max_skip candidates in the whole window -> chain.c:231 cannot fire (max_skip < 0: none); not those whose
+			// window reaches beyond the ring or whose equal-x run reaches into the tile before (the exact scan knows how)
+			const bool short_l = (int64_t)c_l <= (int64_t)P.max_skip && lo_l < idx && rl < cnt && !(FAR && lo_l < stamp_lo) && e_l <= rl && !no_pairs;
 			const mask_t shorts = BALLOT(short_l);
 			if (short_l) tw_l |= (int)0x80000000;               // "not for the hand-written loop": it hands these anchors back
 			const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
-			for (int k = 0; k < cnt; ++k) {
+			int acc_f = bo_l > span_l ? bo_l : span_l, acc_p = bo_l > span_l ? jo_l : -1;   // short-cut lanes: best so far = the older tiles' best or the span (chain.c:188)
+			// candidate k (final) -> the short-cut anchors after it (lanes below 63 - k) whose window holds it
+			// A short-cut anchor's result IS its accumulator once every earlier anchor of the tile has been pushed; it is copied into the own-tile registers
+			// (what the exact scans read, and what leaves the tile) for all such lanes at once, before an exact scan runs and at the end of the tile.
+			mask_t copied = 0;                                   // short-cut lanes whose accumulators have been copied into own_f / own_p
+			auto flush = [&](int k_done) {                       // anchors 0 .. k_done - 1 are final
+				const mask_t fin = shorts & (k_done >= 64 ? ~0ull : ~(~0ull >> k_done)) & ~copied;   // lanes 63 .. 64 - k_done
+				if (fin == 0) return;
+				own_f = sel(fin, own_f, acc_f); own_p = sel(fin, own_p, acc_p);
+				copied |= fin;
+			};
+			// A whole tile of short-cut anchors (every tile of a V2 call; the tiles of a V1 call without a chain in them): the 64 pushes as straight-line code --
+			// the lane that holds f[k] is a constant of the instruction, the table rows come in ahead of their use, and what is left of the walk from one anchor
+			// to the next is read a lane, add, maximum.
+			const bool all_short = cnt == 64 && shorts == ~0ull;
+#if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
+			if (all_short) {
+#pragma unroll
+				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
+					const int row_k = s_pair[k * 64 + lane];
+					const int sc = row_k != SENT ? row_k + rdlane(acc_f, 63 - k) : SENT;
+					const bool take = sc > acc_f || (sc == acc_f && acc_p >= 0 && row_k != SENT);
+					acc_p = take ? i0 + k : acc_p;
+					acc_f = max(acc_f, sc);
+				}
+			}
+#endif
+			int row = cnt > 0 ? s_pair[lane] : SENT;             // row k of the pair table, requested one anchor ahead
+			for (int k = all_short ? cnt : 0; k < cnt;) {
 				const int L = 63 - k;
-				if (!(shorts >> L & 1) && ASM) {
+				const mask_t later = shorts & (L > 0 ? ~0ull >> (64 - L) : 0ull);
+				if (shorts >> L & 1) {
+					// ---- the short cut: everything that can reach this anchor has been pushed; push it on (candidate k -> the short-cut anchors after it)
+					const int row_k = row;
+					if (k + 1 < cnt) row = s_pair[(k + 1) * 64 + lane];
+#if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
+					if (later != 0) {
+						// the chain from one anchor to the next is: read f[k] (a lane of acc_f), add, maximum; who holds the maximum (the index) is settled beside it
+						const int sc = row_k != SENT ? row_k + rdlane(acc_f, L) : SENT;
+						const bool take = sc > acc_f || (sc == acc_f && acc_p >= 0 && row_k != SENT);
+						acc_p = take ? i0 + k : acc_p;
+						acc_f = max(acc_f, sc);
+					}
+#endif
+					++k;
+					continue;
+				}
+				flush(k);
+				int k2 = k;
+				if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
                                  LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v MM2C_LC_ARG)
 #ifdef MM2C_LABEL_COUNT
 					int lc_v = 0;
 #endif
-					if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
-					else k = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
+					if (FAR && tile_far) k2 = TAB ? MM2C_CALL(scan_tile_asm_tab_far, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far, lo_l);
+					else k2 = TAB ? MM2C_CALL(scan_tile_asm_tab, lo_l) : MM2C_CALL(scan_tile_asm_cmp, lo_l);
 #undef MM2C_CALL
-					k = __builtin_amdgcn_readfirstlane(k);
-					if (k >= cnt) break;
+					k2 = __builtin_amdgcn_readfirstlane(k2);
 				}
-				const int Lk = 63 - k;
-				const int i = i0 + k;
-				const int xi = rdlane(own_x, Lk), qi = rdlane(own_q, Lk);
-				const int span_i = rdlane(span_l, Lk);
-				const int lo = rdlane(lo_l, Lk);
-				Carry c = { span_i, -1, 0 };                                                         // chain.c:188-190
-				if (i - lo > 0) {
-					X.xi1 = xi - 1; X.qi1 = qi - 1; X.span_i = span_i; X.span1_v = span_i - 1;
-					if (shorts >> Lk & 1) {
-						// ---- the short cut: maximum over the own-tile candidates (scan order = ascending lane, the nearest wins ties), then the older tiles' best
-						const int e = rdlane(e_l, Lk);
-						const int w = min(k, i - lo);
-						if (w - e > 0) {
-							const mask_t m = (w - e >= 64 ? ~0ull : ((1ull << (w - e)) - 1)) << (Lk + 1 + e);
-							const int dr1 = X.xi1 - own_x, dq1 = X.qi1 - own_q;
-							const int dd = absdiff(dr1, dq1);
-							mask_t same = ~0ull;
-							const mask_t valid = chunk_filter<GEN, false, false>(P, X, m, dr1, dq1, dd, 0, same);
-							if (valid != 0) {
-								int sc;
-								if (TAB) {
-									const int g = *(const int16_t *)(lds + LY::GAP + (min((unsigned)dd, 511u) << 1));
-									sc = add3i(min3i(dq1, dr1, X.span1_v), own_f, g);
-								} else sc = pair_score<GEN, GS1>(P, avg, dr1 + 1, dq1 + 1, dd, same, span_i) + own_f;
-								const int scv = sel(valid, SENT, sc);
-								const int mc = rdlane(prefix_max_incl(scv), 63);
-								if (mc > c.best) { c.best = mc; c.best_j = i0 + 63 - (int)__builtin_ctzll(BALLOT(scv == mc)); }
-							}
-						}
-						const int bo = rdlane(bo_l, Lk);
-						if (bo > c.best) { c.best = bo; c.best_j = rdlane(jo_l, Lk); }               // the older tiles are farther: strict
-					} else {
+				if (k2 == k) {
+					// ---- an anchor the hand-written loop does not take (or no hand-written loop for these scalars): the C++ restatement of the exact scan
+					const int i = i0 + k;
+					const int xi = rdlane(own_x, L), qi = rdlane(own_q, L);
+					const int span_i = rdlane(span_l, L);
+					const int lo = rdlane(lo_l, L);
+					Carry c = { span_i, -1, 0 };                                                     // chain.c:188-190
+					if (i - lo > 0) {
+						X.xi1 = xi - 1; X.qi1 = qi - 1; X.span_i = span_i; X.span1_v = span_i - 1;
 						mask_t eq_run = 0; bool dr0 = false;
 						if (eq_prev != 0) {
-							const mask_t r = eq_prev >> Lk;
+							const mask_t r = eq_prev >> L;
 							const int e = (int)__builtin_ctzll(~r);
 							if (e > k) dr0 = true;
-							else if (e > 0) eq_run = ((1ull << e) - 1) << (Lk + 1);
+							else if (e > 0) eq_run = ((1ull << e) - 1) << (L + 1);
 						}
 						X.lo = lo; X.stamp = i + 1; X.s16 = 1 + k; X.s16_v = X.s16;
 						X.far_mode = FAR && lo < stamp_lo;
 						if (!dr0) scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, false, false>(P, X, M, lane, i0, k, eq_run, own_x, own_q, own_g, own_f, own_p, addr0, c);
 						else scan_anchor<NX, NF, SKIP, GEN, GS1, FAR, TAB, true, false>(P, X, M, lane, i0, k, 0, own_x, own_q, own_g, own_f, own_p, addr0, c);
 					}
+					write_lane2(own_f, own_p, __builtin_amdgcn_readfirstlane(c.best), __builtin_amdgcn_readfirstlane(c.best_j), L);
+					k2 = k + 1;
 				}
-				write_lane2(own_f, own_p, __builtin_amdgcn_readfirstlane(c.best), __builtin_amdgcn_readfirstlane(c.best_j), Lk);
+				// the anchors just made final by an exact scan, pushed to the short-cut anchors after them
+#if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
+				for (int kk = k; kk < k2 && kk < cnt; ++kk) {
+					const int Lk = 63 - kk;
+					if ((shorts & (Lk > 0 ? ~0ull >> (64 - Lk) : 0ull)) == 0) break;
+					const int s0 = s_pair[kk * 64 + lane];
+					const int sc = s0 + rdlane(own_f, Lk);
+					const bool take = s0 != SENT && (sc > acc_f || (sc == acc_f && acc_p >= 0));
+					acc_f = take ? sc : acc_f;
+					acc_p = take ? i0 + kk : acc_p;
+				}
+#endif
+				k = k2;
+				if (k < cnt) row = s_pair[k * 64 + lane];
 			}
+			flush(64);
 			// ---- the finished tile: results leave in coalesced stores and enter the f / p ring
 			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 			const int o = (idx << 3) & LY::FMASK;

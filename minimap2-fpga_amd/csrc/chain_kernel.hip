@@ -693,7 +693,7 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 }
 
 // ---- several waves per task (chain_dp_coop.h): passes too small to fill the GPU with one wave per task; the variants of the hand-written loop only
-constexpr int COOP_W = 8;
+constexpr int COOP_W = 16;
 static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged)
 {
 	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);

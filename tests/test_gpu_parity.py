@@ -223,7 +223,7 @@ def test_several_waves_per_task_equal_the_oracle(case, knobs):
         f, p = gpu_batch(P, off, a, variant=v)
         assert_same(f, p, f_ref, p_ref, off, f"several waves per task, {case}, {params.as_dict(P)}: {v[0]}")
         simple = P.gap_scale == 1.0 or P.bw <= 511
-        assert v[0].startswith("chain_dp_coop<W=8") == (simple and P.bw >= 0 and min(P.max_dist_x, P.max_dist_y) - 1 >= P.bw), (v, params.as_dict(P))
+        assert v[0].startswith("chain_dp_coop<W=16") == (simple and P.bw >= 0 and min(P.max_dist_x, P.max_dist_y) - 1 >= P.bw), (v, params.as_dict(P))
 
 
 @pytest.mark.parametrize("max_skip,far_ring", [(25, 1), (1000, 1), (1000, 0), (25, 2), (INT32_MAX, 1)])
@@ -317,7 +317,7 @@ def test_host_buffer_entries_take_the_compact_ring(entry, knobs):
     coop = entry.endswith("several-waves")                   # a pass of few pieces takes chain_dp_coop by default; with it switched off, one wave per piece and the compact ring
     knobs("coop_waves", 8 if coop else 0)
     entry = entry.replace("-several-waves", "")
-    want = ("chain_dp_coop<W=8", "coop=8") if coop else ("compact=1", "loop=asm")
+    want = ("chain_dp_coop<W=16", "coop=16") if coop else ("compact=1", "loop=asm")
     tasks = []
     for k, (prof, n, locus) in enumerate([("mixed", 3000, None), ("dense", 4000, 20000), ("colinear", 2500, None), ("mixed", 700, None), ("sparse", 500, None), ("mixed", 1, None)]):
         base = synth.make_stream(prof, 1, n, seed=990 + k, locus=locus)[1].numpy().view(np.uint64)
@@ -904,7 +904,7 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
         f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=ms, max_iter=1024), off, a, variant=v)
         assert_same(f, p, f_ref, p_ref, off, f"{route}, scalars {(mdx, mdy, bw)}: {v[0]}")
         if route.startswith("coop"):
-            assert v[0].startswith("chain_dp_coop<W=8") and "FAR=1" in v[0] and "loop=asm" in v[0] and ("TAB=1" in v[0]) == (route == "coop-tab" and bw <= 511), v
+            assert v[0].startswith("chain_dp_coop<W=16") and "FAR=1" in v[0] and "loop=asm" in v[0] and ("TAB=1" in v[0]) == (route == "coop-tab" and bw <= 511), v
         elif route.startswith("wave-"):
             assert v[0].startswith(f"chain_dp_wave<R={route[5:]},SKIP=1"), v
         else:
