@@ -33,6 +33,10 @@
 //     (chain_kernel.hip), which is faster for it.
 #ifndef MM2C_CHAIN_DP_TILE_H
 #define MM2C_CHAIN_DP_TILE_H
+#ifndef MM2C_DEEP_PREFETCH
+#define MM2C_DEEP_PREFETCH 0     // 1: the 32-bit ring forms of the hand-written loop request the deep f / p of the next tile ahead (MM2C_FG_W).  Measured in round 4 and
+                                 // left off: slower on every stream (ava-ont mixed 90.3 -> 92.2 ms, dense ragged 85.2 -> 87.8, colinear 25.7 -> 26.1)
+#endif
 #include "chain_wave.h"
 
 namespace mm2c {
@@ -579,6 +583,60 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #ifndef MM2C_PROBE_LOOP
 #define MM2C_PROBE_LOOP ""
 #endif
+// ---- f / p of a scored ring tile deeper than the f / p ring: from L2 (the task's own earlier stores), the score computed while they are on their way.
+// MM2C_FG_PLAIN: request, score, wait.  MM2C_FG_W (the 32-bit ring forms; the compact form has no registers to spare under its launch bound): the values of the
+// NEXT tile of the window are requested as soon as this tile's are in, into a second register pair, keyed by the tile's first anchor (bpre) -- a deep tile
+// that follows a scored one (the usual case on a noisy long read: ava-ont streams, 1.5 deep tiles per anchor) then finds its f / p already there, or on their
+// way since the fold of the tile before began.  The values belong to a finished tile, so they stay good for the following anchors of the own tile as well.
+// Every wait in the block is vmcnt(0), so the extra loads in flight change no other wait; nothing is in flight at Lexit.
+#define MM2C_R_F2 "v58"
+#define MM2C_R_P2 "v59"
+#define MM2C_FG_CLOB_PF0
+#define MM2C_FG_CLOB_PF2 , MM2C_R_F2, MM2C_R_P2
+#define MM2C_FG_CLOB(SEL) MM2C_FG_CLOB_##SEL      /* (a name, pasted here: a clobber list as a macro argument would fall apart at its commas) */
+#define MM2C_FG_PLAIN(SCORE) \
+	"s_lshl_b32 %[t0], %[d], 6\n\t" \
+	"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+	"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+	"v_max_i32 %[u2], 0, %[u2]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+	"global_load_dword " MM2C_R_P ", %[u2], %[pptr] sc0\n\t" \
+	"global_load_dword " MM2C_R_F ", %[u2], %[fptr] sc0\n\t" \
+	SCORE \
+	"s_waitcnt vmcnt(0)\n\t"
+#if MM2C_DEEP_PREFETCH
+#define MM2C_FG_W(SCORE) \
+	"s_lshl_b32 %[t0], %[d], 6\n\t" \
+	"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
+	"s_cmp_eq_u32 %[base], %[bpre]\n\t" \
+	"s_cbranch_scc1 Lfgh_%=\n\t" \
+	"v_add_u32 %[u2], %[base], %[rl]\n\t" \
+	"v_max_i32 %[u2], 0, %[u2]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+	"global_load_dword " MM2C_R_P ", %[u2], %[pptr] sc0\n\t" \
+	"global_load_dword " MM2C_R_F ", %[u2], %[fptr] sc0\n\t" \
+	SCORE \
+	"s_waitcnt vmcnt(0)\n\t" \
+	"s_branch Lfgp_%=\n" \
+	"Lfgh_%=:\n\t" \
+	SCORE \
+	"s_waitcnt vmcnt(0)\n\t" \
+	"v_mov_b32 " MM2C_R_P ", " MM2C_R_P2 "\n\t" \
+	"v_mov_b32 " MM2C_R_F ", " MM2C_R_F2 "\n" \
+	"Lfgp_%=:\n\t" \
+	"s_or_b32 %[t0], %[n], %[part]\n\t"            /* whole tiles left + lanes of the partly covered one: anything further back in this window? */ \
+	"s_cbranch_scc0 Lfgx_%=\n\t" \
+	"s_sub_i32 %[bpre], %[base], 64\n\t" \
+	"v_add_u32 %[u2], %[bpre], %[rl]\n\t" \
+	"v_max_i32 %[u2], 0, %[u2]\n\t" \
+	"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
+	"global_load_dword " MM2C_R_P2 ", %[u2], %[pptr] sc0\n\t" \
+	"global_load_dword " MM2C_R_F2 ", %[u2], %[fptr] sc0\n" \
+	"Lfgx_%=:\n\t"
+#else
+#define MM2C_FG_W(SCORE) MM2C_FG_PLAIN(SCORE)
+#endif
+
 // Label counters (-DMM2C_LABEL_COUNT: minimap2-fpga_amd/variants/labelcount.so, never the shipped library): MM2C_LC(bit) adds one to lane `bit` of the
 // per-wave register `lc` wherever the block passes -- at the labels of the assembly and on the fall-through side of the branches that pick a fold -- so that the
 // GPU test tests/test_gpu_labels.py can show that the parity inputs drive every path of the REAL instruction sequence (the kernel adds `lc` to
@@ -629,7 +687,7 @@ __device__ unsigned long long g_label_hits[8 * 32];   // row = compact << 2 | ta
 #define MM2C_LB_FOLD "0x10000000"
 #define MM2C_LB_DONE "0x20000000"
 #define MM2C_LB_SPEC "0x40000000"
-#define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, OWNFILTER, FARFILTER, RDXQ, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
+#define MM2C_SCAN_TILE_ASM(NAME, TABV, C16V, XQ1, NEXT_XQ, RFILTER, OLDADDR, BACK, OWNFILTER, FARFILTER, RDXQ, SEG_FG, CLOB, SCORE, ADDF, SEG_RD, SEG_LK, SEG_HF, SEG_TAIL, SEG_END, SEG_DONE, LNEXT) \
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
@@ -637,11 +695,12 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 { \
 	typedef Lds<NX, NF, false, TABV, C16V> LY; \
 	typedef Lds<NX, NF, false, true, C16V> LYT; \
-	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, c, pk, lo, lo0, xi1, qi1, span1, s16, d, fb; \
+	int best, bestj, nskip, n, nfull, part, base, t0, t1, last, c, pk, lo, lo0, xi1, qi1, span1, s16, d, fb, bpre; \
 	mask_t mask, valid, mk, marked, nm, se, ex, oh, pr; (void)pr; \
 	int dr, dq, dd, u1, u2, sc, va, vb, vc, addr, s16v, lom1v, fx, fq; \
 	asm volatile( \
 		"s_mov_b64 %[ex], exec\n\t" \
+		"s_mov_b32 %[bpre], 0x7fffffff\n\t"       /* no tile's deep f / p has been requested ahead (MM2C_FG_W) */ \
 		"s_sub_i32 %[c], %[kstart], %[cnt]\n\t"    /* the anchor counter: position in the tile - anchors of the tile, in [-64, -1]; its carry ends the loop and its low byte is the LDS stamp */ \
 		"s_sub_i32 %[t0], 63, %[kstart]\n\t" \
 		"s_lshl_b64 %[mask], 1, %[t0]\n\t" \
@@ -714,15 +773,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		SEG_TAIL \
 		"Lfg_%=:\n\t" \
 		MM2C_LC(MM2C_LB_FG) \
-		"s_lshl_b32 %[t0], %[d], 6\n\t" \
-		"s_sub_i32 %[base], %[i0], %[t0]\n\t" \
-		"v_add_u32 %[u2], %[base], %[rl]\n\t" \
-		"v_max_i32 %[u2], 0, %[u2]\n\t" \
-		"v_lshlrev_b32 %[u2], 2, %[u2]\n\t" \
-		"global_load_dword " MM2C_R_P ", %[u2], %[pptr] sc0\n\t" \
-		"global_load_dword " MM2C_R_F ", %[u2], %[fptr] sc0\n\t" \
-		SCORE \
-		"s_waitcnt vmcnt(0)\n\t" \
+		SEG_FG(SCORE) \
 		"v_subrev_u32 " MM2C_R_P ", %[pbase], " MM2C_R_P "\n\t" \
 		"v_max_i32 " MM2C_R_P ", -1, " MM2C_R_P "\n\t" \
 		"v_add_u32 " MM2C_R_F ", -14, " MM2C_R_F "\n\t" \
@@ -913,7 +964,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		"s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
 		: [best] "=&s"(best), [bestj] "=&s"(bestj), [nskip] "=&s"(nskip), [n] "=&s"(n), [nfull] "=&s"(nfull), [part] "=&s"(part), [base] "=&s"(base), \
 		  [t0] "=&s"(t0), [t1] "=&s"(t1), [last] "=&s"(last), [c] "=&s"(c), [pk] "=&s"(pk), [lo] "=&s"(lo), [xi1] "=&s"(xi1), [qi1] "=&s"(qi1), \
-		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), \
+		  [span1] "=&s"(span1), [s16] "=&s"(s16), [d] "=&s"(d), [lo0] "=&s"(lo0), [fb] "=&s"(fb), [bpre] "=&s"(bpre), \
 		  [mask] "=&s"(mask), [valid] "=&s"(valid), [mk] "=&s"(mk), [marked] "=&s"(marked), [nm] "=&s"(nm), [se] "=&s"(se), [ex] "=&s"(ex), [oh] "=&s"(oh), \
 		  [dr] "=&v"(dr), [dq] "=&v"(dq), [dd] "=&v"(dd), [u1] "=&v"(u1), [u2] "=&v"(u2), \
 		  [sc] "=&v"(sc), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [addr] "=&v"(addr), [s16v] "=&v"(s16v), [lom1v] "=&v"(lom1v), [fx] "=&v"(fx), [fq] "=&v"(fq), \
@@ -923,14 +974,14 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		  [addr1] "v"(addr1), [addr2] "v"(addr2), [lomc] "v"(lomc), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
 		  [XQOFF] "n"(LY::XQ), [FPOFF] "n"(LY::FP), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [SBITS] "n"(LY::SBITS), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
-		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P); \
+		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P MM2C_FG_CLOB(CLOB)); \
 	return cnt + c; \
 }
 
 // two instantiations of each: `lean` for tiles in which no window reaches beyond the LDS ring (no test for it anywhere in the loop, stamps written
 // without touching exec), `far` for the others
-#define MM2C_RING_W MM2C_XQ1_W, MM2C_NEXT_XQ_W, MM2C_RFILTER_W, MM2C_OLDADDR_W, MM2C_BACK_W, MM2C_OWNFILTER_W, MM2C_FARFILTER_W, MM2C_RDXQ_W
-#define MM2C_RING_C MM2C_XQ1_C, MM2C_NEXT_XQ_C, MM2C_RFILTER_C, MM2C_OLDADDR_C, MM2C_BACK_C, MM2C_OWNFILTER_C, MM2C_FARFILTER_C, MM2C_RDXQ_C
+#define MM2C_RING_W MM2C_XQ1_W, MM2C_NEXT_XQ_W, MM2C_RFILTER_W, MM2C_OLDADDR_W, MM2C_BACK_W, MM2C_OWNFILTER_W, MM2C_FARFILTER_W, MM2C_RDXQ_W, MM2C_FG_W, PF2
+#define MM2C_RING_C MM2C_XQ1_C, MM2C_NEXT_XQ_C, MM2C_RFILTER_C, MM2C_OLDADDR_C, MM2C_BACK_C, MM2C_OWNFILTER_C, MM2C_FARFILTER_C, MM2C_RDXQ_C, MM2C_FG_PLAIN, PF0
 #define MM2C_SCAN_TILE_ASM_(...) MM2C_SCAN_TILE_ASM(__VA_ARGS__)
 #define MM2C_LEAN MM2C_RD_LEAN, MM2C_LK_LEAN, MM2C_HF_LEAN, MM2C_TAIL_LEAN, MM2C_END_LEAN, "", "Lloop_%="
 #define MM2C_FARS MM2C_RD_FAR, MM2C_LK_FAR, MM2C_HF_FAR, MM2C_TAIL_FAR, MM2C_END_FAR, MM2C_DONE_FAR, "Lret_%="
