@@ -36,6 +36,8 @@ for r in range(rounds):
     mm2chain.tune("split_streams", int(rng.choice([1, 2, 2, 0])))
     mm2chain.tune("noskip_loop", int(rng.choice([1, 1, 0])))     # max_skip >= max_iter: through the hand-written loop with max_skip = max_iter - 1, or the C++ loop without the machinery
     mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 4, 4, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
+    # several waves per task (chain_dp_coop.h): always with MM2C_SOAK_COOP set, else in a third of the rounds
+    mm2chain.tune("coop_plans", 1 if os.environ.get("MM2C_SOAK_COOP") or rng.random() < 0.33 else 0)
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
         kind = rng.random()
@@ -58,5 +60,5 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1)
+mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1); mm2chain.tune("coop_plans", 0)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
