@@ -808,11 +808,11 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	const unsigned c16_bound = tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u;
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
-	                   tile ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile ? L.d_cls_stat : (unsigned long long *)nullptr,
-	                   c16_bound);
+	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr,
+	                   coop ? 0u : c16_bound);                    // (the cooperative kernel has one ring form: no classes to find)
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
-	if (e == hipSuccess && tile && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {
+	if (e == hipSuccess && tile && !coop && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {
 		hipLaunchKernelGGL(chain_cls_settle, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_cls, L.d_cls_stat, L.far_ring == 1 ? 1 : 0,
 		                   c16_bound != 0 ? L.wide_pct : 100);
 		e = hipGetLastError();

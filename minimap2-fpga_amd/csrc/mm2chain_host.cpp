@@ -40,6 +40,10 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	std::vector<int64_t> seg_off; std::vector<int32_t> pbase, order; std::vector<float> seg_avg;
 	seg_off.reserve((size_t)n_tasks_all + 16); pbase.reserve((size_t)n_tasks_all + 16); seg_avg.reserve((size_t)n_tasks_all + 16);
 	int64_t g0 = 0;                                                // where this request's anchors start in the arena
+	// while the cutting pass looks at every anchor anyway: does any task hold more than one segment id (mmpriv.h:22-23)?  If none does, the pass runs with the ids
+	// ignored -- the same f / p, chain.c:202-206 only looks at whether two ids are EQUAL -- and needs neither the kernel's per-tile check nor the launch that redoes
+	// flagged tasks with the general variant
+	bool one_seg_each = seg_min > 0;
 	for (int r = 0; r < n_req; ++r) {
 		const HostReq &q = *reqs[r];
 		const int64_t base = q.off[0];
@@ -55,11 +59,18 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 				avg = (float)(.01 * (float)sum / (t1 - t0));
 			}
 			int64_t s0 = t0;
-			for (int64_t i = t0 + 1; i < t1; ++i)
-				if (seg_min > 0 && i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
-					seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
-					s0 = i;
+			if (seg_min > 0) {
+				const uint64_t seg_first = a[t0].y >> 48 & 0xff;
+				uint64_t seg_diff = 0;
+				for (int64_t i = t0 + 1; i < t1; ++i) {
+					seg_diff |= (a[i].y >> 48 & 0xff) ^ seg_first;
+					if (i - s0 >= seg_min && a[i].x > a[i - 1].x + D) {
+						seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
+						s0 = i;
+					}
 				}
+				if (seg_diff) one_seg_each = false;
+			}
 			seg_off.push_back(g0 + s0); pbase.push_back((int32_t)(s0 - t0)); seg_avg.push_back(avg);
 		}
 		g0 += q.off[q.n_tasks] - base;
@@ -186,6 +197,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 	// a pass of few pieces (a lone call, a handful of combined calls) cannot fill the GPU with one wave per piece: several waves per piece (chain_dp_coop.h)
 	L.coop_waves = n_seg <= G.coop_max_tasks ? G.coop_waves.load() : 0;
+	if (one_seg_each && par->n_segs <= 1 && !par->is_cdna) L.P.flags |= mm2c::KF_IGNORE_SEG;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
 	note_host_variant(c->last_info);

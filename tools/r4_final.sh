@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4, evidence run: the whole GPU test suite, the PMC profiles of the four bench shapes the round reports, the throughput table and the driver's line
+set -u
+O=gpurun_out/r4_final; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+timeout -k 10 600 bash tools/profile.sh r4_mixed --profile mixed && echo prof mixed done
+timeout -k 10 600 bash tools/profile.sh r4_dense --profile dense && echo prof dense done
+timeout -k 10 600 bash tools/profile.sh r4_ava_ont_mixed --preset ava-ont --profile mixed && echo prof ava done
+timeout -k 10 600 bash tools/profile.sh r4_asm20_mixed --preset asm20 --profile mixed && echo prof asm20 done
+timeout -k 10 900 bash tools/results_table.sh > $O/results_table.log 2>&1; cp gpurun_out/results_table.md $O/
+timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json

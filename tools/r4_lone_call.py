@@ -18,20 +18,20 @@ for name, P, prof, n, locus, qs in (("map-ont mixed", params.map_ont(), "mixed",
     f_ref, p_ref, _ = ob.chain_fpv(P, t, avg)
     P2 = params.make_params(P.max_dist_x, P.max_dist_y, P.bw, max_skip=2**31 - 1, max_iter=1024, q_span_override=qs, flags=mm2chain.MM2C_F_IGNORE_SEG)
     f2_ref, p2_ref, _ = ob.chain_fpv(P2, t, avg)
-    for coop in (0, 8):
+    for coop in (0, 16):
         mm2chain.tune("coop_waves", coop)
         ts = []
         for k in range(60):
             t0 = time.perf_counter(); f, p = mm2chain.chain_task(P, t, avg); ts.append(time.perf_counter() - t0)
         ok = np.array_equal(f, f_ref) and np.array_equal(p, p_ref)
         ts = np.array(ts[10:]) * 1e3
-        print(f"{name:18s} n={n:6d} waves per piece {max(coop, 1)}: mm2c_chain_task_host (V1) best {ts.min():.3f} ms median {np.median(ts):.3f} ms  identical={ok}  [{mm2chain.last_host_variant()[:40]}]")
+        print(f"{name:18s} n={n:6d} waves per piece {max(coop, 1):2d}: mm2c_chain_task_host (V1) best {ts.min():.3f} ms median {np.median(ts):.3f} ms  identical={ok}  [{mm2chain.last_host_variant()[:40]}]")
         ts = []
         for k in range(60):
             t0 = time.perf_counter(); r, f, p = mm2chain.run_chaining_on_hw(n, P.max_dist_x, P.max_dist_y, P.bw, qs, avg, t); ts.append(time.perf_counter() - t0)
         ok = np.array_equal(f, f2_ref) and np.array_equal(p, p2_ref)
         ts = np.array(ts[10:]) * 1e3
-        print(f"{name:18s} n={n:6d} waves per piece {max(coop, 1)}: run_chaining_on_hw (V2)    best {ts.min():.3f} ms median {np.median(ts):.3f} ms  identical={ok}")
+        print(f"{name:18s} n={n:6d} waves per piece {max(coop, 1):2d}: run_chaining_on_hw (V2)    best {ts.min():.3f} ms median {np.median(ts):.3f} ms  identical={ok}")
     t0 = time.perf_counter()
     for k in range(5): ob.chain_fpv(P, t, avg)
     print(f"{name:18s} CPU oracle 1 thread: {(time.perf_counter()-t0)/5*1e3:.3f} ms")
