@@ -38,7 +38,7 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // LDS behind the rings: per anchor of the tile (= per lane) the best of the older tiles' candidates as one 64-bit key (score << 32 | index: the waves merge their
 // partial results with an LDS atomic maximum, equal scores -> the nearer index) and the candidate count (atomic add), then the own tile's table of pair scores
 // without f (64 x 64 ints, row = candidate, column = lane of the anchor)
-template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 64 * 8, PAIRS = CNTS + 64 * 4, BYTES = PAIRS + 64 * 64 * 4; };
+template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, PAIRS = CNTS + 2 * 64 * 4, BYTES = PAIRS + 64 * 64 * 4; };   // (two sets of summaries: see the schedule)
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -96,8 +96,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v));
 	TileMem M;
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
-	long long *const s_key = (long long *)(lds + LY::BYTES + CL::KEYS);   // [lane] best (score, index) over the older tiles' candidates
-	int *const s_cnt = (int *)(lds + LY::BYTES + CL::CNTS);               // [lane] candidates in the whole window
+	long long *const s_key2 = (long long *)(lds + LY::BYTES + CL::KEYS);  // [tile parity][lane] best (score, index) over the older tiles' candidates
+	int *const s_cnt2 = (int *)(lds + LY::BYTES + CL::CNTS);              // [tile parity][lane] candidates in the whole window
 	int *const s_pair = (int *)(lds + LY::BYTES + CL::PAIRS);             // [candidate k of the own tile][lane]
 
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;
@@ -121,7 +121,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		const int stamp_lo = i0 - 64 * (NX - 1);
 		if (wv == 0) {
-			s_key[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt[lane] = 0;
+			{	// the summaries of the NEXT tile start empty (its older-tile pairs are dealt while this tile is walked); tile 0 has no older tiles, its set is emptied here too
+				const int nb = ((i0 >> 6) + 1) & 1;
+				s_key2[nb * 64 + lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[nb * 64 + lane] = 0;
+				if (i0 == 0) { s_key2[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[lane] = 0; }
+			}
 			for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 			const int o = (idx & (SN - 1)) * LY::XS;
 			*(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
@@ -161,9 +165,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 
 		__syncthreads();      // the rings hold x / q of this tile and f / p of the tiles before it (wave 0 wrote them); the summaries of the tile before have been read
 
-		// ---------------------------------------------------------------- phase A: every pair (candidate, anchor of this tile) once, a candidate per step, an anchor per lane
+		// ---------------------------------------------------------------- phase A: every pair (candidate, anchor of a tile) once, a candidate per step, an anchor per lane
+		// Schedule: the pairs of tile T with the candidates of tiles <= T - 2 are dealt while wave 0 walks tile T - 1 (phase A1, waves 1 .. W - 1, below); what is left
+		// for this point is the tile before this one, whose f became final a moment ago (8 units of 8 candidates), and the own tile's table of scores without f.
 		const int span1_l = span_l - 1;
-		// One pair (candidate with low word of x = xj, q = qj -> this lane's anchor): the filters chain.c:202-205 as the hand-written loop has them -- saturating
+		// One pair (candidate with low word of x = xj, q = qj -> a lane's anchor): the filters chain.c:202-205 as the hand-written loop has them -- saturating
 		// subtraction against max_dq - 1 - bw, maximum with |dr - dq|, one compare with bw; dr == 0 (equal x) fails it too: dr - 1 is then 0xffffffff and either
 		// |dr - dq| or the subtraction is huge -- and the score without f[j] (chain.c:207-209,218; gap_scale 1 or the table).
 		auto pair_ok = [&](int dr1, int dq1, int dd) -> bool {
@@ -171,49 +177,60 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			asm("v_max_u32 %0, %1, %2" : "=v"(m) : "v"(usat_sub(dq1, mdqbw_v)), "v"(dd));
 			return (unsigned)m <= (unsigned)X.bw_v;
 		};
-		auto pair_score0 = [&](int dr1, int dq1, int dd) -> int {
+		auto pair_score0 = [&](int dr1, int dq1, int dd, int sp1) -> int {
 			if (TAB) {
 				const int g = *(const int16_t *)(lds + LY::GAP + (min((unsigned)dd, 511u) << 1));
-				return min3i(dq1, dr1, span1_l) + g;
+				return min3i(dq1, dr1, sp1) + g;
 			}
 			const int cz = __builtin_clz((unsigned)dd | 1u);
-			return min3i(dq1, dr1, span1_l) - 14 - (int)((float)dd * avg) + (cz >> 1);       // min(dq, dr, span) - (lin + (ilog2(dd) >> 1)): 1 - 15 = -14
+			return min3i(dq1, dr1, sp1) - 14 - (int)((float)dd * avg) + (cz >> 1);       // min(dq, dr, span) - (lin + (ilog2(dd) >> 1)): 1 - 15 = -14
 		};
-		{
+		// candidates j1 - 1 down to j0 of older tiles against the 64 anchors of the tile that starts at anchor t0 (per lane: x - 1, q - 1, span - 1, window start), in units
+		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (An anchor with equal-x predecessors in an older tile never takes
+		// the short cut, so dr == 0 needs no thought here.)
+		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov) {
 			int best_l = SENT, jb_l = -1, cnt_l = 0;
-			// ---- the older tiles: candidates i0 - 1 down to the start of the first anchor's window (st[] is monotone) or of the ring, in units of 8 dealt to the waves
-			// (an anchor with equal-x predecessors in an older tile never takes the short cut, so dr == 0 needs no thought here)
-			const int lo_first = rdlane(lo_l, 63);
-			const int jmin = max(max(lo_first, stamp_lo), 0);
-			const int n_units = (i0 - jmin + 7) >> 3;
+			const int n_units = (j1 - j0 + 7) >> 3;
 #if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
 			if (0)
 #endif
-			for (int u = wv; u < n_units; u += W) {
-				const int jl = i0 - 1 - 8 * u - (lane & 7);          // lanes 0 .. 7 fetch the unit's candidates
+			for (int u = me; u < n_units; u += nw) {
+				const int jl = j1 - 1 - 8 * u - (lane & 7);          // lanes 0 .. 7 fetch the unit's candidates
 				int xv = 0, qv = 0, fv = 0;
-				if (lane < 8 && jl >= jmin) {
+				if (lane < 8 && jl >= j0) {
 					const int2 xq = *(const int2 *)(lds + LY::XQ + (jl & (SN - 1)) * 8);
 					xv = xq.x; qv = xq.y;
-					if ((i0 >> 6) - (jl >> 6) <= NF) fv = ((const int2 *)(lds + LY::FP + ((jl << 3) & LY::FMASK)))->x + FBIAS;
+					if ((t0 >> 6) - (jl >> 6) <= NF) fv = ((const int2 *)(lds + LY::FP + ((jl << 3) & LY::FMASK)))->x + FBIAS;
 					else fv = __hip_atomic_load(&f[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
-				const int n_here = min(8, i0 - jmin - 8 * u);
+				const int n_here = min(8, j1 - j0 - 8 * u);
 #pragma unroll
 				for (int t = 0; t < 8; ++t) {
 					if (t < n_here) {
-						const int j = i0 - 1 - 8 * u - t;
-						const int dr1 = tx1_l - rdlane(xv, t), dq1 = tq1_l - rdlane(qv, t);
+						const int j = j1 - 1 - 8 * u - t;
+						const int dr1 = tx1v - rdlane(xv, t), dq1 = tq1v - rdlane(qv, t);
 						const int dd = absdiff(dr1, dq1);
-						const bool ok = pair_ok(dr1, dq1, dd) && j >= lo_l;
-						const int sc = ok ? pair_score0(dr1, dq1, dd) + rdlane(fv, t) : SENT;
+						const bool ok = pair_ok(dr1, dq1, dd) && j >= lov;
+						const int sc = ok ? pair_score0(dr1, dq1, dd, sp1v) + rdlane(fv, t) : SENT;
 						cnt_l += ok ? 1 : 0;
 						const bool take = sc > best_l;             // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
 						best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
 					}
 				}
 			}
+			const int sb = ((t0 >> 6) & 1) * 64;
+			if (BALLOT(cnt_l != 0) != 0) {
+				if (best_l != SENT) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[sb + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		};
+		{
+			// ---- the tile before this one (the part of it inside the first anchor's window and the ring)
+			const int lo_first = rdlane(lo_l, 63);
+			const int jmin = max(max(lo_first, stamp_lo), 0);
+			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l);
 			// ---- the own tile: its candidates' f is not final, so the score without f goes to the table (SENT: not a candidate of this lane's anchor)
+			int cnt_l = 0;
 #if MM2C_COOP_PROBE == 2 || MM2C_COOP_PROBE == 4
 			if (0)
 #endif
@@ -223,12 +240,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				const int dd = absdiff(dr1, dq1);
 				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && i0 + k >= lo_l && lane < Lk;
 				cnt_l += ok ? 1 : 0;
-				s_pair[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd) : SENT;
+				s_pair[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd, span1_l) : SENT;
 			}
-			if (BALLOT(cnt_l != 0) != 0) {
-				if (best_l != SENT) __hip_atomic_fetch_max(&s_key[lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt[lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
+			if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[((i0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
 
@@ -237,17 +251,21 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// later short-cut anchor of the tile (one per lane) scores the pair (k -> itself) and keeps the better of the two -- the dependent chain per anchor is
 		// read f[k], add, compare, instead of a whole chunk scan.  Candidates arrive in ascending j, the reference scans in descending j and keeps the first of
 		// equal scores (strict `>`, chain.c:226): so an equal score from a later (nearer) candidate replaces an earlier one, but never the anchor's own span
-		// (p = -1), which only a strictly better score beats.
+		// (p = -1), which only a strictly better score beats -- one 64-bit comparison, see `acc` below.
 		if (wv == 0) {
-			const long long key = s_key[lane];                  // this lane's anchor: best of the older tiles' candidates (score << 32 | index), candidates in the whole window
-			const int bo_l = (int)(key >> 32), jo_l = (int)(unsigned)key, c_l = s_cnt[lane];
+			const long long key = s_key2[((i0 >> 6) & 1) * 64 + lane];   // this lane's anchor: best of the older tiles' candidates (score << 32 | index), candidates in the whole window
+			const int bo_l = (int)(key >> 32), jo_l = (int)(unsigned)key, c_l = s_cnt2[((i0 >> 6) & 1) * 64 + lane];
 			// the anchors that take the short cut: at most max_skip candidates in the whole window -> chain.c:231 cannot fire (max_skip < 0: none); not those whose
 			// window reaches beyond the ring or whose equal-x run reaches into the tile before (the exact scan knows how)
 			const bool short_l = (int64_t)c_l <= (int64_t)P.max_skip && lo_l < idx && rl < cnt && !(FAR && lo_l < stamp_lo) && e_l <= rl && !no_pairs;
 			const mask_t shorts = BALLOT(short_l);
 			if (short_l) tw_l |= (int)0x80000000;               // "not for the hand-written loop": it hands these anchors back
 			const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
-			int acc_f = bo_l > span_l ? bo_l : span_l, acc_p = bo_l > span_l ? jo_l : -1;   // short-cut lanes: best so far = the older tiles' best or the span (chain.c:188)
+			// short-cut lanes: best so far = the older tiles' best or the span (chain.c:188).  Score and index travel as ONE signed 64-bit key, score << 32 | index: a
+			// maximum over keys prefers the higher score and, among equal scores, the higher = nearer index; the span's key carries index 0xffffffff (p = -1), so an equal
+			// score never replaces it (chain.c:226 is strict)
+			auto mk_key = [](int sc, int j) -> long long { return (long long)(((unsigned long long)(unsigned)sc << 32) | (unsigned)j); };
+			long long acc = bo_l > span_l ? mk_key(bo_l, jo_l) : mk_key(span_l, -1);
 			// candidate k (final) -> the short-cut anchors after it (lanes below 63 - k) whose window holds it
 			// A short-cut anchor's result IS its accumulator once every earlier anchor of the tile has been pushed; it is copied into the own-tile registers
 			// (what the exact scans read, and what leaves the tile) for all such lanes at once, before an exact scan runs and at the end of the tile.
@@ -255,7 +273,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			auto flush = [&](int k_done) {                       // anchors 0 .. k_done - 1 are final
 				const mask_t fin = shorts & (k_done >= 64 ? ~0ull : ~(~0ull >> k_done)) & ~copied;   // lanes 63 .. 64 - k_done
 				if (fin == 0) return;
-				own_f = sel(fin, own_f, acc_f); own_p = sel(fin, own_p, acc_p);
+				own_f = sel(fin, own_f, (int)(acc >> 32)); own_p = sel(fin, own_p, (int)(unsigned)acc);
 				copied |= fin;
 			};
 			// A whole tile of short-cut anchors (every tile of a V2 call; the tiles of a V1 call without a chain in them): the 64 pushes as straight-line code --
@@ -264,13 +282,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const bool all_short = cnt == 64 && shorts == ~0ull;
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
 			if (all_short) {
-#pragma unroll
+#pragma unroll 4
 				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
 					const int row_k = s_pair[k * 64 + lane];
-					const int sc = row_k != SENT ? row_k + rdlane(acc_f, 63 - k) : SENT;
-					const bool take = sc > acc_f || (sc == acc_f && acc_p >= 0 && row_k != SENT);
-					acc_p = take ? i0 + k : acc_p;
-					acc_f = max(acc_f, sc);
+					const long long key = mk_key(row_k + rdlane((int)(acc >> 32), 63 - k), i0 + k);
+					acc = (row_k != SENT && key > acc) ? key : acc;
 				}
 			}
 #endif
@@ -284,11 +300,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 					if (k + 1 < cnt) row = s_pair[(k + 1) * 64 + lane];
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
 					if (later != 0) {
-						// the chain from one anchor to the next is: read f[k] (a lane of acc_f), add, maximum; who holds the maximum (the index) is settled beside it
-						const int sc = row_k != SENT ? row_k + rdlane(acc_f, L) : SENT;
-						const bool take = sc > acc_f || (sc == acc_f && acc_p >= 0 && row_k != SENT);
-						acc_p = take ? i0 + k : acc_p;
-						acc_f = max(acc_f, sc);
+						const long long key = mk_key(row_k + rdlane((int)(acc >> 32), L), i0 + k);
+						acc = (row_k != SENT && key > acc) ? key : acc;
 					}
 #endif
 					++k;
@@ -337,10 +350,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 					const int Lk = 63 - kk;
 					if ((shorts & (Lk > 0 ? ~0ull >> (64 - Lk) : 0ull)) == 0) break;
 					const int s0 = s_pair[kk * 64 + lane];
-					const int sc = s0 + rdlane(own_f, Lk);
-					const bool take = s0 != SENT && (sc > acc_f || (sc == acc_f && acc_p >= 0));
-					acc_f = take ? sc : acc_f;
-					acc_p = take ? i0 + kk : acc_p;
+					const long long key = mk_key(s0 + rdlane(own_f, Lk), i0 + kk);
+					acc = (s0 != SENT && key > acc) ? key : acc;
 				}
 #endif
 				k = k2;
@@ -351,6 +362,18 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 			const int o = (idx << 3) & LY::FMASK;
 			*(int2 *)(lds + LY::FP + o) = make_int2(own_f - FBIAS, own_p);
+		} else if (i0 + 64 < n) {
+			// ---------------------------------------------------------------- phase A1 for the NEXT tile, beside wave 0's walk of this one: its anchors (already in `nxt`) against
+			// the candidates of the tiles before this one -- final f, and ring slots nobody writes during the walk (wave 0 puts this tile's f / p into the slot of the tile
+			// NF + 1 back from the next one, which the next tile reads from memory; the x / q of the next tile enter the ring after the barrier)
+			const int t0 = i0 + 64, idn = t0 + rl;
+			const int lo_n = no_pairs ? idn : min(nxt_st, idn);
+			const int lo_first_n = rdlane(lo_n, 63);
+			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1)), 0);
+			if (jmin_n < i0) {
+				const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
+				older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n);
+			}
 		}
 		cur = nxt; cur_st = nxt_st;
 	}
