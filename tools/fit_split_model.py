@@ -9,7 +9,8 @@ anchor lists of simulated reads on a synthetic genome captured from the referenc
 regressors) and PBCCS (k = 19 spans, cleaner and longer chains).  The intercepts are what the smallest tasks cost; the slopes come from NON-NEGATIVE least squares
 (n and total_subparts are collinear; an unconstrained fit gives a negative per-anchor cost, which no host could use), on every second task; the
 other half is the hold-out on which the decision `hw_pred < sw_pred` (chain.c:101) is scored against the measured faster side.
-Runs on the GPU box:  python tools/fit_split_model.py  -> include/mm2chain_split.h, profiles/r2_split_model.{md,json}"""
+Runs on the GPU box:  python tools/fit_split_model.py  -> include/mm2chain_split.h, profiles/<tag>_split_model.{md,json} (tag: MM2C_SPLIT_TAG, default r4:
+round 4 re-fitted it because a lone call now runs with 16 waves per piece, csrc/chain_dp_coop.h)"""
 import json
 import os
 import struct
@@ -21,6 +22,7 @@ import numpy as np
 from scipy.optimize import nnls
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = os.environ.get("MM2C_SPLIT_TAG", "r4")
 sys.path.insert(0, os.path.join(ROOT, "minimap2-fpga_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mm2chain  # noqa: E402
 from mm2chain import params, synth  # noqa: E402
@@ -123,8 +125,8 @@ if __name__ == "__main__":
     md += ["Reference constants (VU9P / F1 host, `chain_hardware.h:19-30`): ONT K1_HW 2.992e-4, K2_HW 1.215e-5, C_HW 0.319, K_SW 5.234e-6, C_SW -1.0015.", ""]
     hdr = ["/* mm2chain_split.h -- HW/SW split parameters for MI355X, in the form of the reference's chain_hardware.h:19-30 (ONT_* / PBCCS_*),",
            " * for a host that keeps chain.c:80-81,101: set K1_HW..C_SW (options.c:6,95-99,118-122) from these, or ask mm2c_split_model().",
-           " * hw = one synchronous per-read call into the library (PCIe + launch + DP on a lone wave), sw = chain.c's loop on one host core.",
-           " * GENERATED by tools/fit_split_model.py on the MI355X box (non-negative least squares; hold-out accuracy in profiles/r2_split_model.md). */",
+           " * hw = one synchronous per-read call into the library (PCIe + launches + DP with 16 waves per piece, csrc/chain_dp_coop.h), sw = chain.c's loop on one host core.",
+           " * GENERATED by tools/fit_split_model.py on the MI355X box (non-negative least squares; hold-out accuracy in profiles/" + TAG + "_split_model.md). */",
            "#ifndef MM2CHAIN_SPLIT_H", "#define MM2CHAIN_SPLIT_H", ""]
     for preset in ("ONT", "PBCCS"):
         hdr += [f"// Parameters used for HW/SW split ({'ONT' if preset == 'ONT' else 'PacBio CCS'}), MI355X"]
@@ -133,8 +135,8 @@ if __name__ == "__main__":
     open(os.path.join(ROOT, "include", "mm2chain_split.h"), "w").write("\n".join(hdr) + "\n")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for d in ("profiles", "gpurun_out"):
-        open(os.path.join(ROOT, d, "r2_split_model.md"), "w").write("\n".join(md) + "\n")
-        json.dump(out, open(os.path.join(ROOT, d, "r2_split_model.json"), "w"), indent=1)
+        open(os.path.join(ROOT, d, TAG + "_split_model.md"), "w").write("\n".join(md) + "\n")
+        json.dump(out, open(os.path.join(ROOT, d, TAG + "_split_model.json"), "w"), indent=1)
     # the header is written inside the repo copy on the GPU box: leave a copy where gpurun collects files
     open(os.path.join(ROOT, "gpurun_out", "mm2chain_split.h"), "w").write("\n".join(hdr) + "\n")
     print("\n".join(md))
