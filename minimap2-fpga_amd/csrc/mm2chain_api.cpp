@@ -212,25 +212,34 @@ int get_thread_ctx(ThreadCtx **out)
 	return 0;
 }
 
-static ThreadCtx g_batch_ctx;
-static std::mutex g_batch_mu;
-static uint64_t g_batch_epoch = ~0ull;
+// Two batch contexts (stream set + grow-only arenas each).  A host whose mini-batches arrive one at a time (kt_pipeline runs a step for one mini-batch at a time,
+// map.c:529-620) only ever uses the first, so its arenas are reused whichever pipeline thread calls; a second caller that arrives while the first is busy takes the
+// other set instead of waiting for the whole call (upload, kernels, download), and only a third one waits.
+static constexpr int N_BATCH_CTX = 2;
+static ThreadCtx g_batch_ctx[N_BATCH_CTX];
+static std::mutex g_batch_mu[N_BATCH_CTX];
+static uint64_t g_batch_epoch[N_BATCH_CTX] = { ~0ull, ~0ull };
 
 int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
 {
 	if (tl_slot >= 0) return get_thread_ctx(out);                   // the slot's lock is held by run_split
-	hold = std::unique_lock<std::mutex>(g_batch_mu);
+	int k = 0;
+	for (; k < N_BATCH_CTX; ++k) {
+		hold = std::unique_lock<std::mutex>(g_batch_mu[k], std::try_to_lock);
+		if (hold.owns_lock()) break;
+	}
+	if (k == N_BATCH_CTX) { k = 0; hold = std::unique_lock<std::mutex>(g_batch_mu[0]); }   // both busy: wait for the first
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
-	if (!g_batch_ctx.st || g_batch_epoch != G.epoch) {
-		g_batch_ctx = ThreadCtx();
+	if (!g_batch_ctx[k].st || g_batch_epoch[k] != G.epoch) {
+		g_batch_ctx[k] = ThreadCtx();
 		DeviceScope on(G.device);
 		hipError_t e = on.err;
-		if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_batch_ctx.st, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_batch_ctx[k].st, hipStreamNonBlocking);
 		if (e != hipSuccess) return fail(MM2C_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-		g_batch_epoch = G.epoch;
+		g_batch_epoch[k] = G.epoch;
 	}
-	*out = &g_batch_ctx;
+	*out = &g_batch_ctx[k];
 	return 0;
 }
 
@@ -470,7 +479,8 @@ int mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64
 
 void mm2c_shutdown(void)
 {
-	std::lock_guard<std::mutex> bl(g_batch_mu);       // same order as get_batch_ctx: the batch context's lock, then the library's
+	std::lock_guard<std::mutex> bl0(g_batch_mu[0]);   // same order as get_batch_ctx: a batch context's lock (a caller holds at most one), then the library's
+	std::lock_guard<std::mutex> bl1(g_batch_mu[1]);
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!G.ready) return;
 	(void)hipSetDevice(cur_device());
@@ -478,8 +488,7 @@ void mm2c_shutdown(void)
 	for (ThreadCtx *c : G.thread_ctxs) { c->release(); delete c; }
 	for (size_t k = 0; k < G.devices.size() && k < 64; ++k) if (g_slot_ctx[k].st) { (void)hipSetDevice(G.devices[k]); (void)hipDeviceSynchronize(); g_slot_ctx[k].release(); }
 	(void)hipSetDevice(G.device);
-	if (g_batch_ctx.st) g_batch_ctx.release();
-	g_batch_epoch = ~0ull;
+	for (int k = 0; k < N_BATCH_CTX; ++k) { if (g_batch_ctx[k].st) g_batch_ctx[k].release(); g_batch_epoch[k] = ~0ull; }
 	release_combiner();
 	release_seed_aux();
 	dev_cache_release();

@@ -688,6 +688,25 @@ def test_batched_mm_chain_dp_pipelined_in_chunks():
     assert _assert_chains(res, P, 3, 40, off, a, "chunked") > 40
 
 
+def test_concurrent_batch_calls_take_separate_contexts():
+    """Three host threads inside mm2c_mm_chain_dp_batch_host at once (a host whose pipeline threads overlap their GPU calls): the library keeps two batch contexts
+    (stream set + arenas), the first two callers each take one, the third waits for the first -- every call's chains equal the oracle's, whoever shared what."""
+    import threading
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    batches = [_stream("mixed", 120, (500, 3000), seed=300 + k) for k in range(3)]
+    out = [None] * 3
+    def work(k):
+        for _ in range(3):                                   # several rounds, so that the calls really overlap
+            out[k] = mm2chain.mm_chain_dp_batch(P, 3, 40, batches[k][0], batches[k][1])
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(3):
+        _assert_chains(out[k], P, 3, 40, batches[k][0], batches[k][1], f"concurrent batch call {k}")
+
+
 @pytest.mark.parametrize("min_cnt,min_sc", [(1, 0), (1, 40), (2, 15), (3, 100), (5, 1000), (0, -5)])
 def test_device_epilogue_filter_corners(min_cnt, min_sc, epi_path):
     """chain.c:385-388 with thresholds that keep one-anchor chains (incl. chains that keep only an already taken peak) or
