@@ -498,6 +498,28 @@ def main():
                             "what": "matches -> anchors as collect_seed_hits leaves them (map.c:215-247, incl. radix_sort_128x's order among equal x), HBM-resident",
                             "verified_vs_oracle": bool(ok_s)}
         sp.close(); del d_m, d_h, d_as
+        # one synchronous call for ONE read, the reference's call pattern (chain.c:103 -> run_chaining_on_hw, chain_hardware.cpp:27-197): the dispatch symbol itself (V2:
+        # look-back 1024, no max-skip) and the extended entry (V1 = stock mm_chain_dp), upload / launches / download / synchronisation included, beside one CPU thread
+        t_one = a1[: int(off1[1])].cpu().numpy().view(np.uint64)
+        avg_one = ob.avg_qspan(t_one)
+        P2 = params.make_params(P.max_dist_x, P.max_dist_y, P.bw, max_skip=2**31 - 1, max_iter=1024, q_span_override=q_span, flags=mm2chain.MM2C_F_IGNORE_SEG)
+        f1_ref, p1_ref, _ = ob.chain_fpv(P, t_one, avg_one)
+        f2_ref, p2_ref, _ = ob.chain_fpv(P2, t_one, avg_one)
+        lone = {"task": f"the first read of the batch ({t_one.shape[0]} anchors)", "what": "best and median of 40 synchronous calls from one host thread, idle GPU otherwise"}
+        for key, call, ref in (("run_chaining_on_hw_ms", lambda: mm2chain.run_chaining_on_hw(t_one.shape[0], P.max_dist_x, P.max_dist_y, P.bw, q_span, avg_one, t_one)[1:], (f2_ref, p2_ref)),
+                               ("mm2c_chain_task_host_ms", lambda: mm2chain.chain_task(P, t_one, avg_one), (f1_ref, p1_ref))):
+            ts, same = [], True
+            for k in range(48):
+                tl = time.perf_counter(); fo, po = call(); ts.append(time.perf_counter() - tl)
+                same = same and (k > 0 or (np.array_equal(fo, ref[0]) and np.array_equal(po, ref[1])))
+            ts = np.array(ts[8:]) * 1e3
+            lone[key] = {"best": round(float(ts.min()), 4), "median": round(float(np.median(ts)), 4), "identical_to_oracle": bool(same)}
+        lone["kernel"] = mm2chain.last_host_variant()
+        tl = time.perf_counter()
+        for _ in range(5):
+            ob.chain_fpv(P, t_one, avg_one)
+        lone["cpu_thread_ms"] = round((time.perf_counter() - tl) / 5 * 1e3, 4)
+        out["lone_call"] = lone
         n_h = min(distinct, 8192)                                            # the distinct reads of the batch: 4.1e7 anchors at the default sizes
         a_host = a1[: int(off1[n_h])].cpu().numpy().view(np.uint64)
         off_host = off1[: n_h + 1].numpy()

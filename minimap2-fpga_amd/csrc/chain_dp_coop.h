@@ -38,7 +38,7 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // LDS behind the rings: per anchor of the tile (= per lane) the best of the older tiles' candidates as one 64-bit key (score << 32 | index: the waves merge their
 // partial results with an LDS atomic maximum, equal scores -> the nearer index) and the candidate count (atomic add), then the own tile's table of pair scores
 // without f (64 x 64 ints, row = candidate, column = lane of the anchor)
-template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, PAIRS = CNTS + 2 * 64 * 4, BYTES = PAIRS + 64 * 64 * 4; };   // (two sets of summaries: see the schedule)
+template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, PAIRS = CNTS + 2 * 64 * 4, BYTES = PAIRS + 2 * 64 * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -98,13 +98,16 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
 	long long *const s_key2 = (long long *)(lds + LY::BYTES + CL::KEYS);  // [tile parity][lane] best (score, index) over the older tiles' candidates
 	int *const s_cnt2 = (int *)(lds + LY::BYTES + CL::CNTS);              // [tile parity][lane] candidates in the whole window
-	int *const s_pair = (int *)(lds + LY::BYTES + CL::PAIRS);             // [candidate k of the own tile][lane]
+	int *const s_pair2 = (int *)(lds + LY::BYTES + CL::PAIRS);            // [tile parity][candidate k of that tile][lane]
 
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;
 	int seg0 = 0;
 	bool t_ready = false;
 	const bool no_pairs = P.max_dq <= 0 || P.bw < 0;
 
+#if MM2C_COOP_PROBE == 9
+	long long tp[6] = {0, 0, 0, 0, 0, 0}, tq = wall_clock64();   // wave 0: 100 MHz ticks spent up to barrier 1 / in phase A2 / summary + flags / in the pushes / rest of phase B / tile end
+#endif
 	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
 	int cur_st = (rl < n) ? st[rl] : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
@@ -164,6 +167,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
 		__syncthreads();      // the rings hold x / q of this tile and f / p of the tiles before it (wave 0 wrote them); the summaries of the tile before have been read
+#if MM2C_COOP_PROBE == 9
+		if (wv == 0) { const long long tn = wall_clock64(); tp[1] += tn - tq; tq = tn; }
+#endif
 
 		// ---------------------------------------------------------------- phase A: every pair (candidate, anchor of a tile) once, a candidate per step, an anchor per lane
 		// Schedule: the pairs of tile T with the candidates of tiles <= T - 2 are dealt while wave 0 walks tile T - 1 (phase A1, waves 1 .. W - 1, below); what is left
@@ -211,10 +217,12 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 						const int dr1 = tx1v - rdlane(xv, t), dq1 = tq1v - rdlane(qv, t);
 						const int dd = absdiff(dr1, dq1);
 						const bool ok = pair_ok(dr1, dq1, dd) && j >= lov;
-						const int sc = ok ? pair_score0(dr1, dq1, dd, sp1v) + rdlane(fv, t) : SENT;
-						cnt_l += ok ? 1 : 0;
-						const bool take = sc > best_l;             // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
-						best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
+						if (BALLOT(ok) != 0) {                       // (most candidates are candidates of none of the 64 anchors: the score waits for one that is)
+							const int sc = ok ? pair_score0(dr1, dq1, dd, sp1v) + rdlane(fv, t) : SENT;
+							cnt_l += ok ? 1 : 0;
+							const bool take = sc > best_l;         // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
+							best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
+						}
 					}
 				}
 			}
@@ -224,27 +232,36 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[sb + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		};
-		{
-			// ---- the tile before this one (the part of it inside the first anchor's window and the ring)
-			const int lo_first = rdlane(lo_l, 63);
-			const int jmin = max(max(lo_first, stamp_lo), 0);
-			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l);
-			// ---- the own tile: its candidates' f is not final, so the score without f goes to the table (SENT: not a candidate of this lane's anchor)
+		// the table of a tile (first anchor t0, `tn` anchors; x, q per lane in xv, qv): for candidate k and the lane of a later anchor, the pair's score without f, or SENT
+		// when k is not one of that anchor's candidates (the candidates' f is not final when the table is made); the candidates are counted on the way
+		auto own_table = [&](int t0, int tn, int me, int nw, int xv, int qv, int sp1v, int lov) {
 			int cnt_l = 0;
+			int *const tab = s_pair2 + ((t0 >> 6) & 1) * (64 * 64);
 #if MM2C_COOP_PROBE == 2 || MM2C_COOP_PROBE == 4
 			if (0)
 #endif
-			for (int k = wv; k < cnt; k += W) {
+			for (int k = me; k < tn; k += nw) {
 				const int Lk = 63 - k;
-				const int dr1 = tx1_l - rdlane(own_x, Lk), dq1 = tq1_l - rdlane(own_q, Lk);
+				const int dr1 = xv - 1 - rdlane(xv, Lk), dq1 = qv - 1 - rdlane(qv, Lk);
 				const int dd = absdiff(dr1, dq1);
-				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && i0 + k >= lo_l && lane < Lk;
+				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && t0 + k >= lov && lane < Lk;
 				cnt_l += ok ? 1 : 0;
-				s_pair[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd, span1_l) : SENT;
+				tab[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd, sp1v) : SENT;
 			}
-			if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[((i0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[((t0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		};
+		{
+			// ---- the tile before this one (the part of it inside the first anchor's window and the ring); the first tile's table (the later ones are made a tile ahead, below)
+			const int lo_first = rdlane(lo_l, 63);
+			const int jmin = max(max(lo_first, stamp_lo), 0);
+			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l);
+			else own_table(0, cnt, wv, W, own_x, own_q, span1_l, lo_l);
 		}
+		int *const s_pair = s_pair2 + ((i0 >> 6) & 1) * (64 * 64);          // this tile's table
 		__syncthreads();
+#if MM2C_COOP_PROBE == 9
+		if (wv == 0) { const long long tn = wall_clock64(); tp[2] += tn - tq; tq = tn; }
+#endif
 
 		// ---------------------------------------------------------------- phase B: wave 0 walks the tile's anchors; the other waves go on to the next barrier
 		// An anchor that takes the short cut only needs the maximum over its candidates, so its own-tile candidates are PUSHED to it: when anchor k is final, every
@@ -279,9 +296,26 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// A whole tile of short-cut anchors (every tile of a V2 call; the tiles of a V1 call without a chain in them): the 64 pushes as straight-line code --
 			// the lane that holds f[k] is a constant of the instruction, the table rows come in ahead of their use, and what is left of the walk from one anchor
 			// to the next is read a lane, add, maximum.
+#if MM2C_COOP_PROBE == 9
+			{ const long long tn = wall_clock64(); tp[3] += tn - tq; tq = tn; }
+#endif
 			const bool all_short = cnt == 64 && shorts == ~0ull;
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
-			if (all_short) {
+			if (all_short && n < (1 << 15)) {
+				// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size (a chain gains at most span <= 255 per anchor), so score and origin fit ONE word:
+				// score << 7 | code, code 0 = the older tiles' best, 1 + k = candidate k of this tile, 127 = the span itself (p = -1).  A signed maximum then is the whole
+				// rule: the higher score, among equal scores the nearer origin, and never an equal score over the span.  A push is: read a lane, mask, add, maximum.
+				int a32 = (int)(acc >> 32) * 128 + ((int)(unsigned)acc == -1 ? 127 : 0);
+#pragma unroll 4
+				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
+					const int row_k = s_pair[k * 64 + lane];
+					const int fk7 = (rdlane(a32, 63 - k) & ~127) + (k + 1);                 // f[k] << 7 | code of candidate k
+					const int key = row_k != SENT ? row_k * 128 + fk7 : SENT;
+					a32 = max(a32, key);
+				}
+				const int code = a32 & 127;
+				acc = mk_key(a32 >> 7, code == 127 ? -1 : code == 0 ? jo_l : i0 + code - 1);
+			} else if (all_short) {
 #pragma unroll 4
 				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
 					const int row_k = s_pair[k * 64 + lane];
@@ -357,6 +391,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				k = k2;
 				if (k < cnt) row = s_pair[k * 64 + lane];
 			}
+#if MM2C_COOP_PROBE == 9
+			{ const long long tn = wall_clock64(); tp[4] += tn - tq; tq = tn; }
+#endif
 			flush(64);
 			// ---- the finished tile: results leave in coalesced stores and enter the f / p ring
 			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
@@ -370,13 +407,18 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int lo_n = no_pairs ? idn : min(nxt_st, idn);
 			const int lo_first_n = rdlane(lo_n, 63);
 			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1)), 0);
-			if (jmin_n < i0) {
-				const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
-				older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n);
-			}
+			const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
+			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n);
+			own_table(t0, min(64, n - t0), wv - 1, W - 1, (int)nxt.x, (int)nxt.z, sp_n, lo_n);   // x and q only: nothing of it waits for this tile's walk
 		}
+#if MM2C_COOP_PROBE == 9
+		if (wv == 0) { const long long tn = wall_clock64(); tp[5] += tn - tq; tq = tn; }
+#endif
 		cur = nxt; cur_st = nxt_st;
 	}
+#if MM2C_COOP_PROBE == 9
+	if (threadIdx.x == 0 && task == 0) printf("coop ticks (100 MHz) n=%d: to barrier1 %lld, A2 %lld, summary %lld, pushes %lld, rest of B %lld, tile end %lld\n", n, tp[1], tp[2], tp[3], tp[4], tp[5], tp[0]);
+#endif
 }
 
 } // namespace mm2c
