@@ -57,6 +57,7 @@ struct LaunchArgs {
 	int32_t *d_t;               // stamp scratch for look-back beyond the LDS ring, one int per anchor
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
+	int64_t max_task_anchors = 0;   // length of the longest task when the caller knows it (0: unknown): lets a small pass size a grid of one block per 256 anchors (chain_window_start_wide)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
 	int force_tab = 0;          // 1: the gap-cost table of the tile kernel also for gap_scale == 1 (mm2c_tune("force_tab"); slower, kept for the parity tests)
 	int ring_class;             // 3: tile kernel (general variant: first-generation kernel); 4: tile kernel for every variant; 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring

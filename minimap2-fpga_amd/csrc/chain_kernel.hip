@@ -361,6 +361,29 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	}
 }
 
+// The same window starts for a pass of few tasks (a lone call: one block above would walk the task's tiles one after the other, 25 us for 5 000 anchors, while the
+// GPU is empty): one block per 256 anchors of a task, blockIdx.y = the tile, every lane a binary search over the task's sorted x in memory -- the tiles do not wait for
+// one another, the answers are the same by construction (the same bounds [max(i - max_iter, 0), i], the same condition).  Only st[]: no classes, no avg, no cut flags.
+__global__ void __launch_bounds__(256)
+chain_window_start_wide(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all)
+{
+	const int64_t task = (int64_t)blockIdx.x;
+	if (task >= n_tasks) return;
+	const int64_t base = offsets[task];
+	const int n = (int)(offsets[task + 1] - base);
+	const int i = (int)blockIdx.y * 256 + (int)threadIdx.x;
+	if (i >= n) return;
+	const ulonglong2 *a = a_all + base;
+	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
+	const uint64_t xi = a[i].x;
+	int hi = i, lo = max(i - P.max_iter, 0);                          // answer in [lo, hi]; x_i <= x_i + D always holds
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;           // chain.c:192 condition for "++st"
+	}
+	st_all[base + i] = lo;
+}
+
 // ---------------------------------------------------------------- ring-size classes: one class for a batch that is nearly of one kind
 // The two classes are two launches that run one after the other, and each ends with the GPU part empty while its last tasks finish.  A handful
 // of long tasks in a launch of their own costs the batch the whole length of one of them (ragged mixed stream: 53.1 -> 59.6 ms for a few reads
@@ -806,6 +829,12 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	const unsigned c16_bound = tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u;
+	// a pass of few tasks that wants nothing but st[] from the prepass (the cooperative kernel: no classes; avg handed in; no cut on the device): one block per tile
+	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && L.d_avg != nullptr && L.cut.max_pieces == 0;
+	if (wide_prepass)
+		hipLaunchKernelGGL(chain_window_start_wide, dim3((unsigned)L.n_tasks, (unsigned)((L.max_task_anchors + 255) / 256)), dim3(256), 0, st, P, L.n_tasks, L.d_offsets,
+		                   (const ulonglong2 *)L.d_anchors, L.d_st);
+	else
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
 	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr,

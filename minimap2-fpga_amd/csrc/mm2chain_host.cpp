@@ -197,6 +197,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 	// a pass of few pieces (a lone call, a handful of combined calls) cannot fill the GPU with one wave per piece: several waves per piece (chain_dp_coop.h)
 	L.coop_waves = n_seg <= G.coop_max_tasks ? G.coop_waves.load() : 0;
+	if (L.coop_waves > 1) for (int64_t k = 0; k < n_seg; ++k) L.max_task_anchors = std::max<int64_t>(L.max_task_anchors, seg_off[(size_t)k + 1] - seg_off[(size_t)k]);
 	if (one_seg_each && par->n_segs <= 1 && !par->is_cdna) L.P.flags |= mm2c::KF_IGNORE_SEG;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
