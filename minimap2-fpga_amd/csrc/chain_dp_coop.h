@@ -6,10 +6,12 @@
 //   * Whether a predecessor j passes the filters of anchor i (chain.c:202-205) depends on x and q only, and the score of the pair (chain.c:207-220) on f[j],
 //     which is final for every j in a tile before i's own.
 //   * The scan order only matters through the early exit (chain.c:226-233): the `break` needs more than max_skip skip events, and a skip event is a candidate
-//     that passed the filters.  An anchor with at most max_skip candidates in its whole window can therefore never take the `break`, and without it the loop
-//     computes the maximum of f[j] + score over the candidates, the nearest j winning ties (strict `>`, chain.c:226) -- an order-independent reduction.  That
-//     is every anchor of a V2 call (max_skip = INT_MAX, what run_chaining_on_hw computes) and the noise anchors of a V1 call, the ones whose scans run through
-//     their whole window; the anchors on a chain have many candidates, but their scans end after a tile or two.
+//     that passed the filters -- so the scan always visits an anchor's first max_skip + 1 candidates (nearest first).  Whenever the BEST candidate of the whole
+//     window (the maximum of f[j] + score, nearest j among equal scores) is among those first max_skip + 1, it is what the scan returns: it is visited, nothing
+//     visited beats it, and the strict `>` of chain.c:226 keeps the nearest of equal scores.  The maximum over all candidates is an order-independent
+//     reduction, and the rank of the best one -- how many candidates are nearer -- is a popcount over candidate masks.  That covers every anchor of a V2 call
+//     (max_skip = INT_MAX, what run_chaining_on_hw computes), the noise anchors of a V1 call (few candidates) AND the anchors on a chain (many candidates, but
+//     the best predecessor is one of the nearest): on the bench's streams every anchor.  The rare anchor whose best predecessor lies farther takes the exact scan.
 // So a workgroup of W waves shares the task's LDS rings, and per tile of 64 anchors (lane L of every wave stands for the anchor i0 + 63 - L, as in chain_dp_tile):
 //   phase A, all waves, PAIRS dealt by candidate: a candidate j (its x, q, f as scalars) is scored against the 64 anchors of the tile at once, one anchor per
 //            lane -- filters, score, "inside this anchor's window" -- and each lane keeps the count of its candidates and the best (score, nearest index) among
@@ -38,7 +40,7 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // LDS behind the rings: per anchor of the tile (= per lane) the best of the older tiles' candidates as one 64-bit key (score << 32 | index: the waves merge their
 // partial results with an LDS atomic maximum, equal scores -> the nearer index) and the candidate count (atomic add), then the own tile's table of pair scores
 // without f (64 x 64 ints, row = candidate, column = lane of the anchor)
-template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, PAIRS = CNTS + 2 * 64 * 4, BYTES = PAIRS + 2 * 64 * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
+template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, BYTES = PAIRS + 2 * 64 * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -98,6 +100,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
 	long long *const s_key2 = (long long *)(lds + LY::BYTES + CL::KEYS);  // [tile parity][lane] best (score, index) over the older tiles' candidates
 	int *const s_cnt2 = (int *)(lds + LY::BYTES + CL::CNTS);              // [tile parity][lane] candidates in the whole window
+	unsigned long long *const s_own2 = (unsigned long long *)(lds + LY::BYTES + CL::MASKS);   // [tile parity][lane] bit k: candidate k of the anchor's own tile is one of its candidates
+	unsigned long long *const s_d12 = s_own2 + 2 * 64;                                          // [tile parity][lane] bit c: anchor (tile start - 1 - c), in the tile before, is one of its candidates
 	int *const s_pair2 = (int *)(lds + LY::BYTES + CL::PAIRS);            // [tile parity][candidate k of that tile][lane]
 
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;
@@ -126,8 +130,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		if (wv == 0) {
 			{	// the summaries of the NEXT tile start empty (its older-tile pairs are dealt while this tile is walked); tile 0 has no older tiles, its set is emptied here too
 				const int nb = ((i0 >> 6) + 1) & 1;
-				s_key2[nb * 64 + lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[nb * 64 + lane] = 0;
-				if (i0 == 0) { s_key2[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[lane] = 0; }
+				s_key2[nb * 64 + lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[nb * 64 + lane] = 0; s_own2[nb * 64 + lane] = 0; s_d12[nb * 64 + lane] = 0;
+				if (i0 == 0) { s_key2[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[lane] = 0; s_own2[lane] = 0; s_d12[lane] = 0; }
 			}
 			for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
 			const int o = (idx & (SN - 1)) * LY::XS;
@@ -194,8 +198,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// candidates j1 - 1 down to j0 of older tiles against the 64 anchors of the tile that starts at anchor t0 (per lane: x - 1, q - 1, span - 1, window start), in units
 		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (An anchor with equal-x predecessors in an older tile never takes
 		// the short cut, so dr == 0 needs no thought here.)
-		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov) {
+		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1) {
 			int best_l = SENT, jb_l = -1, cnt_l = 0;
+			unsigned long long m_l = 0;                          // d1: which anchors of the tile before t0 are candidates (bit c: anchor t0 - 1 - c)
 			const int n_units = (j1 - j0 + 7) >> 3;
 #if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
 			if (0)
@@ -220,6 +225,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 						if (BALLOT(ok) != 0) {                       // (most candidates are candidates of none of the 64 anchors: the score waits for one that is)
 							const int sc = ok ? pair_score0(dr1, dq1, dd, sp1v) + rdlane(fv, t) : SENT;
 							cnt_l += ok ? 1 : 0;
+							if (d1) m_l |= ok ? 1ull << (t0 - 1 - j) : 0ull;
 							const bool take = sc > best_l;         // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
 							best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
 						}
@@ -230,12 +236,14 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (BALLOT(cnt_l != 0) != 0) {
 				if (best_l != SENT) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[sb + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (d1 && m_l != 0) __hip_atomic_fetch_or(&s_d12[sb + lane], m_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		};
 		// the table of a tile (first anchor t0, `tn` anchors; x, q per lane in xv, qv): for candidate k and the lane of a later anchor, the pair's score without f, or SENT
 		// when k is not one of that anchor's candidates (the candidates' f is not final when the table is made); the candidates are counted on the way
 		auto own_table = [&](int t0, int tn, int me, int nw, int xv, int qv, int sp1v, int lov) {
 			int cnt_l = 0;
+			unsigned long long m_l = 0;
 			int *const tab = s_pair2 + ((t0 >> 6) & 1) * (64 * 64);
 #if MM2C_COOP_PROBE == 2 || MM2C_COOP_PROBE == 4
 			if (0)
@@ -246,15 +254,19 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				const int dd = absdiff(dr1, dq1);
 				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && t0 + k >= lov && lane < Lk;
 				cnt_l += ok ? 1 : 0;
+				m_l |= ok ? 1ull << k : 0ull;
 				tab[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd, sp1v) : SENT;
 			}
-			if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[((t0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (cnt_l != 0) {
+				__hip_atomic_fetch_add(&s_cnt2[((t0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_or(&s_own2[((t0 >> 6) & 1) * 64 + lane], m_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 		};
 		{
 			// ---- the tile before this one (the part of it inside the first anchor's window and the ring); the first tile's table (the later ones are made a tile ahead, below)
 			const int lo_first = rdlane(lo_l, 63);
 			const int jmin = max(max(lo_first, stamp_lo), 0);
-			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l);
+			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l, true);
 			else own_table(0, cnt, wv, W, own_x, own_q, span1_l, lo_l);
 		}
 		int *const s_pair = s_pair2 + ((i0 >> 6) & 1) * (64 * 64);          // this tile's table
@@ -270,76 +282,97 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// equal scores (strict `>`, chain.c:226): so an equal score from a later (nearer) candidate replaces an earlier one, but never the anchor's own span
 		// (p = -1), which only a strictly better score beats -- one 64-bit comparison, see `acc` below.
 		if (wv == 0) {
-			const long long key = s_key2[((i0 >> 6) & 1) * 64 + lane];   // this lane's anchor: best of the older tiles' candidates (score << 32 | index), candidates in the whole window
-			const int bo_l = (int)(key >> 32), jo_l = (int)(unsigned)key, c_l = s_cnt2[((i0 >> 6) & 1) * 64 + lane];
-			// the anchors that take the short cut: at most max_skip candidates in the whole window -> chain.c:231 cannot fire (max_skip < 0: none); not those whose
-			// window reaches beyond the ring or whose equal-x run reaches into the tile before (the exact scan knows how)
-			const bool short_l = (int64_t)c_l <= (int64_t)P.max_skip && lo_l < idx && rl < cnt && !(FAR && lo_l < stamp_lo) && e_l <= rl && !no_pairs;
-			const mask_t shorts = BALLOT(short_l);
-			if (short_l) tw_l |= (int)0x80000000;               // "not for the hand-written loop": it hands these anchors back
+			const int sbuf = ((i0 >> 6) & 1) * 64;
+			const long long key = s_key2[sbuf + lane];          // this lane's anchor: best of the older tiles' candidates (score << 32 | index), candidates in the whole window
+			const int bo_l = (int)(key >> 32), jo_l = (int)(unsigned)key, c_l = s_cnt2[sbuf + lane];
+			const unsigned long long own_m = s_own2[sbuf + lane], d1_m = s_d12[sbuf + lane];   // which anchors of the own tile / of the tile before are its candidates
+			// WHICH ANCHORS TAKE THE SHORT CUT.  The `break` of chain.c:231 needs more than max_skip skip events and every skip event is a candidate, so the scan always
+			// visits an anchor's first max_skip + 1 candidates (in scan order: nearest first).  The maximum over ALL candidates (nearest index among equal scores) is
+			// therefore the scan's result whenever that best candidate is among the first max_skip + 1: it is visited, nothing visited beats it, and the nearest of equal
+			// scores is the one the strict `>` of chain.c:226 keeps.  Its rank = the number of candidates nearer than it, counted from the candidate masks of the own
+			// tile and of the tile before (deeper: bounded by the candidate count).  No candidate better than the span (p = -1): true of every visited subset as well.
+			// The rank is known only once the anchor's maximum is, so the anchors are walked as if all of them qualified and each is checked when it becomes final;
+			// the few that fail (a best predecessor more than max_skip candidates away) take the exact scan.  Not eligible at all: a window beyond the ring, an
+			// equal-x run that reaches into the tile before.
+			const bool tent_l = rl < cnt && !(FAR && lo_l < stamp_lo && lo_l < idx) && e_l <= rl && !no_pairs;
+			mask_t tents = BALLOT(tent_l);
+			auto rank_ok = [&](int j) -> bool {                 // per lane: is candidate j (this lane's best) among the first max_skip + 1 of its scan?
+				int r;
+				if (j >= i0) { const int kb = j - i0 + 1; r = kb >= 64 ? 0 : (int)__builtin_popcountll(own_m >> kb); }
+				else if (j >= i0 - 64) r = (int)__builtin_popcountll(own_m) + (int)__builtin_popcountll(d1_m & ((1ull << (i0 - 1 - j)) - 1ull));
+				else r = c_l - 1;
+				return j == -1 || (int64_t)r <= (int64_t)P.max_skip;
+			};
+			if (tent_l && !(lo_l >= idx)) tw_l |= (int)0x80000000;   // "not for the hand-written loop" (it commits the anchors without a window itself, bit 29): it hands these anchors back
 			const bool tile_far = FAR && BALLOT((tw_l >> 30) & 1) != 0;
-			// short-cut lanes: best so far = the older tiles' best or the span (chain.c:188).  Score and index travel as ONE signed 64-bit key, score << 32 | index: a
-			// maximum over keys prefers the higher score and, among equal scores, the higher = nearer index; the span's key carries index 0xffffffff (p = -1), so an equal
-			// score never replaces it (chain.c:226 is strict)
+			// best so far = the older tiles' best or the span (chain.c:188).  Score and index travel as ONE signed 64-bit key, score << 32 | index: a maximum over keys
+			// prefers the higher score and, among equal scores, the higher = nearer index; the span's key carries index 0xffffffff (p = -1), so an equal score never
+			// replaces it (chain.c:226 is strict)
 			auto mk_key = [](int sc, int j) -> long long { return (long long)(((unsigned long long)(unsigned)sc << 32) | (unsigned)j); };
-			long long acc = bo_l > span_l ? mk_key(bo_l, jo_l) : mk_key(span_l, -1);
-			// candidate k (final) -> the short-cut anchors after it (lanes below 63 - k) whose window holds it
-			// A short-cut anchor's result IS its accumulator once every earlier anchor of the tile has been pushed; it is copied into the own-tile registers
-			// (what the exact scans read, and what leaves the tile) for all such lanes at once, before an exact scan runs and at the end of the tile.
-			mask_t copied = 0;                                   // short-cut lanes whose accumulators have been copied into own_f / own_p
+			const long long acc0 = bo_l > span_l ? mk_key(bo_l, jo_l) : mk_key(span_l, -1);
+			long long acc = acc0;
+			// A short-cut anchor's result IS its accumulator once every earlier anchor of the tile has been pushed and its rank has been checked; it is copied into the
+			// own-tile registers (what the exact scans read, and what leaves the tile) for all such lanes at once, before an exact scan runs and at the end of the tile.
+			mask_t copied = 0;
 			auto flush = [&](int k_done) {                       // anchors 0 .. k_done - 1 are final
-				const mask_t fin = shorts & (k_done >= 64 ? ~0ull : ~(~0ull >> k_done)) & ~copied;   // lanes 63 .. 64 - k_done
+				const mask_t fin = tents & (k_done >= 64 ? ~0ull : ~(~0ull >> k_done)) & ~copied;   // lanes 63 .. 64 - k_done
 				if (fin == 0) return;
 				own_f = sel(fin, own_f, (int)(acc >> 32)); own_p = sel(fin, own_p, (int)(unsigned)acc);
 				copied |= fin;
 			};
-			// A whole tile of short-cut anchors (every tile of a V2 call; the tiles of a V1 call without a chain in them): the 64 pushes as straight-line code --
-			// the lane that holds f[k] is a constant of the instruction, the table rows come in ahead of their use, and what is left of the walk from one anchor
-			// to the next is read a lane, add, maximum.
 #if MM2C_COOP_PROBE == 9
 			{ const long long tn = wall_clock64(); tp[3] += tn - tq; tq = tn; }
 #endif
-			const bool all_short = cnt == 64 && shorts == ~0ull;
+			// A whole tile of eligible anchors: the 63 pushes as a loop with nothing else in it -- the lane that holds f[k] is a constant of the instruction, the
+			// table rows come in ahead of their use -- and the ranks checked for all lanes at once afterwards; one failing lane sends the tile through the walk below.
+			bool all_done = false;
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
-			if (all_short && n < (1 << 15)) {
-				// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size (a chain gains at most span <= 255 per anchor), so score and origin fit ONE word:
-				// score << 7 | code, code 0 = the older tiles' best, 1 + k = candidate k of this tile, 127 = the span itself (p = -1).  A signed maximum then is the whole
-				// rule: the higher score, among equal scores the nearer origin, and never an equal score over the span.  A push is: read a lane, mask, add, maximum.
-				int a32 = (int)(acc >> 32) * 128 + ((int)(unsigned)acc == -1 ? 127 : 0);
+			if (cnt == 64 && tents == ~0ull) {
+				if (n < (1 << 15)) {
+					// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size (a chain gains at most span <= 255 per anchor), so score and origin fit ONE word:
+					// score << 7 | code, code 0 = the older tiles' best, 1 + k = candidate k of this tile, 127 = the span itself (p = -1).  A signed maximum then is the whole
+					// rule: the higher score, among equal scores the nearer origin, and never an equal score over the span.  A push is: read a lane, mask, add, maximum.
+					int a32 = (int)(acc >> 32) * 128 + ((int)(unsigned)acc == -1 ? 127 : 0);
 #pragma unroll 4
-				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
-					const int row_k = s_pair[k * 64 + lane];
-					const int fk7 = (rdlane(a32, 63 - k) & ~127) + (k + 1);                 // f[k] << 7 | code of candidate k
-					const int key = row_k != SENT ? row_k * 128 + fk7 : SENT;
-					a32 = max(a32, key);
-				}
-				const int code = a32 & 127;
-				acc = mk_key(a32 >> 7, code == 127 ? -1 : code == 0 ? jo_l : i0 + code - 1);
-			} else if (all_short) {
+					for (int k = 0; k < 63; ++k) {               // (anchor 63 has nobody after it)
+						const int row_k = s_pair[k * 64 + lane];
+						const int fk7 = (rdlane(a32, 63 - k) & ~127) + (k + 1);             // f[k] << 7 | code of candidate k
+						const int key32 = row_k != SENT ? row_k * 128 + fk7 : SENT;
+						a32 = max(a32, key32);
+					}
+					const int code = a32 & 127;
+					acc = mk_key(a32 >> 7, code == 127 ? -1 : code == 0 ? jo_l : i0 + code - 1);
+				} else {
 #pragma unroll 4
-				for (int k = 0; k < 63; ++k) {                   // (anchor 63 has nobody after it)
-					const int row_k = s_pair[k * 64 + lane];
-					const long long key = mk_key(row_k + rdlane((int)(acc >> 32), 63 - k), i0 + k);
-					acc = (row_k != SENT && key > acc) ? key : acc;
+					for (int k = 0; k < 63; ++k) {
+						const int row_k = s_pair[k * 64 + lane];
+						const long long key64 = mk_key(row_k + rdlane((int)(acc >> 32), 63 - k), i0 + k);
+						acc = (row_k != SENT && key64 > acc) ? key64 : acc;
+					}
 				}
+				if (BALLOT(!rank_ok((int)(unsigned)acc)) == 0) { all_done = true; own_f = (int)(acc >> 32); own_p = (int)(unsigned)acc; }
+				else acc = acc0;                                 // some anchor's best predecessor lies beyond its first max_skip + 1 candidates: the walk below sorts it out
 			}
 #endif
 			int row = cnt > 0 ? s_pair[lane] : SENT;             // row k of the pair table, requested one anchor ahead
-			for (int k = all_short ? cnt : 0; k < cnt;) {
+			for (int k = all_done ? cnt : 0; k < cnt;) {
 				const int L = 63 - k;
-				const mask_t later = shorts & (L > 0 ? ~0ull >> (64 - L) : 0ull);
-				if (shorts >> L & 1) {
-					// ---- the short cut: everything that can reach this anchor has been pushed; push it on (candidate k -> the short-cut anchors after it)
+				if (tents >> L & 1) {
+					// ---- everything that can reach this anchor has been pushed: its maximum is final.  Does the short cut hold for it?
 					const int row_k = row;
 					if (k + 1 < cnt) row = s_pair[(k + 1) * 64 + lane];
+					if (BALLOT(rank_ok((int)(unsigned)acc)) >> L & 1) {
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
-					if (later != 0) {
-						const long long key = mk_key(row_k + rdlane((int)(acc >> 32), L), i0 + k);
-						acc = (row_k != SENT && key > acc) ? key : acc;
-					}
+						if ((tents & (L > 0 ? ~0ull >> (64 - L) : 0ull)) != 0) {           // push it on: candidate k -> the eligible anchors after it
+							const long long key64 = mk_key(row_k + rdlane((int)(acc >> 32), L), i0 + k);
+							acc = (row_k != SENT && key64 > acc) ? key64 : acc;
+						}
 #endif
-					++k;
-					continue;
+						++k;
+						continue;
+					}
+					tents &= ~(1ull << L);                         // no: the exact scan for this anchor (the hand-written loop takes it once bit 31 of its word is cleared)
+					tw_l = lane == L ? tw_l & 0x7fffffff : tw_l;
 				}
 				flush(k);
 				int k2 = k;
@@ -378,14 +411,14 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 					write_lane2(own_f, own_p, __builtin_amdgcn_readfirstlane(c.best), __builtin_amdgcn_readfirstlane(c.best_j), L);
 					k2 = k + 1;
 				}
-				// the anchors just made final by an exact scan, pushed to the short-cut anchors after them
+				// the anchors just made final by an exact scan, pushed to the eligible anchors after them
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
 				for (int kk = k; kk < k2 && kk < cnt; ++kk) {
 					const int Lk = 63 - kk;
-					if ((shorts & (Lk > 0 ? ~0ull >> (64 - Lk) : 0ull)) == 0) break;
+					if ((tents & (Lk > 0 ? ~0ull >> (64 - Lk) : 0ull)) == 0) break;
 					const int s0 = s_pair[kk * 64 + lane];
-					const long long key = mk_key(s0 + rdlane(own_f, Lk), i0 + kk);
-					acc = (s0 != SENT && key > acc) ? key : acc;
+					const long long key64 = mk_key(s0 + rdlane(own_f, Lk), i0 + kk);
+					acc = (s0 != SENT && key64 > acc) ? key64 : acc;
 				}
 #endif
 				k = k2;
@@ -394,7 +427,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #if MM2C_COOP_PROBE == 9
 			{ const long long tn = wall_clock64(); tp[4] += tn - tq; tq = tn; }
 #endif
-			flush(64);
+			if (!all_done) flush(64);
 			// ---- the finished tile: results leave in coalesced stores and enter the f / p ring
 			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 			const int o = (idx << 3) & LY::FMASK;
@@ -408,7 +441,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int lo_first_n = rdlane(lo_n, 63);
 			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1)), 0);
 			const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
-			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n);
+			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false);
 			own_table(t0, min(64, n - t0), wv - 1, W - 1, (int)nxt.x, (int)nxt.z, sp_n, lo_n);   // x and q only: nothing of it waits for this tile's walk
 		}
 #if MM2C_COOP_PROBE == 9

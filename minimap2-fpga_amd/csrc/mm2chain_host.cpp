@@ -15,6 +15,11 @@ struct HostReq {
 	int rc = 0; bool done = false; char err[256];
 };
 
+// where the wall time of the small staged passes goes (MM2C_PASS_TIMING=1: printed when the combiner is released, mm2c_shutdown): assembling the pass on the host,
+// the runtime calls that put it on the stream, the wait for it, handing the results back
+static std::atomic<uint64_t> g_pt_build{0}, g_pt_submit{0}, g_pt_wait{0}, g_pt_out{0}, g_pt_n{0};
+static inline uint64_t pt_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Runs one GPU pass over the union of the requests (all with the same scalars).
 //  * every task is split at empty-window cut points: where x_i > x_{i-1} + max_dist_x no anchor at or
 //    after i can chain to, stamp or be stamped by an anchor before i (chain.c:192 pushes st to i), so the pieces are
@@ -27,6 +32,7 @@ static ThreadCtx *combiner_ctx();
 int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 {
 	int rc;
+	const uint64_t pt0 = pt_now();
 	const mm2c_params_t *par = reqs[0]->par;
 	const uint64_t D = (uint64_t)(int64_t)par->max_dist_x;
 	int64_t total = 0, n_tasks_all = 0;
@@ -104,6 +110,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	memcpy(hm + (o_pb - o_off), pbase.data(), (size_t)n_seg * 4);
 	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
 	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);           // status, classes, class counters
+	uint64_t pt1 = 0;
 	if (staged) {
 		size_t at = o_a;
 		for (int r = 0; r < n_req; ++r) {
@@ -111,6 +118,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			memcpy(c->h_in + at, reqs[r]->a + reqs[r]->off[0], nb);
 			at += nb;
 		}
+		pt1 = pt_now();
 		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
 	} else if (n_req == 1 && total >= 2 * pipe_chunk) {
 		// big batch: a three-stage pipeline over chunks of whole pieces.  One stream uploads the chunks back to back (PCIe never idles), the
@@ -205,7 +213,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	if (staged) {
 		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
 		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
+		const uint64_t pt2 = pt_now();
 		HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
+		const uint64_t pt3 = pt_now();
 		size_t at = 0;
 		for (int r = 0; r < n_req; ++r) {
 			const size_t n = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]);
@@ -213,6 +223,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			memcpy(reqs[r]->p + reqs[r]->off[0], c->h_out + (size_t)total * 4 + at * 4, n * 4);
 			at += n;
 		}
+		g_pt_build += pt1 - pt0; g_pt_submit += pt2 - pt1; g_pt_wait += pt3 - pt2; g_pt_out += pt_now() - pt3; ++g_pt_n;
 	} else {
 		size_t at = 0;
 		for (int r = 0; r < n_req; ++r) {
@@ -256,6 +267,9 @@ static ThreadCtx *combiner_ctx() { return &CB.ctx; }
 
 void release_combiner()
 {
+	if (getenv("MM2C_PASS_TIMING") && g_pt_n.load())
+		fprintf(stderr, "[mm2chain] %llu staged passes: assembled on the host %.1f us each, put on the stream %.1f us, waited for %.1f us, results handed back %.1f us\n",
+		        (unsigned long long)g_pt_n.load(), g_pt_build.load() / 1e3 / g_pt_n.load(), g_pt_submit.load() / 1e3 / g_pt_n.load(), g_pt_wait.load() / 1e3 / g_pt_n.load(), g_pt_out.load() / 1e3 / g_pt_n.load());
 	std::lock_guard<std::mutex> lk(CB.mu);
 	CB.ctx.release();
 	CB.epoch = ~0ull;
