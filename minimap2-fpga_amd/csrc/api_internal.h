@@ -54,6 +54,7 @@ struct Global {
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{8};                     // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> combiner_lanes{3};                 // passes of the call combiner in flight at once (1 .. 4)
 	std::atomic<int> coop_plans{0};                     // plans take the cooperative kernel too when they have few tasks (tests; default: the host-buffer entries only)
 	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
 	std::atomic<int> plan_cut_min{8192};                // ... tasks of at least this many anchors (the ones that make the tail of a batch)

@@ -431,6 +431,8 @@ int mm2c_init(int device_ordinal)
 	if (wp) G.wide_pct = std::max(0, std::min(100, atoi(wp)));
 	const char *cm = getenv("MM2C_COMBINE_MAX");         // experiments: 0 = no call combiner
 	if (cm) G.combine_max_anchors = (size_t)std::max(0, atoi(cm));
+	const char *cl = getenv("MM2C_COMBINER_LANES");      // experiments: passes of the call combiner in flight
+	if (cl) G.combiner_lanes = std::max(1, std::min(4, atoi(cl)));
 	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
 	if (cw) G.coop_waves = std::max(0, atoi(cw));
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
@@ -618,6 +620,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "combine_max_anchors") == 0) {            // calls of up to this many anchors go through the call combiner (0: every call runs a pass of its own on its thread's stream)
 		if (value < 0) return fail(MM2C_E_ARG, "combine_max_anchors must be >= 0");
 		G.combine_max_anchors = (size_t)value;
+		return 0;
+	}
+	if (strcmp(key, "combiner_lanes") == 0) {
+		if (value < 1 || value > 4) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 4");
+		G.combiner_lanes = value;
 		return 0;
 	}
 	if (strcmp(key, "coop_plans") == 0) {

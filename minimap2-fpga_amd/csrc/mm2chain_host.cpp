@@ -13,6 +13,7 @@ struct HostReq {
 	const mm2c_params_t *par; int64_t n_tasks; const int64_t *off; const mm2c_anchor_t *a; const float *avg;
 	int32_t *f, *p;
 	int rc = 0; bool done = false; char err[256];
+	bool taken = false;               // a leader of the call combiner has put the request into its pass (its owner then only waits for `done`)
 };
 
 // where the wall time of the small staged passes goes (MM2C_PASS_TIMING=1: printed when the combiner is released, mm2c_shutdown): assembling the pass on the host,
@@ -28,7 +29,7 @@ static inline uint64_t pt_now() { return (uint64_t)std::chrono::duration_cast<st
 //  * avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
 //  * one upload arena [anchors | piece offsets | launch order | p base | avg | status(0)] and one download arena [f | p],
 //    mirrored in pinned memory for small passes: one H2D copy, the kernels, one D2H copy, one sync.
-static ThreadCtx *combiner_ctx();
+static bool is_combiner_ctx(const ThreadCtx *c);
 int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 {
 	int rc;
@@ -85,7 +86,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	seg_off.push_back(total);
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
-	HIP_TRY(hipSetDevice(c == combiner_ctx() ? G.device : cur_device()));   // the context's stream and arenas belong to that device
+	HIP_TRY(hipSetDevice(is_combiner_ctx(c) ? G.device : cur_device()));   // the context's stream and arenas belong to that device
 	// chunk size of the two-stream pipeline: "pipeline_chunk_anchors" (a chunk that fills the GPU on its own) for batches many times that size;
 	// a batch of a few chunks' worth is cut into about eight pieces of at least 4 Mi anchors instead, whose kernels overlap on the two streams --
 	// the upload of a piece then hides behind the kernels of the one before (one pass over 2 * 10^7 anchors: 1.44 G anchors/s, PCIe and kernels in series)
@@ -254,16 +255,20 @@ void note_host_variant(const mm2c::LaunchInfo &I)
 // pending request with the same scalars, runs ONE GPU pass for all of them and wakes their owners; callers that arrive
 // meanwhile queue up and are served by the next leader.  (The reference instead serialises callers on a mutex and a FIFO,
 // chain_hardware.cpp:54-93.)  Big requests skip the combiner and run on the caller's own stream.
+// Up to N_LANES passes in flight, each on a context (stream + arenas) of its own: with the cooperative kernel a pass is short on the GPU (tens of microseconds), and the
+// host side of the next one -- collecting the requests, staging their anchors, the runtime calls -- can run beside it ("combiner_lanes", default 3: measured 5.53-5.67 / 5.40 / 5.26 / 5.53 s for 1 / 2 / 3 / 4 on the 120 000-read run).
+constexpr int N_LANES = 4;
 struct Combiner {
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<HostReq *> pending;
-	bool leader_active = false;
-	ThreadCtx ctx;                      // stream + arenas of the pass in flight (leader-exclusive)
-	uint64_t epoch = ~0ull;
+	int leaders = 0;                    // passes being put together or in flight
+	bool busy[N_LANES] = {};
+	ThreadCtx ctx[N_LANES];             // stream + arenas of a pass in flight (exclusive to its leader)
+	uint64_t epoch[N_LANES] = { ~0ull, ~0ull, ~0ull, ~0ull };
 } CB;
 
-static ThreadCtx *combiner_ctx() { return &CB.ctx; }
+static bool is_combiner_ctx(const ThreadCtx *c) { return c >= &CB.ctx[0] && c < &CB.ctx[N_LANES]; }
 
 void release_combiner()
 {
@@ -271,8 +276,7 @@ void release_combiner()
 		fprintf(stderr, "[mm2chain] %llu staged passes: assembled on the host %.1f us each, put on the stream %.1f us, waited for %.1f us, results handed back %.1f us\n",
 		        (unsigned long long)g_pt_n.load(), g_pt_build.load() / 1e3 / g_pt_n.load(), g_pt_submit.load() / 1e3 / g_pt_n.load(), g_pt_wait.load() / 1e3 / g_pt_n.load(), g_pt_out.load() / 1e3 / g_pt_n.load());
 	std::lock_guard<std::mutex> lk(CB.mu);
-	CB.ctx.release();
-	CB.epoch = ~0ull;
+	for (int k = 0; k < N_LANES; ++k) { CB.ctx[k].release(); CB.epoch[k] = ~0ull; }
 }
 
 int submit_combined(HostReq *me)
@@ -281,30 +285,34 @@ int submit_combined(HostReq *me)
 	CB.pending.push_back(me);
 	for (;;) {
 		if (me->done) return me->rc;
-		if (!CB.leader_active) break;
+		if (!me->taken && CB.leaders < std::max(1, std::min<int>(N_LANES, G.combiner_lanes))) break;   // (a request that sits in another leader's pass waits for that pass)
 		CB.cv.wait(lk);
 	}
+	int lane_k = 0;
+	while (lane_k < N_LANES - 1 && CB.busy[lane_k]) ++lane_k;
+	CB.busy[lane_k] = true;
 	// leader: collect the pending requests that share my scalars, up to the staging size.  Nothing in here may leave the followers waiting
 	// or `leader_active` set: allocation failures (std::bad_alloc from the vectors here and inside run_requests) become an error code for
 	// every request of the batch, and no exception crosses the extern "C" boundary.
-	CB.leader_active = true;
+	++CB.leaders;
 	std::vector<HostReq *> batch, rest;
 	int rc = 0;
 	try {
 		size_t tot = 0;
 		for (HostReq *q : CB.pending) {
 			const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
-			if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; }
+			if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; q->taken = true; }
 			else rest.push_back(q);
 		}
 		CB.pending.swap(rest);
 	} catch (...) {
 		// could not even form the batch: serve only myself (the others stay pending for the next leader)
+		for (HostReq *q : CB.pending) if (q != me) q->taken = false;
 		batch.clear();
 		for (size_t k = 0; k < CB.pending.size(); ++k) if (CB.pending[k] == me) { CB.pending.erase(CB.pending.begin() + (long)k); break; }
 		me->rc = fail(MM2C_E_ARG, "out of host memory in the call combiner"); me->done = true;
 		strncpy(me->err, g_err, sizeof(me->err) - 1); me->err[sizeof(me->err) - 1] = 0;
-		CB.leader_active = false;
+		--CB.leaders; CB.busy[lane_k] = false;
 		CB.cv.notify_all();
 		return me->rc;
 	}
@@ -313,15 +321,15 @@ int submit_combined(HostReq *me)
 		{
 			std::lock_guard<std::mutex> gl(G.mu);
 			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
-			else if (CB.epoch != G.epoch) {                           // first pass after (re)initialisation: fresh stream and arenas
-				CB.ctx = ThreadCtx();
+			else if (CB.epoch[lane_k] != G.epoch) {                   // first pass after (re)initialisation: fresh stream and arenas
+				CB.ctx[lane_k] = ThreadCtx();
 				hipError_t e = hipSetDevice(G.device);                       // the combiner belongs to the primary device, whoever leads first
-				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx.st, hipStreamNonBlocking);
+				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx[lane_k].st, hipStreamNonBlocking);
 				if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
-				else CB.epoch = G.epoch;
+				else CB.epoch[lane_k] = G.epoch;
 			}
 		}
-		if (rc == 0) rc = run_requests(&CB.ctx, batch.data(), (int)batch.size());
+		if (rc == 0) rc = run_requests(&CB.ctx[lane_k], batch.data(), (int)batch.size());
 	} catch (...) {
 		rc = fail(MM2C_E_ARG, "out of host memory in a combined chaining pass");
 	}
@@ -330,7 +338,7 @@ int submit_combined(HostReq *me)
 		q->rc = rc; q->done = true;
 		if (rc != 0) { strncpy(q->err, g_err, sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
 	}
-	CB.leader_active = false;
+	--CB.leaders; CB.busy[lane_k] = false;
 	CB.cv.notify_all();
 	return me->rc;
 }
