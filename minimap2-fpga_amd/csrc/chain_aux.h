@@ -59,9 +59,12 @@ struct SeedArgs {
 	int32_t *tiecnt;                             // per anchor: equal-x neighbours before this position of the sorted read
 	int64_t biggest;                             // anchors of the longest read
 	int32_t *stack;                              // pending buckets of the tie replay: 4 * (total / 64 + 2 * n_reads + 2) ints
-	uint32_t *big_id; uint8_t *big_dg;           // replay arrays for reads too long for the LDS (nullptr when there is none)
+	uint32_t *tie_id;                            // per anchor: the arrangement of the tie replay (position -> anchor of the unsorted array)
+	uint8_t *big_dg;                             // digits of the replay for reads too long for the LDS: total + n_reads bytes (nullptr when there is none)
+	int64_t n_above[6] = {0, 0, 0, 0, 0, 0};     // reads whose capacity exceeds the lower bound of each class of seed_ties (64, then the class sizes): the grid of that class
 };
 int seed_tie_lds_max();
+const int64_t *seed_tie_class_lower();          // six lower bounds (exclusive) of the size classes of seed_ties, shortest class first
 // aux: three helper streams (or nullptr: everything on st), ev: four events without timing
 hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev);
 

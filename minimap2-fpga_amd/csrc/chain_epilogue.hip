@@ -864,8 +864,9 @@ constexpr int TS_MAX = 4096;
 __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 {
 	__shared__ uint16_t s_id[TS_MAX];
-	__shared__ uint8_t s_dg[TS_MAX];
-	__shared__ int s_cur[256], s_lo[256], s_hi[256], s_sp;
+	__shared__ uint8_t s_dg[TS_MAX + 8];                                         // (the walk of radix_replay.h looks one byte beyond the digit it takes)
+	__shared__ __attribute__((aligned(8))) int s_cur[512];
+	__shared__ int s_lo[257], s_sp;
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
 	const int lane = (int)threadIdx.x;
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 	if (nk <= 64) return;                                                        // insertion sort only: stable (ksort.h:141-143)
 	uint64_t *sx = A.rkey1 + base, *rank_x = A.key0 + base;                      // first-x keys: sorted / in rank order (chain k at index k)
 	int32_t *ord = A.val1 + base, *ids = A.val0 + base, *tiecnt = A.dest + base, *stack = A.ctop + base;
+	int32_t *moved = (int32_t *)A.sort_tmp + base;                               // source position per position of a replayed pass (radix_replay.h)
 	// tiecnt[i] = equal neighbours before position i of the sorted keys
 	int run = 0;
 	for (int i0 = 0; i0 < nk; i0 += 64) {
@@ -888,11 +890,11 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 	for (int i = lane; i < nk; i += 64) rank_x[ord[i]] = sx[i];                  // back to rank order, as chain.c:407-410 fills w[]
 	__syncthreads();
 	if (nk <= TS_MAX) {
-		replay_passes<uint16_t, false>(rank_x, 1, sx, 1, tiecnt, nk, s_id, s_dg, stack, nullptr, lane, s_cur, s_lo, s_hi, &s_sp);
+		replay_passes<uint16_t, false>(rank_x, 1, sx, 1, tiecnt, nk, s_id, s_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
 		for (int i = lane; i < nk; i += 64) ids[i] = (int32_t)s_id[i];
 	} else {                                                                     // does not fit the LDS: same replay through global memory
 		uint8_t *g_dg = (uint8_t *)(stack + 2 * (nk / 64 + 2));
-		replay_passes<uint32_t, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, nullptr, lane, s_cur, s_lo, s_hi, &s_sp);
+		replay_passes<uint32_t, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
 	}
 	if (A.debug_phases == 22) return;
 	__syncthreads();
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(64) void epi_emit_cd(EpiArgs A)
 
 } // namespace
 
-size_t epilogue_sort_temp_bytes(int64_t, int64_t) { return 0; }   // the sorts run inside epi_claim (wave_sort64); no library scratch
+size_t epilogue_sort_temp_bytes(int64_t total, int64_t) { return (size_t)total * 4; }   // one int per anchor: the permutation of a replayed pass (epi_tiesort); the sorts themselves need no library scratch
 
 hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launches)
 {

@@ -10,7 +10,7 @@ struct mm2c_seedplan {
 	int32_t *d_cnt = nullptr; int64_t *d_oo = nullptr;   // per-read anchor counts / packed offsets of runs with skip_seed
 	const mm2c_seed_skip_t *skip = nullptr;                // set by mm2c_seedplan_run_device_skip for the run it starts
 	int64_t n_hits_declared = 0;           // set by mm2c_seedplan_run_device_n for the run it starts
-	char *d_mem = nullptr;                 // [match_off | anchor_off | order | status | has_ties | stack | unsorted | scratch | big_id | big_dg]
+	char *d_mem = nullptr;                 // [match_off | anchor_off | order | status | has_ties | stack | unsorted | scratch | tie_id | big_dg]
 	mm2c::SeedArgs S;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipStream_t aux[3] = {};               // helper streams: the size classes of the tie replay run side by side
@@ -100,7 +100,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
 	             o_stack = take(4 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
-	             o_bid = take(big ? tot * 4 : 1), o_bdg = take(big ? tot : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
+	             o_bid = take(tot * 4), o_bdg = take(big ? tot + nr : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
 	pl->device = cur_device();
 	DeviceScope on(pl->device);
 	hipError_t e = on.err;
@@ -127,7 +127,11 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	S.d_order = (const int32_t *)(b + o_ord); S.status = (int32_t *)(b + o_stat); S.has_ties = (int32_t *)(b + o_ties);
 	S.tiecnt = (int32_t *)(b + o_tc); S.xdiff = (uint64_t *)(b + o_xd); S.biggest = biggest;
 	S.stack = (int32_t *)(b + o_stack); S.unsorted = (ulonglong2 *)(b + o_un); S.scratch = (ulonglong2 *)(b + o_scr);
-	S.big_id = big ? (uint32_t *)(b + o_bid) : nullptr; S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
+	S.tie_id = (uint32_t *)(b + o_bid); S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
+	{
+		const int64_t *lower = mm2c::seed_tie_class_lower();                     // a read keeps at most its capacity: these bound the grids of the classes
+		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 6; ++k) S.n_above[k] += cap > lower[k]; }
+	}
 	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);
 	return pl;
 }

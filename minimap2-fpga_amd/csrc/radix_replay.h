@@ -8,7 +8,8 @@
 // the sort, hence: the sorted array tells in O(1) whether a bucket holds equal keys (prefix count `tiecnt`) and which byte is the highest in
 // which its keys differ (clz of smallest ^ largest); buckets without equal keys, passes in which all keys share the digit, and buckets of
 // <= 64 records (insertion sort in the reference = stable; the caller's final stable sort of the replayed arrangement does the same) need
-// no replay.  A pass over two buckets has a closed form (all lanes); a pass over more buckets is the reference's loop on one lane.
+// no replay.  A pass over two buckets has a closed form (all lanes); a pass over more buckets is the reference's loop as a walk on one lane
+// that reads digits only (replay_walk).
 #ifndef MM2C_RADIX_REPLAY_H
 #define MM2C_RADIX_REPLAY_H
 #include <hip/hip_runtime.h>
@@ -27,9 +28,10 @@ __device__ __forceinline__ int rp_incl_scan(int x, int lane)
 }
 
 // un_x / sorted_x: the keys of the unsorted and of the (stably) sorted array, `stride` 64-bit words apart; tiecnt[i] = number of positions
-// j < i of the sorted array with key[j] == key[j+1]; work: 4 ints per record (only with TWO_BUCKET); s_cur, s_lo, s_hi: 256 ints of LDS
-// each, private to the calling wave.  All synchronisation inside is wave-local, so several waves of a workgroup may replay different
-// buckets at the same time.
+// j < i of the sorted array with key[j] == key[j+1]; id: position -> record (any memory); dg: one byte per position, with at least one
+// readable byte behind the last position; moved: one int per position; fa, fb: one int per position each (only with TWO_BUCKET);
+// s_cur: 512 ints (8-byte aligned), s_lo: 257 ints of LDS, private to the calling wave.  All synchronisation inside is wave-local, so several waves of a
+// workgroup may replay different buckets at the same time.
 
 // LDS and global memory written by some lanes of the wave, read by others
 __device__ __forceinline__ void rp_wave_sync()
@@ -38,11 +40,53 @@ __device__ __forceinline__ void rp_wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
+// ---- the cycle-leader distribution of ksort.h:117-131 as a walk over the buckets -------------------------------------------------------
+// What the reference's loop does to a bucket array, stated without the swaps: every bucket d is a queue of its original occupants in
+// position order, with ONE cursor that is both where the next occupant is taken from and where the next arrival is put (`l->b++`; the slots
+// at and behind a cursor are always untouched originals).  Standing at bucket c: take the occupant at c's cursor (digit d), advance the
+// cursor, the record goes to bucket d and lands at d's cursor -- which is the slot whose occupant is taken next, standing at d.  The head
+// bucket k (ksort.h:118, filled first, then k + 1 ...) differs in one thing: it gives up its occupant when a cycle starts and receives the
+// record that closes the cycle into that same slot (`*k->b++ = tmp`), i.e. one place before its cursor; a record of k that is in place
+// (`++k->b`) is a cycle of length one.  When the head's queue is exhausted (only the head's can be: every other bucket still expects as many
+// arrivals as it has occupants left) the next bucket that is not exhausted becomes the head.  So the order inside a bucket after the pass is
+// the order in which the walk sent records there, and the walk needs the digits only -- n steps of (cursor of c, digit at it) -> next c on
+// one lane -- and moves nothing: it writes moved[destination] = source, which all lanes apply afterwards.  The records (16 bytes, or an
+// index) are thus never touched by the sequential part, and the only LDS the replay needs is one byte per position.
+// s_cur[d] = {cursor of d, the digit at the cursor}: the cursor of the next bucket and the digit behind the current cursor are fetched side
+// by side, one LDS round trip per step.
+__device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, int32_t *moved, int lane, int *s_cnt, const int *s_lo)
+{
+	int2 *s_cur = (int2 *)s_cnt;                                             // {cursor relative to lo, digit at the cursor}: read and written in one piece
+	for (int d = lane; d < 256; d += 64) { const int b = s_lo[d]; s_cur[d] = int2{b - lo, (int)dg[b]}; }   // (an empty last bucket reads the byte behind the array)
+	rp_wave_sync();
+	if (lane != 0) return;
+	const int n = hi - lo;
+	int head = 0;
+	while (s_lo[head] == s_lo[head + 1]) ++head;
+	int c = head, head_end = s_lo[head + 1] - lo;
+	int2 pk = s_cur[c];
+	for (int s = 0; s < n; ++s) {
+		if (c == head && pk.x == head_end) {                                 // the head's queue is exhausted: the next bucket that is not takes over
+			do ++head; while (s_cur[head].x == s_lo[head + 1] - lo);
+			c = head; pk = s_cur[c]; head_end = s_lo[head + 1] - lo;
+		}
+		const int p = pk.x, d = pk.y;
+		const int nx = dg[lo + p + 1];                                       // the digit behind it and the cursor of the next bucket: in flight together
+		const int2 pkd = s_cur[d];
+		const int2 npk = int2{p + 1, nx};
+		s_cur[c] = npk;
+		pk = d == c ? npk : pkd;
+		moved[lo + pk.x - (d == head ? 1 : 0)] = lo + p;
+		c = d;
+	}
+}
+
 // One pass of the reference's sort over the bucket [lo, hi) (which must hold equal keys).  Sub-buckets that need the next pass are appended
 // to out_list (two ints each) through the counter *out_count.
 template <typename IdT, bool TWO_BUCKET>
-__device__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int lo, int hi,
-                              IdT *id, uint8_t *dg, int32_t *work, int lane, int *s_cur, int *s_lo, int *s_hi, int32_t *out_list, int *out_count)
+__device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int lo, int hi,
+                              IdT *id, uint8_t *dg, int32_t *moved, int32_t *fa, int32_t *fb, int lane, int *s_cur, int *s_lo,
+                              int32_t *out_list, int *out_count)
 {
 	// the keys of a bucket are the keys of the same positions of the sorted array: smallest and largest differ first in the
 	// highest byte in which any two differ; the passes above that byte move nothing (one bucket each, ksort.h:117-131)
@@ -62,36 +106,34 @@ __device__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_
 		}
 	}
 	rp_wave_sync();
+	int n_buckets = 0;
 	{
 		int h[4], sum = 0;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { h[k] = s_cur[4 * lane + k]; sum += h[k]; }
+		for (int k = 0; k < 4; ++k) { h[k] = s_cur[4 * lane + k]; sum += h[k]; n_buckets += h[k] > 0; }
 		int at = lo + rp_incl_scan(sum, lane) - sum;
-		rp_wave_sync();
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; s_cur[4 * lane + k] = at; at += h[k]; s_hi[4 * lane + k] = at; }
+		for (int k = 0; k < 4; ++k) { s_lo[4 * lane + k] = at; at += h[k]; }
+		if (lane == 63) s_lo[256] = at;                                      // = hi
 	}
 	rp_wave_sync();
-	int n_buckets = 0;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) n_buckets += s_hi[4 * lane + k] > s_lo[4 * lane + k];
 	for (int o = 32; o > 0; o >>= 1) n_buckets += __shfl_xor(n_buckets, o);
 	if (TWO_BUCKET && n_buckets == 2) {
-		// Two buckets A | B (the strand byte, often the top position byte): the distribution has a closed form, no lane has to walk.
+		// Two buckets A | B (the strand byte, often the top position byte): the distribution has a closed form, no walk.
 		// Bucket A is filled first (ksort.h:118).  Its t-th misplaced record starts a cycle: it is dropped at B's cursor, the records
 		// of B that follow are pushed one place on until B's t-th misplaced record falls out, and that one comes back to the slot the
 		// cycle started from.  So A's misplaced slot t gets B's t-th misplaced record; in B the t-th record from A lands right after
 		// B's misplaced slot t-1 (at B's start for t = 0) and the B-records before misplaced slot t move one place up.
 		const int da = (int)(sorted_x[(int64_t)lo * sorted_stride] >> shift) & 255, db = (int)(sorted_x[(int64_t)(hi - 1) * sorted_stride] >> shift) & 255;
-		const int mid = s_hi[da], sz = hi - lo, half = (sz + 1) / 2 + 1;
-		int32_t *g = work + 4 * (int64_t)lo;                                // 4 ints of scratch per position of the bucket
-		int32_t *fposA = g, *fidA = g + half, *fposB = g + 2 * half, *fidB = g + 3 * half, *newB = g + 4 * half;
+		const int mid = s_lo[da + 1];
+		int32_t *fposA = fa + lo, *fposB = fb + lo;                           // at most min(|A|, |B|) entries each
 		int F = 0;
 		for (int q0 = lo; q0 < mid; q0 += 64) {
 			const int q = q0 + lane;
-			const bool foreign = q < mid && dg[q] != da;
+			const bool in = q < mid, foreign = in && dg[q] != da;
 			const uint64_t m = __ballot(foreign);
-			if (foreign) { const int t = F + rp_lanes_before(m); fposA[t] = q; fidA[t] = (int32_t)id[q]; }
+			if (foreign) fposA[F + rp_lanes_before(m)] = q;
+			else if (in) moved[q] = q;
 			F += __popcll(m);
 		}
 		int FB = 0;
@@ -100,39 +142,32 @@ __device__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_
 			const bool in = q < hi, foreign = in && dg[q] != db;
 			const uint64_t m = __ballot(foreign);
 			const int t = FB + rp_lanes_before(m);                              // misplaced slots of B before q
-			if (foreign) { fposB[t] = q; fidB[t] = (int32_t)id[q]; }
-			else if (in) newB[q + (t < F ? 1 : 0) - mid] = (int32_t)id[q];
+			if (foreign) fposB[t] = q;
+			else if (in) moved[q + (t < F ? 1 : 0)] = q;
 			FB += __popcll(m);
 		}
 		rp_wave_sync();
 		for (int t = lane; t < F; t += 64) {
-			id[fposA[t]] = (IdT)fidB[t];
-			newB[(t == 0 ? mid : fposB[t - 1] + 1) - mid] = fidA[t];
+			moved[fposA[t]] = fposB[t];
+			moved[t == 0 ? mid : fposB[t - 1] + 1] = fposA[t];
 		}
-		rp_wave_sync();
-		for (int q = mid + lane; q < hi; q += 64) id[q] = (IdT)newB[q - mid];
-		rp_wave_sync();
-	} else if (lane == 0) {                                                  // ksort.h:117-131
-		for (int d = 0; d < 256; ) {
-			const int bl = s_cur[d];
-			if (bl == s_hi[d]) { ++d; continue; }
-			int dst = dg[bl];
-			if (dst == d) { s_cur[d] = bl + 1; continue; }
-			IdT hid = id[bl]; uint8_t hd = (uint8_t)dst;
-			do {
-				const int at = s_cur[dst]++;
-				const IdT nid = id[at]; const uint8_t nd = dg[at];
-				id[at] = hid; dg[at] = hd; hid = nid; hd = nd;
-				dst = hd;
-			} while (dst != d);
-			id[s_cur[d]] = hid; dg[s_cur[d]] = hd; ++s_cur[d];
-		}
+	} else replay_walk(dg, lo, hi, moved, lane, s_cur, s_lo);              // ksort.h:117-131
+	rp_wave_sync();
+	// the new arrangement: position q holds the record that stood at moved[q]
+	for (int q0 = lo; q0 < hi; q0 += 256) {
+		int v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; v[k] = q < hi ? (int)id[moved[q]] : 0; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; if (q < hi) moved[q] = v[k]; }
 	}
+	rp_wave_sync();
+	for (int q = lo + lane; q < hi; q += 64) id[q] = (IdT)moved[q];
 	rp_wave_sync();
 	if (shift == 0) return;                                                // ksort.h:132
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
-		const int d = 4 * lane + k, bl = s_lo[d], bh = s_hi[d];
+		const int d = 4 * lane + k, bl = s_lo[d], bh = s_lo[d + 1];
 		// ksort.h:143: buckets of more than 64 records get the next pass (smaller ones an insertion sort = the final stable sort);
 		// those without equal keys end up in their one sorted order whatever happens inside
 		if (bh - bl > 64 && tiecnt[bh - 1] - tiecnt[bl] > 0) {
@@ -144,8 +179,8 @@ __device__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_
 
 // The whole replay on one wave: buckets on a stack (2 * (n / 64 + 2) ints), s_sp one int of LDS.
 template <typename IdT, bool TWO_BUCKET>
-__device__ void replay_passes(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
-                              uint8_t *dg, int32_t *stack, int32_t *work, int lane, int *s_cur, int *s_lo, int *s_hi, int *s_sp)
+__device__ __forceinline__ void replay_passes(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
+                              uint8_t *dg, int32_t *stack, int32_t *moved, int32_t *fa, int32_t *fb, int lane, int *s_cur, int *s_lo, int *s_sp)
 {
 	for (int i = lane; i < n; i += 64) id[i] = (IdT)i;
 	if (lane == 0) { stack[0] = 0; stack[1] = n; *s_sp = 1; }                  // only buckets that hold equal keys are ever pushed
@@ -157,16 +192,16 @@ __device__ void replay_passes(const uint64_t *un_x, int un_stride, const uint64_
 		rp_wave_sync();
 		if (lane == 0) *s_sp = sp - 1;
 		rp_wave_sync();
-		replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, lo, hi, id, dg, work, lane, s_cur, s_lo, s_hi, stack, s_sp);
+		replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, lo, hi, id, dg, moved, fa, fb, lane, s_cur, s_lo, stack, s_sp);
 	}
 }
 
 // The whole replay on the NW waves of a workgroup, level by level: the buckets of one level are independent, wave w takes every NW-th of
 // them; between levels one workgroup barrier (every wave reaches it: the loop is bounded by the eight byte positions of a key).
-// list_a / list_b: n / 64 + 2 buckets (two ints) each; s_n: two ints of LDS; s_cur / s_lo / s_hi: NW * 256 ints of LDS each.
+// list_a / list_b: n / 64 + 2 buckets (two ints) each; s_n: two ints of LDS; s_cur: NW * 512, s_lo: NW * 257 ints of LDS.
 template <typename IdT, bool TWO_BUCKET, int NW>
-__device__ void replay_levels(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
-                              uint8_t *dg, int32_t *list_a, int32_t *list_b, int32_t *work, int tid, int *s_cur, int *s_lo, int *s_hi, int *s_n)
+__device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
+                              uint8_t *dg, int32_t *list_a, int32_t *list_b, int32_t *moved, int32_t *fa, int32_t *fb, int tid, int *s_cur, int *s_lo, int *s_n)
 {
 	const int lane = tid & 63, wave = tid >> 6;
 	for (int i = tid; i < n; i += 64 * NW) id[i] = (IdT)i;
@@ -180,8 +215,8 @@ __device__ void replay_levels(const uint64_t *un_x, int un_stride, const uint64_
 		__syncthreads();
 		int32_t *in = cur ? list_b : list_a, *out = cur ? list_a : list_b;
 		for (int k = wave; k < n_seg; k += NW)
-			replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, work, lane,
-			                               s_cur + 256 * wave, s_lo + 256 * wave, s_hi + 256 * wave, out, &s_n[cur ^ 1]);
+			replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, moved, fa, fb, lane,
+			                               s_cur + 512 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1]);
 	}
 	__syncthreads();
 }

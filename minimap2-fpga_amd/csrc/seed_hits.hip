@@ -9,7 +9,7 @@
 //   seed_sort   : stable LSD radix sort of the 16-byte anchors on x (bytes in which all keys agree are skipped; ping-pong between
 //                 two global buffers).  Where all x of a read differ this IS the reference's result: a sorted order is unique.
 //   seed_ties   : radix_sort_128x is not stable, so a read with equal x values gets that sort's passes replayed: the arrangement is
-//                 tracked as (digit, index) pairs in LDS, the cycle-leader distribution of ksort.h:117-131 runs on one lane per
+//                 tracked as an index array, the cycle-leader distribution of ksort.h:117-131 runs as a walk over the digits (in LDS) on one lane per
 //                 pass (its outcome depends on the order of the swaps), only for buckets that hold equal keys (a bucket is a
 //                 position range, so the sorted output tells which ones do); buckets of <= 64 records are insertion-sorted by the
 //                 reference (stable), so a final stable sort of the replayed arrangement gives the reference's array.
@@ -342,39 +342,6 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	if (lane == 0) A.has_ties[read] = run > 0;
 }
 
-// ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
-// The replay of a read needs 3 bytes of LDS per anchor; four size classes keep the occupancy of the common (short) reads high.
-// CAP = 0: reads beyond the largest class, arrays in global memory.
-constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 20480;   // the last one: 60 of the 64 KB a block may take
-
-template <int CAP, int PREV>
-__global__ __launch_bounds__(64) void seed_ties(SeedArgs A)
-{
-	__shared__ uint16_t s_id[CAP ? CAP : 1];
-	__shared__ uint8_t s_dg[CAP ? CAP : 1];
-	__shared__ int s_cur[256], s_lo[256], s_hi[256], s_sp;
-	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
-	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
-	const int lane = (int)threadIdx.x;
-	const ReadGeom g = read_geom(A, read);
-	const int64_t a0 = g.a0;
-	const int na = g.na;
-	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
-	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
-	int32_t *stack = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na/64 + 2 entries suffice (room for two such lists)
-	if (CAP) {
-		replay_passes<uint16_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
-#pragma unroll 4
-		for (int i = lane; i < na; i += 64) tmp[i] = un[s_id[i]];
-	} else {
-		uint32_t *g_id = A.big_id + a0; uint8_t *g_dg = A.big_dg + a0;
-		replay_passes<uint32_t, true>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, g_id, g_dg, stack, (int32_t *)tmp, lane, s_cur, s_lo, s_hi, &s_sp);
-		for (int i = lane; i < na; i += 64) tmp[i] = un[g_id[i]];
-	}
-	__syncthreads();
-	wave_sort_anchors(tmp, un, out, na, lane, s_cur);                            // stable: keeps the replayed order among equal x; `un` is free now
-}
-
 // ---- the key sort of wave_sort_keys on the NW waves of a workgroup (for ONE long read whose sort a batch would otherwise wait for): per step
 // of 64 * NW records every wave ranks its own 64 (peers by ballots) and publishes its per-digit counts; a record's place is the digit's
 // cursor + the counts of the waves before its own + its rank inside the wave (stable).  s_cnt: 256 ints, s_w: NW * 256 ints of LDS.
@@ -428,28 +395,37 @@ __device__ uint64_t *block_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo
 	return from;
 }
 
-// The same for the longest reads that fit the LDS, on the four waves of a workgroup: their replay is what a batch waits for, and the
-// buckets of one level are independent (radix_replay.h, replay_levels).
-constexpr int TIE_MW_LO = TIE_CAP2, TIE_MW_HI = 16384, TIE_MW_WAVES = 4;
+// ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
+// The sequential part of the replay (the walk of replay_walk) reads digits only, so a read needs ONE byte of LDS per anchor (the index
+// array, the permutation of a pass and the lists of the closed form live in global memory and are touched by all lanes); size classes keep
+// the occupancy of the common (short) reads high: up to 12 288 anchors one wave replays a read, longer reads -- whose replay a batch waits
+// for -- run the independent buckets of each level and the final sort on the four waves of a workgroup, with up to 128 K digits in LDS
+// (gfx950: 160 KB per workgroup).  CAP = 0: reads beyond that, digits in global memory.
+constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 65536, TIE_CAP4 = 131072;
+constexpr int TIE_MW_WAVES = 4;
 
-__global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
+template <int CAP, int PREV, int NW>
+__global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 3 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
 {
-	__shared__ uint16_t s_id[TIE_MW_HI];
-	__shared__ uint8_t s_dg[TIE_MW_HI];
-	__shared__ int s_cur[256 * TIE_MW_WAVES], s_lo[256 * TIE_MW_WAVES], s_hi[256 * TIE_MW_WAVES], s_n[2];
+	__shared__ __attribute__((aligned(8))) uint8_t s_dg[CAP + 8];            // (the walk looks one byte beyond the digit it takes)
+	__shared__ __attribute__((aligned(8))) int s_cur[512 * NW];
+	__shared__ int s_lo[257 * NW], s_n[2];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
 	const int tid = (int)threadIdx.x;
 	const ReadGeom g = read_geom(A, read);
 	const int64_t a0 = g.a0;
 	const int na = g.na;
-	if (na <= TIE_MW_LO || na > TIE_MW_HI) return;
+	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
-	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);
-	replay_levels<uint16_t, true, TIE_MW_WAVES>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, s_id, s_dg, lists, lists + 2 * (na / 64 + 2),
-	                                             (int32_t *)tmp, tid, s_cur, s_lo, s_hi, s_n);
-	// the final stable sort of the replayed arrangement, also on all four waves: keys = (differing bits of x, squeezed) << id bits | position
-	// in the arrangement, as in seed_sort
+	uint32_t *id = A.tie_id + a0;
+	uint8_t *dg = CAP ? s_dg : A.big_dg + a0 + read;                             // one spare byte per read
+	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na / 64 + 2 entries per list suffice
+	int32_t *moved = (int32_t *)tmp, *fa = moved + na, *fb = fa + na;            // the read's 16 bytes of scratch per anchor
+	replay_levels<uint32_t, true, NW>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, id, dg, lists, lists + 2 * (na / 64 + 2),
+	                                   moved, fa, fb, tid, s_cur, s_lo, s_n);
+	// the final stable sort of the replayed arrangement: keys = (differing bits of x, squeezed) << id bits | position in the arrangement, as in
+	// seed_sort (the scratch of the replay is free now)
 	const uint64_t diff = A.xdiff[read];
 	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
 	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);
@@ -457,17 +433,18 @@ __global__ __launch_bounds__(64 * TIE_MW_WAVES) void seed_ties_mw(SeedArgs A)
 	if (kb + idb <= 64) {
 		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;
 		const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
-		for (int q = tid; q < na; q += 64 * TIE_MW_WAVES) {
-			const uint64_t x = un[s_id[q]].x;
+		for (int q = tid; q < na; q += 64 * NW) {
+			const uint64_t x = un[id[q]].x;
 			ka[q] = ((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0)) << idb | (uint64_t)q;
 		}
 		__syncthreads();
-		const uint64_t *ks = block_sort_keys<TIE_MW_WAVES>(ka, kbuf, na, idb, kb, tid, s_cur, s_lo);   // the tables of the replay are free now
+		const uint64_t *ks = NW == 1 ? wave_sort_keys(ka, kbuf, na, idb, kb, tid, s_cur)
+		                             : block_sort_keys<NW>(ka, kbuf, na, idb, kb, tid, s_cur, s_cur + 256);   // the tables of the replay are free now
 		const uint64_t idm = (1ull << idb) - 1;
-		for (int i = tid; i < na; i += 64 * TIE_MW_WAVES) out[i] = un[s_id[(int)(ks[i] & idm)]];
+		for (int i = tid; i < na; i += 64 * NW) out[i] = un[id[(int)(ks[i] & idm)]];
 		return;
 	}
-	for (int i = tid; i < na; i += 64 * TIE_MW_WAVES) tmp[i] = un[s_id[i]];
+	for (int i = tid; i < na; i += 64 * NW) tmp[i] = un[id[i]];
 	__syncthreads();
 	if (tid >= 64) return;                                                       // the anchors themselves: a one-wave routine
 	wave_sort_anchors(tmp, un, out, na, tid, s_cur);
@@ -536,7 +513,12 @@ __global__ __launch_bounds__(64) void seed_heap(SeedArgs A)
 
 } // namespace
 
-int seed_tie_lds_max() { return TIE_CAP3; }
+int seed_tie_lds_max() { return TIE_CAP4; }
+const int64_t *seed_tie_class_lower()
+{
+	static const int64_t lower[6] = { 64, TIE_CAP0, TIE_CAP1, TIE_CAP2, TIE_CAP3, TIE_CAP4 };
+	return lower;
+}
 
 // The tie replay of one read is a long dependent chain on one wave, so each size class ends in a tail of a few long reads; the classes
 // handle disjoint reads and run side by side on the caller's stream and three helper streams (fork after the sort, join at the end).
@@ -560,33 +542,30 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 		if (n_launches) ++*n_launches;
 		return hipGetLastError();
 	}
-	// the grid is in order of decreasing read length: each class covers a contiguous range of blocks, the others exit at once
-	const bool use[5] = { true, A.biggest > TIE_CAP0, A.biggest > TIE_CAP1, A.biggest > TIE_MW_HI, A.biggest > TIE_CAP3 };
+	// The grid is in order of decreasing read capacity: class c holds reads of more than its PREV anchors, i.e. the first n_above[c] workgroups
+	// at most (a read keeps at most its capacity); those that belong to a longer class exit at once.  The classes of the longest reads go first, each on
+	// a helper stream; the shortest class stays on the caller's stream.
+	const unsigned grid[6] = { A.d_order ? (unsigned)A.n_above[0] : nr, A.d_order ? (unsigned)A.n_above[1] : nr, A.d_order ? (unsigned)A.n_above[2] : nr,
+	                           A.d_order ? (unsigned)A.n_above[3] : nr, A.d_order ? (unsigned)A.n_above[4] : nr, A.d_order ? (unsigned)A.n_above[5] : nr };
 	if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;                 // fork
 	bool used[3] = { false, false, false };
-	if (A.biggest > TIE_MW_LO) {                                                 // the multi-wave class, on a helper stream of its own
-		hipStream_t s = aux ? aux[2] : st;
-		if (s != st) { if ((e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e; used[2] = true; }
-		hipLaunchKernelGGL(seed_ties_mw, dim3(nr), dim3(64 * TIE_MW_WAVES), 0, s, A);
-		if ((e = hipGetLastError()) != hipSuccess) return e;
-		if (n_launches) ++*n_launches;
-	}
 	int helper = 0;
-	for (int c = 4; c >= 0; --c) {                                              // the longest reads first
-		if (!use[c]) continue;
+	for (int c = 5; c >= 0; --c) {
+		if (grid[c] == 0 || (c == 5 && !A.big_dg)) continue;
 		hipStream_t s = st;
-		if (c != 0 && aux && helper < 2) {                                       // class 0 (and whatever exceeds the helpers) stays on the caller's stream
-			s = aux[helper];
-			if (!used[helper] && (e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e;
-			used[helper] = true;
-			++helper;
+		if (c != 0 && aux) {
+			const int h = helper++ % 3;
+			s = aux[h];
+			if (!used[h] && (e = hipStreamWaitEvent(s, ev[0], 0)) != hipSuccess) return e;
+			used[h] = true;
 		}
 		switch (c) {
-		case 4: hipLaunchKernelGGL((seed_ties<0, TIE_CAP3>), dim3(nr), dim3(64), 0, s, A); break;
-		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_MW_HI>), dim3(nr), dim3(64), 0, s, A); break;
-		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1>), dim3(nr), dim3(64), 0, s, A); break;
-		case 1: hipLaunchKernelGGL((seed_ties<TIE_CAP1, TIE_CAP0>), dim3(nr), dim3(64), 0, s, A); break;
-		default: hipLaunchKernelGGL((seed_ties<TIE_CAP0, 0>), dim3(nr), dim3(64), 0, s, A); break;
+		case 5: hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
+		case 4: hipLaunchKernelGGL((seed_ties<TIE_CAP4, TIE_CAP3, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
+		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
+		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
+		case 1: hipLaunchKernelGGL((seed_ties<TIE_CAP1, TIE_CAP0, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
+		default: hipLaunchKernelGGL((seed_ties<TIE_CAP0, 0, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		if (n_launches) ++*n_launches;

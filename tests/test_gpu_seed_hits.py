@@ -102,19 +102,21 @@ def test_random_matches_against_the_oracle(seed):
 
 
 def test_reads_too_long_for_the_lds_replay():
-    """reads of the largest one-wave LDS class (16 385 .. 20 480 anchors) and beyond it (the replay runs through global memory), with equal x"""
+    """the size classes of seed_ties beyond one wave per read: 12 289 .. 65 536 anchors (four waves, digits in LDS), 65 537 .. 131 072 (the same with
+    128 KB of LDS) and beyond it (one wave, digits in global memory), with equal x"""
     rng = np.random.default_rng(77)
     reads = [_random_read(rng, 4500, 8, 2, 20000, qlen=60000), _random_read(rng, 3600, 10, 1, 1 << 24, qlen=60000, dup_frac=0.2),
-             _random_read(rng, 7000, 8, 2, 50000, qlen=90000), _random_read(rng, 9000, 6, 3, 1 << 25, qlen=90000, dup_frac=0.25)]
+             _random_read(rng, 7000, 8, 2, 50000, qlen=90000), _random_read(rng, 9000, 6, 3, 1 << 25, qlen=90000, dup_frac=0.25),
+             _random_read(rng, 22000, 8, 2, 90000, qlen=150000, dup_frac=0.1), _random_read(rng, 38000, 8, 3, 1 << 23, qlen=200000, dup_frac=0.2)]
     sizes = [int(r[1]["n"].sum()) for r in reads]
-    assert 16384 < sizes[0] <= 20480 or 16384 < sizes[1] <= 20480, sizes
-    assert sizes[2] > 20480 and sizes[3] > 20480, sizes
+    assert all(12288 < n <= 65536 for n in sizes[:4]), sizes
+    assert 65536 < sizes[4] <= 131072 and sizes[5] > 131072, sizes
     assert _check(reads, "long") > 1000
 
 
 @pytest.mark.parametrize("seed", range(3))
 def test_reads_of_the_multi_wave_replay_class(seed):
-    """12 289 .. 16 384 anchors with equal x: the replay runs level by level on the four waves of a workgroup (replay_levels)"""
+    """12 289 .. 16 384 anchors with equal x (the short end of the four-wave class: the replay runs level by level on the four waves of a workgroup, replay_levels)"""
     rng = np.random.default_rng(900 + seed)
     reads = []
     for pos_range, rids, dup in ((40000, 2, 0.0), (1 << 22, 3, 0.3), (3000, 1, 0.1)):
