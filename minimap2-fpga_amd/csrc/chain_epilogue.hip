@@ -865,7 +865,7 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 {
 	__shared__ uint16_t s_id[TS_MAX];
 	__shared__ uint8_t s_dg[TS_MAX + 8];                                         // (the walk of radix_replay.h looks one byte beyond the digit it takes)
-	__shared__ __attribute__((aligned(8))) int s_cur[512];
+	__shared__ __attribute__((aligned(8))) int s_cur[576];
 	__shared__ int s_lo[257], s_sp;
 	const int task = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	const int64_t base = A.d_off[task];
@@ -890,11 +890,11 @@ __global__ __launch_bounds__(64) void epi_tiesort(EpiArgs A)
 	for (int i = lane; i < nk; i += 64) rank_x[ord[i]] = sx[i];                  // back to rank order, as chain.c:407-410 fills w[]
 	__syncthreads();
 	if (nk <= TS_MAX) {
-		replay_passes<uint16_t, false>(rank_x, 1, sx, 1, tiecnt, nk, s_id, s_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
+		replay_passes<uint16_t, false, true>(rank_x, 1, sx, 1, tiecnt, nk, s_id, s_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
 		for (int i = lane; i < nk; i += 64) ids[i] = (int32_t)s_id[i];
 	} else {                                                                     // does not fit the LDS: same replay through global memory
 		uint8_t *g_dg = (uint8_t *)(stack + 2 * (nk / 64 + 2));
-		replay_passes<uint32_t, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
+		replay_passes<uint32_t, false, false>(rank_x, 1, sx, 1, tiecnt, nk, (uint32_t *)ids, g_dg, stack, moved, nullptr, nullptr, lane, s_cur, s_lo, &s_sp);
 	}
 	if (A.debug_phases == 22) return;
 	__syncthreads();

@@ -127,6 +127,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	S.d_order = (const int32_t *)(b + o_ord); S.status = (int32_t *)(b + o_stat); S.has_ties = (int32_t *)(b + o_ties);
 	S.tiecnt = (int32_t *)(b + o_tc); S.xdiff = (uint64_t *)(b + o_xd); S.biggest = biggest;
 	S.stack = (int32_t *)(b + o_stack); S.unsorted = (ulonglong2 *)(b + o_un); S.scratch = (ulonglong2 *)(b + o_scr);
+	{ const char *cut = getenv("MM2C_TIE_CUT"); S.debug_cut = cut ? atoi(cut) : 0; }
 	S.tie_id = (uint32_t *)(b + o_bid); S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
 	{
 		const int64_t *lower = mm2c::seed_tie_class_lower();                     // a read keeps at most its capacity: these bound the grids of the classes

@@ -15,6 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MM2C_REPLAY_SKIP_WALK
+#define MM2C_REPLAY_SKIP_WALK 0
+#endif
+
 namespace mm2c {
 
 __device__ __forceinline__ int rp_lanes_before(uint64_t m)
@@ -30,7 +34,7 @@ __device__ __forceinline__ int rp_incl_scan(int x, int lane)
 // un_x / sorted_x: the keys of the unsorted and of the (stably) sorted array, `stride` 64-bit words apart; tiecnt[i] = number of positions
 // j < i of the sorted array with key[j] == key[j+1]; id: position -> record (any memory); dg: one byte per position, with at least one
 // readable byte behind the last position; moved: one int per position; fa, fb: one int per position each (only with TWO_BUCKET);
-// s_cur: 512 ints (8-byte aligned), s_lo: 257 ints of LDS, private to the calling wave.  All synchronisation inside is wave-local, so several waves of a
+// s_cur: 576 ints (8-byte aligned; 256 cells and, with the digits in LDS, 256 bytes of links), s_lo: 257 ints of LDS, private to the calling wave.  All synchronisation inside is wave-local, so several waves of a
 // workgroup may replay different buckets at the same time.
 
 // LDS and global memory written by some lanes of the wave, read by others
@@ -54,9 +58,102 @@ __device__ __forceinline__ void rp_wave_sync()
 // index) are thus never touched by the sequential part, and the only LDS the replay needs is one byte per position.
 // s_cur[d] = {cursor of d, the digit at the cursor}: the cursor of the next bucket and the digit behind the current cursor are fetched side
 // by side, one LDS round trip per step.
+template <bool LDS_DG>
 __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, int32_t *moved, int lane, int *s_cnt, const int *s_lo)
 {
-	int2 *s_cur = (int2 *)s_cnt;                                             // {cursor relative to lo, digit at the cursor}: read and written in one piece
+	int2 *s_cur = (int2 *)s_cnt;                                             // {cursor, digit at the cursor}: read and written in one piece
+	if constexpr (LDS_DG) {
+		// The loop below written by hand (one lane; the compiler's version of it is twice as long): cells hold the LDS ADDRESS of the cursor's
+		// digit, s_nx[d] (bytes behind the 256 cells) links every bucket to the next one that is not empty (0: none) for the change of head,
+		// and the destination is stored as moved_base + 4 * address with the address of dg[0] folded into the base.
+		uint8_t *s_nx = (uint8_t *)(s_cur + 256);
+		const uint32_t dgA = (uint32_t)(uintptr_t)(const void *)dg;
+		uint64_t mask[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int d = 64 * r + lane, b = s_lo[d];
+			s_cur[d] = int2{(int)dgA + b, (int)dg[b]};                           // (an empty last bucket reads the byte behind the array)
+			mask[r] = __ballot(s_lo[d + 1] > b);
+		}
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			int nx = 0;
+#pragma unroll
+			for (int rr = 3; rr >= r; --rr) {
+				const uint64_t m = rr == r ? (lane == 63 ? 0 : mask[rr] & (~0ull << (lane + 1))) : mask[rr];
+				if (m) nx = 64 * rr + (int)__builtin_ctzll(m);
+			}
+			s_nx[64 * r + lane] = (uint8_t)nx;
+		}
+		int head = 0;
+#pragma unroll
+		for (int r = 3; r >= 0; --r) if (mask[r]) head = 64 * r + (int)__builtin_ctzll(mask[r]);
+		rp_wave_sync();
+		if (lane == 0) {
+			const uint64_t mb = (uint64_t)(uintptr_t)moved - 4ull * dgA;
+			asm volatile(
+				"v_mov_b32 v56, %1\n\tv_mov_b32 v57, %2\n\tv_mov_b32 v58, %3\n\tv_mov_b32 v59, %4\n\tv_mov_b32 v60, %0\n\t"
+				"s_branch 5f\n"
+				"1:\n\t"                                                          // step: state {v40 cell address of c, v41 cursor, v42 digit} -> {v44, v45, v46}
+				"v_cmp_eq_u64 vcc, v[40:41], v[52:53]\n\t"                        // standing at the head with its queue exhausted?
+				"s_cbranch_vccnz 3f\n\t"
+				"v_lshl_add_u32 v44, v42, 3, v56\n\t"                             // the cell of bucket d
+				"ds_read_u8 v51, v41 offset:1\n\t"                                // the digit behind the one taken
+				"ds_read_b64 v[48:49], v44\n\t"
+				"v_add_u32 v50, 1, v41\n\t"
+				"v_sub_u32 v55, v41, v57\n\t"                                     // source position
+				"v_cmp_eq_u32 vcc, v44, v40\n\t"
+				"s_waitcnt lgkmcnt(0)\n\t"
+				"ds_write_b64 v40, v[50:51]\n\t"
+				"v_cndmask_b32 v45, v48, v50, vcc\n\t"                            // d == c: the cell just written
+				"v_cndmask_b32 v46, v49, v51, vcc\n\t"
+				"v_cmp_eq_u32 vcc, v44, v52\n\t"                                  // d is the head: one place before its cursor
+				"v_subb_co_u32 v54, vcc, v45, 0, vcc\n\t"
+				"v_lshlrev_b32 v54, 2, v54\n\t"
+				"global_store_dword v54, v55, %5\n\t"
+				"v_cmp_eq_u64 vcc, v[44:45], v[52:53]\n\t"                        // the same with the two states exchanged
+				"s_cbranch_vccnz 3f\n\t"
+				"v_lshl_add_u32 v40, v46, 3, v56\n\t"
+				"ds_read_u8 v51, v45 offset:1\n\t"
+				"ds_read_b64 v[48:49], v40\n\t"
+				"v_add_u32 v50, 1, v45\n\t"
+				"v_sub_u32 v55, v45, v57\n\t"
+				"v_cmp_eq_u32 vcc, v40, v44\n\t"
+				"s_waitcnt lgkmcnt(0)\n\t"
+				"ds_write_b64 v44, v[50:51]\n\t"
+				"v_cndmask_b32 v41, v48, v50, vcc\n\t"
+				"v_cndmask_b32 v42, v49, v51, vcc\n\t"
+				"v_cmp_eq_u32 vcc, v40, v52\n\t"
+				"v_subb_co_u32 v54, vcc, v41, 0, vcc\n\t"
+				"v_lshlrev_b32 v54, 2, v54\n\t"
+				"global_store_dword v54, v55, %5\n\t"
+				"s_branch 1b\n"
+				"3:\n\t"                                                          // the next bucket that is not exhausted becomes the head
+				"v_add_u32 v61, v59, v60\n\t"
+				"ds_read_u8 v60, v61\n\t"
+				"s_waitcnt lgkmcnt(0)\n\t"
+				"v_cmp_eq_u32 vcc, 0, v60\n\t"
+				"s_cbranch_vccnz 9f\n"
+				"5:\n\t"
+				"v_lshl_add_u32 v52, v60, 3, v56\n\t"
+				"v_lshl_add_u32 v61, v60, 2, v58\n\t"
+				"ds_read_b64 v[48:49], v52\n\t"
+				"ds_read_b32 v53, v61 offset:4\n\t"
+				"v_mov_b32 v40, v52\n\t"
+				"s_waitcnt lgkmcnt(0)\n\t"
+				"v_mov_b32 v41, v48\n\t"
+				"v_mov_b32 v42, v49\n\t"
+				"v_add_u32 v53, v53, v57\n\t"
+				"v_cmp_eq_u32 vcc, v41, v53\n\t"
+				"s_cbranch_vccnz 3b\n\t"
+				"s_branch 1b\n"
+				"9:\n\t"
+				"s_waitcnt vmcnt(0) lgkmcnt(0)"
+				: : "v"(head), "v"((uint32_t)(uintptr_t)(void *)s_cur), "v"(dgA), "v"((uint32_t)(uintptr_t)(const void *)s_lo), "v"((uint32_t)(uintptr_t)(void *)s_nx), "s"(mb)
+				: "memory", "vcc", "v40", "v41", "v42", "v44", "v45", "v46", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61");
+		}
+		return;
+	}
 	for (int d = lane; d < 256; d += 64) { const int b = s_lo[d]; s_cur[d] = int2{b - lo, (int)dg[b]}; }   // (an empty last bucket reads the byte behind the array)
 	rp_wave_sync();
 	if (lane != 0) return;
@@ -83,7 +180,7 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 
 // One pass of the reference's sort over the bucket [lo, hi) (which must hold equal keys).  Sub-buckets that need the next pass are appended
 // to out_list (two ints each) through the counter *out_count.
-template <typename IdT, bool TWO_BUCKET>
+template <typename IdT, bool TWO_BUCKET, bool LDS_DG>
 __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int lo, int hi,
                               IdT *id, uint8_t *dg, int32_t *moved, int32_t *fa, int32_t *fb, int lane, int *s_cur, int *s_lo,
                               int32_t *out_list, int *out_count)
@@ -151,7 +248,7 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 			moved[fposA[t]] = fposB[t];
 			moved[t == 0 ? mid : fposB[t - 1] + 1] = fposA[t];
 		}
-	} else replay_walk(dg, lo, hi, moved, lane, s_cur, s_lo);              // ksort.h:117-131
+	} else if (!MM2C_REPLAY_SKIP_WALK) replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo);      // ksort.h:117-131
 	rp_wave_sync();
 	// the new arrangement: position q holds the record that stood at moved[q]
 	for (int q0 = lo; q0 < hi; q0 += 256) {
@@ -178,7 +275,7 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 }
 
 // The whole replay on one wave: buckets on a stack (2 * (n / 64 + 2) ints), s_sp one int of LDS.
-template <typename IdT, bool TWO_BUCKET>
+template <typename IdT, bool TWO_BUCKET, bool LDS_DG>
 __device__ __forceinline__ void replay_passes(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
                               uint8_t *dg, int32_t *stack, int32_t *moved, int32_t *fa, int32_t *fb, int lane, int *s_cur, int *s_lo, int *s_sp)
 {
@@ -192,14 +289,14 @@ __device__ __forceinline__ void replay_passes(const uint64_t *un_x, int un_strid
 		rp_wave_sync();
 		if (lane == 0) *s_sp = sp - 1;
 		rp_wave_sync();
-		replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, lo, hi, id, dg, moved, fa, fb, lane, s_cur, s_lo, stack, s_sp);
+		replay_bucket<IdT, TWO_BUCKET, LDS_DG>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, lo, hi, id, dg, moved, fa, fb, lane, s_cur, s_lo, stack, s_sp);
 	}
 }
 
 // The whole replay on the NW waves of a workgroup, level by level: the buckets of one level are independent, wave w takes every NW-th of
 // them; between levels one workgroup barrier (every wave reaches it: the loop is bounded by the eight byte positions of a key).
-// list_a / list_b: n / 64 + 2 buckets (two ints) each; s_n: two ints of LDS; s_cur: NW * 512, s_lo: NW * 257 ints of LDS.
-template <typename IdT, bool TWO_BUCKET, int NW>
+// list_a / list_b: n / 64 + 2 buckets (two ints) each; s_n: two ints of LDS; s_cur: NW * 576, s_lo: NW * 257 ints of LDS.
+template <typename IdT, bool TWO_BUCKET, bool LDS_DG, int NW>
 __device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
                               uint8_t *dg, int32_t *list_a, int32_t *list_b, int32_t *moved, int32_t *fa, int32_t *fb, int tid, int *s_cur, int *s_lo, int *s_n)
 {
@@ -215,8 +312,8 @@ __device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_strid
 		__syncthreads();
 		int32_t *in = cur ? list_b : list_a, *out = cur ? list_a : list_b;
 		for (int k = wave; k < n_seg; k += NW)
-			replay_bucket<IdT, TWO_BUCKET>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, moved, fa, fb, lane,
-			                               s_cur + 512 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1]);
+			replay_bucket<IdT, TWO_BUCKET, LDS_DG>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, moved, fa, fb, lane,
+			                               s_cur + 576 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1]);
 	}
 	__syncthreads();
 }

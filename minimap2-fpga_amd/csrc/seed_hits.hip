@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	const ulonglong2 *un = A.unsorted + a0;
 	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
 	int32_t *tiecnt = A.tiecnt + a0;
+	uint32_t *srt = A.tie_id + a0;
 	const uint64_t diff = A.xdiff[read];
 	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
 	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 		for (int i0 = 0; i0 < na; i0 += 64) {
 			const int i = i0 + lane;
 			const uint64_t k = i < na ? ks[i] : 0, kn = i + 1 < na ? ks[i + 1] : ~0ull;
-			if (i < na) out[i] = un[(int)(k & idm)];
+			if (i < na) { out[i] = un[(int)(k & idm)]; srt[i] = (uint32_t)(k & idm); }   // srt: which anchor of the unsorted array stands here (seed_ties reorders equal x by it)
 			const int flag = (i + 1 < na && (k >> idb) == (kn >> idb)) ? 1 : 0;
 			const int incl = wave_incl_scan(flag, lane);
 			if (i < na) tiecnt[i] = run + incl - flag;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 			run += __shfl(incl, 63);
 		}
 	}
-	if (lane == 0) A.has_ties[read] = run > 0;
+	if (lane == 0) A.has_ties[read] = run > 0 ? (kb + idb <= 64 ? 1 : 2) : 0;       // 2: sorted as whole anchors, no srt[]
 }
 
 // ---- the key sort of wave_sort_keys on the NW waves of a workgroup (for ONE long read whose sort a batch would otherwise wait for): per step
@@ -405,10 +406,10 @@ constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 655
 constexpr int TIE_MW_WAVES = 4;
 
 template <int CAP, int PREV, int NW>
-__global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 3 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
+__global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TIE_CAP0 ? 4 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
 {
 	__shared__ __attribute__((aligned(8))) uint8_t s_dg[CAP + 8];            // (the walk looks one byte beyond the digit it takes)
-	__shared__ __attribute__((aligned(8))) int s_cur[512 * NW];
+	__shared__ __attribute__((aligned(8))) int s_cur[576 * NW];
 	__shared__ int s_lo[257 * NW], s_n[2];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
@@ -417,13 +418,77 @@ __global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 3 : 5) void 
 	const int64_t a0 = g.a0;
 	const int na = g.na;
 	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
+	if (A.debug_cut == 1) return;
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
-	uint32_t *id = A.tie_id + a0;
+	// The replay leaves an arrangement id[] (position -> anchor of the unsorted array).  The reference's array is the stable sort of that
+	// arrangement by x; seed_sort already left the anchors sorted by x with equal x in the order of the unsorted array and srt[] = which anchor
+	// stands where, so only the runs of equal x have to be put in the order of the arrangement (has_ties == 1; == 2: no srt[], full sort below).
+	const bool fix = A.has_ties[read] == 1;
+	int32_t *w = (int32_t *)tmp;                                                 // the read's 16 bytes of scratch per anchor: four int arrays
+	uint32_t *id = fix ? (uint32_t *)(w + 3 * (int64_t)na) : A.tie_id + a0;
 	uint8_t *dg = CAP ? s_dg : A.big_dg + a0 + read;                             // one spare byte per read
 	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na / 64 + 2 entries per list suffice
-	int32_t *moved = (int32_t *)tmp, *fa = moved + na, *fb = fa + na;            // the read's 16 bytes of scratch per anchor
-	replay_levels<uint32_t, true, NW>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, id, dg, lists, lists + 2 * (na / 64 + 2),
-	                                   moved, fa, fb, tid, s_cur, s_lo, s_n);
+	int32_t *moved = w, *fa = w + na, *fb = fa + na;
+	replay_levels<uint32_t, true, CAP != 0, NW>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, id, dg, lists, lists + 2 * (na / 64 + 2),
+	                                             moved, fa, fb, tid, s_cur, s_lo, s_n);
+	if (A.debug_cut == 2) return;
+	if (fix) {
+		// place[i] = where the anchor at sorted position i stands in the arrangement; inside a run of equal x the anchor with the k-th smallest
+		// place goes to the k-th position of the run.  Runs are short (one reference position hit by a few query minimizers): every position
+		// of a run counts the smaller places of its run by itself, from a window of place[] and of the prefix counts of equal neighbours that
+		// its wave keeps in LDS (64 positions and RUN_MAX - 1 on either side).  A run of RUN_MAX positions or more: the full sort below.
+		constexpr int RUN_MAX = 224, MARGIN = RUN_MAX - 1, WIN = 64 + 2 * MARGIN;
+		static_assert(WIN <= 576 && 2 * WIN <= 4 * 257, "the windows take the place of the replay's tables");
+		const uint32_t *srt = A.tie_id + a0;
+		const int32_t *tiecnt = A.tiecnt + a0;
+		int32_t *inv = w, *place = w + na;
+		const int lane = tid & 63, wave = tid >> 6;
+		int *winp = s_cur + 576 * wave;
+		uint16_t *wint = (uint16_t *)(s_lo + 257 * wave);
+		for (int q = tid; q < na; q += 64 * NW) inv[id[q]] = q;
+		__syncthreads();
+		for (int i = tid; i < na; i += 64 * NW) place[i] = inv[srt[i]];
+		__syncthreads();
+		if (A.debug_cut == 3) return;
+		bool over = false;
+		for (int i0 = 64 * wave; i0 < na; i0 += 64 * NW) {
+			const int i = i0 + lane;
+			bool tied = false;
+			if (i < na) {
+				const int t0 = tiecnt[i], t1 = i + 1 < na ? tiecnt[i + 1] : t0, tm = i > 0 ? tiecnt[i - 1] : t0;
+				tied = t1 != t0 || t0 != tm;                                       // tiecnt[k + 1] - tiecnt[k] = 1: x[k] == x[k + 1]
+			}
+			if (!__ballot(tied)) continue;
+			const int base = i0 - MARGIN, tb = tiecnt[base > 0 ? base : 0];
+			rp_wave_sync();                                                        // the window of the step before has been read
+			for (int k = lane; k < WIN; k += 64) {
+				const int idx = base + k;
+				const bool in = idx >= 0 && idx < na;
+				winp[k] = in ? place[idx] : 0;
+				wint[k] = in ? (uint16_t)(tiecnt[idx] - tb) : (uint16_t)0;
+			}
+			rp_wave_sync();
+			if (!tied) continue;
+			// the run [s, e] of i, in window positions: every neighbour pair between two positions is equal when their prefix counts differ by their distance
+			const int iw = lane + MARGIN, ti = wint[iw];
+			int sw = iw, ew = iw;
+			for (int step = 128; step > 0; step >>= 1) {
+				const int a = sw - step, b = ew + step;
+				if (a >= iw - MARGIN && base + a >= 0 && ti - (int)wint[a] == iw - a) sw = a;
+				if (b <= iw + MARGIN && base + b < na && (int)wint[b] - ti == b - iw) ew = b;
+			}
+			if (ew - sw >= MARGIN) { over = true; continue; }                      // (the first position of a run that long sees it)
+			const int mine = winp[iw];
+			int rank = 0;
+#pragma unroll 4
+			for (int j = sw; j <= ew; ++j) rank += winp[j] < mine;
+			out[base + sw + rank] = un[srt[i]];
+		}
+		if (!__syncthreads_or(over)) return;
+		for (int q = tid; q < na; q += 64 * NW) A.tie_id[a0 + q] = id[q];        // srt[] has served: the arrangement moves there, the scratch is needed for the keys
+		__syncthreads();
+		id = A.tie_id + a0;
+	}
 	// the final stable sort of the replayed arrangement: keys = (differing bits of x, squeezed) << id bits | position in the arrangement, as in
 	// seed_sort (the scratch of the replay is free now)
 	const uint64_t diff = A.xdiff[read];
