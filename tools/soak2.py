@@ -95,7 +95,8 @@ for r in range(rounds):
     # 3. seed hits
     reads = []
     for _ in range(int(rng.integers(1, 6))):
-        nm = int(rng.integers(0, 1500)); max_n = int(rng.integers(0, 9))
+        nm = int(rng.integers(0, 1500)) if rng.random() > 0.12 else int(rng.integers(3000, 24000))   # now and then a read of the longer size classes of seed_ties (up to ~10^5 anchors)
+        max_n = int(rng.integers(0, 9))
         m = np.zeros(nm, ob.MATCH_DTYPE)
         qlen = int(rng.integers(100, 50000))
         m["q_pos"] = (np.sort(rng.integers(15, qlen, nm)).astype(np.uint32) << 1) | rng.integers(0, 2, nm).astype(np.uint32)
