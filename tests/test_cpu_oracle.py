@@ -407,3 +407,24 @@ def test_compact_ring_arithmetic_is_exact_within_its_bound():
         # one beyond the bound: a pair with dq = -(bound + 1) passes the 16-bit test as dq = max_dq
         qi, qj = 0, bound + 1
         assert ((qi & 0xffff) - 1 - (qj & 0xffff)) & 0xffff == max_dq - 1
+
+
+def test_walk_restatement_of_the_tie_replay_equals_the_cycle_leader_loop():
+    """csrc/radix_replay.h replays a pass of radix_sort_128x (ksort.h:117-131) as a walk that reads digits only and records source -> destination.
+    The restatement, and the control flow of the hand-written loop built on it, against the literal loop on random digit arrays: few and many buckets,
+    skewed digits (long in-place runs at the head), buckets that are exhausted before they become the head."""
+    import random
+    import replay_model as rm
+    rnd = random.Random(12345)
+    for trial in range(6000):
+        K = rnd.choice([2, 3, 4, 7, 16, 256])
+        n = rnd.randint(1, 300)
+        if rnd.random() < 0.3:
+            dig = [rnd.randrange(K) if rnd.random() < 0.5 else 0 for _ in range(n)]
+        elif rnd.random() < 0.2:
+            dig = sorted(rnd.randrange(K) for _ in range(n))          # already distributed: every record in place
+        else:
+            dig = [rnd.randrange(K) for _ in range(n)]
+        ids = rm.literal(dig, K)
+        assert rm.walk(dig, K) == ids, (trial, dig)
+        assert rm.asm_walk(dig, K) == ids, (trial, dig)
