@@ -436,53 +436,75 @@ __global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TI
 		// place[i] = where the anchor at sorted position i stands in the arrangement; inside a run of equal x the anchor with the k-th smallest
 		// place goes to the k-th position of the run.  Runs are short (one reference position hit by a few query minimizers): every position
 		// of a run counts the smaller places of its run by itself, from a window of place[] and of the prefix counts of equal neighbours that
-		// its wave keeps in LDS (64 positions and RUN_MAX - 1 on either side).  A run of RUN_MAX positions or more: the full sort below.
-		constexpr int RUN_MAX = 224, MARGIN = RUN_MAX - 1, WIN = 64 + 2 * MARGIN;
-		static_assert(WIN <= 576 && 2 * WIN <= 4 * 257, "the windows take the place of the replay's tables");
+		// its wave keeps in LDS (STEP positions and RUN_MAX - 1 on either side; the digits and tables of the replay have served: their space
+		// takes the windows).  A run of RUN_MAX positions or more: the full sort below.
+		constexpr int RUN_MAX = 224, MARGIN = RUN_MAX - 1;
+		constexpr int ROOM_P = CAP ? (CAP / NW) / 4 : 576, ROOM_T = CAP ? 2 * 576 : 2 * 257;   // entries the two windows may take per wave
+		constexpr int STEP_P = (ROOM_P - 2 * MARGIN) / 64 * 64, STEP_T = (ROOM_T - 2 * MARGIN) / 64 * 64;
+		constexpr int STEP = STEP_P < STEP_T ? (STEP_P < 512 ? STEP_P : 512) : (STEP_T < 512 ? STEP_T : 512), KP = STEP / 64, WIN = STEP + 2 * MARGIN;
+		static_assert(STEP >= 64 && WIN <= ROOM_P && WIN <= ROOM_T, "the windows fit the space of the replay");
 		const uint32_t *srt = A.tie_id + a0;
 		const int32_t *tiecnt = A.tiecnt + a0;
 		int32_t *inv = w, *place = w + na;
 		const int lane = tid & 63, wave = tid >> 6;
-		int *winp = s_cur + 576 * wave;
-		uint16_t *wint = (uint16_t *)(s_lo + 257 * wave);
+		int *winp = CAP ? (int *)(s_dg + (CAP / NW) * wave) : s_cur + 576 * wave;
+		uint16_t *wint = CAP ? (uint16_t *)(s_cur + 576 * wave) : (uint16_t *)(s_lo + 257 * wave);
 		for (int q = tid; q < na; q += 64 * NW) inv[id[q]] = q;
 		__syncthreads();
 		for (int i = tid; i < na; i += 64 * NW) place[i] = inv[srt[i]];
 		__syncthreads();
 		if (A.debug_cut == 3) return;
 		bool over = false;
-		for (int i0 = 64 * wave; i0 < na; i0 += 64 * NW) {
-			const int i = i0 + lane;
-			bool tied = false;
-			if (i < na) {
-				const int t0 = tiecnt[i], t1 = i + 1 < na ? tiecnt[i + 1] : t0, tm = i > 0 ? tiecnt[i - 1] : t0;
-				tied = t1 != t0 || t0 != tm;                                       // tiecnt[k + 1] - tiecnt[k] = 1: x[k] == x[k + 1]
+		for (int c0 = STEP * wave; c0 < na; c0 += STEP * NW) {
+			bool tied[KP], any = false;
+#pragma unroll
+			for (int k = 0; k < KP; ++k) {
+				const int i = c0 + 64 * k + lane, ic = i < na ? i : na - 1;
+				const int t0 = tiecnt[ic], t1 = tiecnt[ic + 1 < na ? ic + 1 : ic], tm = tiecnt[ic > 0 ? ic - 1 : 0];
+				tied[k] = i < na && (t1 != t0 || t0 != tm);                        // tiecnt[j + 1] - tiecnt[j] = 1: x[j] == x[j + 1]
+				any |= tied[k];
 			}
-			if (!__ballot(tied)) continue;
-			const int base = i0 - MARGIN, tb = tiecnt[base > 0 ? base : 0];
-			rp_wave_sync();                                                        // the window of the step before has been read
-			for (int k = lane; k < WIN; k += 64) {
-				const int idx = base + k;
-				const bool in = idx >= 0 && idx < na;
-				winp[k] = in ? place[idx] : 0;
-				wint[k] = in ? (uint16_t)(tiecnt[idx] - tb) : (uint16_t)0;
+			if (!__ballot(any)) continue;
+			const int base = c0 - MARGIN, tb = tiecnt[base > 0 ? base : 0];
+			rp_wave_sync();                                                        // the windows of the step before have been read
+			{
+				constexpr int NWIN = (WIN + 63) / 64;
+				int wp[NWIN], wt[NWIN];                                              // all loads of the two windows in flight together
+#pragma unroll
+				for (int k = 0; k < NWIN; ++k) {
+					const int idx = base + 64 * k + lane, ci = idx < 0 ? 0 : idx >= na ? na - 1 : idx;
+					wp[k] = place[ci]; wt[k] = tiecnt[ci];
+				}
+#pragma unroll
+				for (int k = 0; k < NWIN; ++k)
+					if (64 * k + lane < WIN) { winp[64 * k + lane] = wp[k]; wint[64 * k + lane] = (uint16_t)(wt[k] - tb); }
 			}
 			rp_wave_sync();
-			if (!tied) continue;
-			// the run [s, e] of i, in window positions: every neighbour pair between two positions is equal when their prefix counts differ by their distance
-			const int iw = lane + MARGIN, ti = wint[iw];
-			int sw = iw, ew = iw;
-			for (int step = 128; step > 0; step >>= 1) {
-				const int a = sw - step, b = ew + step;
-				if (a >= iw - MARGIN && base + a >= 0 && ti - (int)wint[a] == iw - a) sw = a;
-				if (b <= iw + MARGIN && base + b < na && (int)wint[b] - ti == b - iw) ew = b;
-			}
-			if (ew - sw >= MARGIN) { over = true; continue; }                      // (the first position of a run that long sees it)
-			const int mine = winp[iw];
-			int rank = 0;
+			int dst[KP], rec[KP];
+#pragma unroll
+			for (int k = 0; k < KP; ++k) {
+				dst[k] = -1; rec[k] = 0;
+				if (!tied[k]) continue;
+				// the run [s, e] of i, in window positions: every neighbour pair between two positions is equal when their prefix counts differ by their distance
+				const int iw = 64 * k + lane + MARGIN, ti = wint[iw];
+				int sw = iw, ew = iw;
+				for (int step = 128; step > 0; step >>= 1) {
+					const int a = sw - step, b = ew + step;
+					if (a >= iw - MARGIN && base + a >= 0 && ti - (int)wint[a] == iw - a) sw = a;
+					if (b <= iw + MARGIN && base + b < na && (int)wint[b] - ti == b - iw) ew = b;
+				}
+				if (ew - sw >= MARGIN) { over = true; continue; }                    // (the first position of a run that long sees it)
+				const int mine = winp[iw];
+				int rank = 0;
 #pragma unroll 4
-			for (int j = sw; j <= ew; ++j) rank += winp[j] < mine;
-			out[base + sw + rank] = un[srt[i]];
+				for (int j = sw; j <= ew; ++j) rank += winp[j] < mine;
+				dst[k] = base + sw + rank; rec[k] = (int)srt[c0 + 64 * k + lane];
+			}
+			ulonglong2 an[KP];
+#pragma unroll
+			for (int k = 0; k < KP; ++k) { an[k] = ulonglong2{0, 0}; if (dst[k] >= 0) an[k] = un[rec[k]]; }
+#pragma unroll
+			for (int k = 0; k < KP; ++k) if (dst[k] >= 0) out[dst[k]] = an[k];
 		}
 		if (!__syncthreads_or(over)) return;
 		for (int q = tid; q < na; q += 64 * NW) A.tie_id[a0 + q] = id[q];        // srt[] has served: the arrangement moves there, the scratch is needed for the keys
