@@ -10,5 +10,5 @@ import csv,glob
 for fn in glob.glob("gpurun_out/prof/r4_secondary/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(fn)):
         if "mm2c::" in r["Name"] and float(r["TotalDurationNs"])>2e5:
-            print("%-72s calls %4s avg %8.3f ms total %8.2f ms" % (r["Name"].split("(")[0].replace("void ","")[:72], r["Calls"], float(r["AverageNs"])/1e6, float(r["TotalDurationNs"])/1e6))
+            print("%-72s calls %4s avg %8.3f ms total %8.2f ms" % (r["Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","")[:72], r["Calls"], float(r["AverageNs"])/1e6, float(r["TotalDurationNs"])/1e6))
 PY
