@@ -34,6 +34,10 @@
 
 namespace mm2c {
 
+#ifndef MM2C_COOP_FAR_TILES
+#define MM2C_COOP_FAR_TILES 4
+#endif
+constexpr int COOP_FAR_TILES = MM2C_COOP_FAR_TILES;   // tiles beyond the x / q ring whose candidates phase A still deals (from memory)
 constexpr int COOP_NX = 16, COOP_NF = 8;    // rings of the cooperative kernel: 960 anchors of look-back in LDS, f / p of the 8 nearest tiles beside them
 constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that must take the exact scan
 
@@ -198,7 +202,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// candidates j1 - 1 down to j0 of older tiles against the 64 anchors of the tile that starts at anchor t0 (per lane: x - 1, q - 1, span - 1, window start), in units
 		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (An anchor with equal-x predecessors in an older tile never takes
 		// the short cut, so dr == 0 needs no thought here.)
-		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1) {
+		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1, int ring_lo) {
 			int best_l = SENT, jb_l = -1, cnt_l = 0;
 			unsigned long long m_l = 0;                          // d1: which anchors of the tile before t0 are candidates (bit c: anchor t0 - 1 - c)
 			const int n_units = (j1 - j0 + 7) >> 3;
@@ -209,8 +213,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				const int jl = j1 - 1 - 8 * u - (lane & 7);          // lanes 0 .. 7 fetch the unit's candidates
 				int xv = 0, qv = 0, fv = 0;
 				if (lane < 8 && jl >= j0) {
-					const int2 xq = *(const int2 *)(lds + LY::XQ + (jl & (SN - 1)) * 8);
-					xv = xq.x; qv = xq.y;
+					if (!FAR || jl >= ring_lo) { const int2 xq = *(const int2 *)(lds + LY::XQ + (jl & (SN - 1)) * 8); xv = xq.x; qv = xq.y; }
+					else { const uint4 aj = a[jl]; xv = (int)aj.x; qv = (int)aj.z; }   // a candidate of a tile that has left the ring: from memory (the anchors are read-only)
 					if ((t0 >> 6) - (jl >> 6) <= NF) fv = ((const int2 *)(lds + LY::FP + ((jl << 3) & LY::FMASK)))->x + FBIAS;
 					else fv = __hip_atomic_load(&f[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
@@ -266,7 +270,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// ---- the tile before this one (the part of it inside the first anchor's window and the ring); the first tile's table (the later ones are made a tile ahead, below)
 			const int lo_first = rdlane(lo_l, 63);
 			const int jmin = max(max(lo_first, stamp_lo), 0);
-			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l, true);
+			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l, true, stamp_lo);
 			else own_table(0, cnt, wv, W, own_x, own_q, span1_l, lo_l);
 		}
 		int *const s_pair = s_pair2 + ((i0 >> 6) & 1) * (64 * 64);          // this tile's table
@@ -294,7 +298,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// The rank is known only once the anchor's maximum is, so the anchors are walked as if all of them qualified and each is checked when it becomes final;
 			// the few that fail (a best predecessor more than max_skip candidates away) take the exact scan.  Not eligible at all: a window beyond the ring, an
 			// equal-x run that reaches into the tile before.
-			const bool tent_l = rl < cnt && !(FAR && lo_l < stamp_lo && lo_l < idx) && e_l <= rl && !no_pairs;
+			const bool tent_l = rl < cnt && !(FAR && lo_l < stamp_lo - 64 * COOP_FAR_TILES && lo_l < idx) && e_l <= rl && !no_pairs;
 			mask_t tents = BALLOT(tent_l);
 			auto rank_ok = [&](int j) -> bool {                 // per lane: is candidate j (this lane's best) among the first max_skip + 1 of its scan?
 				int r;
@@ -439,9 +443,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int t0 = i0 + 64, idn = t0 + rl;
 			const int lo_n = no_pairs ? idn : min(nxt_st, idn);
 			const int lo_first_n = rdlane(lo_n, 63);
-			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1)), 0);
+			// (FAR: up to COOP_FAR_TILES tiles beyond the ring are dealt as well, their x / q from memory, so that an anchor whose window reaches a little further back
+			// than the ring -- the 1 024 anchors of a V2 scan are up to 17 tiles -- keeps the short cut)
+			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1 + (FAR ? COOP_FAR_TILES : 0))), 0);
 			const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
-			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false);
+			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false, t0 - 64 * (NX - 1));   // (the slot of the tile NX back from the next one is the next tile's: wave 0 fills it when it gets there)
 			own_table(t0, min(64, n - t0), wv - 1, W - 1, (int)nxt.x, (int)nxt.z, sp_n, lo_n);   // x and q only: nothing of it waits for this tile's walk
 		}
 #if MM2C_COOP_PROBE == 9
