@@ -15,10 +15,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef MM2C_REPLAY_SKIP_WALK
-#define MM2C_REPLAY_SKIP_WALK 0
-#endif
-
 namespace mm2c {
 
 __device__ __forceinline__ int rp_lanes_before(uint64_t m)
@@ -248,7 +244,7 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 			moved[fposA[t]] = fposB[t];
 			moved[t == 0 ? mid : fposB[t - 1] + 1] = fposA[t];
 		}
-	} else if (!MM2C_REPLAY_SKIP_WALK) replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo);      // ksort.h:117-131
+	} else replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo);      // ksort.h:117-131
 	rp_wave_sync();
 	// the new arrangement: position q holds the record that stood at moved[q]
 	for (int q0 = lo; q0 < hi; q0 += 256) {
