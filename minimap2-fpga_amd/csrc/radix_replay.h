@@ -188,12 +188,14 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 	const int shift = (63 - __clzll(diff)) & ~7;
 	for (int d = lane; d < 256; d += 64) s_cur[d] = 0;
 	rp_wave_sync();
-	for (int q0 = lo; q0 < hi; q0 += 256) {                                  // four gathers in flight per lane
-		uint64_t x[4];
+	for (int q0 = lo; q0 < hi; q0 += 512) {                                  // eight gathers in flight per lane
+		int r[8]; uint64_t x[8];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; x[k] = q < hi ? un_x[(int64_t)id[q] * un_stride] : 0; }
+		for (int k = 0; k < 8; ++k) { const int q = q0 + 64 * k + lane; r[k] = (int)id[q < hi ? q : lo]; }
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
+		for (int k = 0; k < 8; ++k) x[k] = un_x[(int64_t)r[k] * un_stride];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
 			const int q = q0 + 64 * k + lane;
 			if (q < hi) { const int d = (int)(x[k] >> shift) & 255; dg[q] = (uint8_t)d; atomicAdd(&s_cur[d], 1); }
 		}
@@ -247,12 +249,14 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 	} else replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo);      // ksort.h:117-131
 	rp_wave_sync();
 	// the new arrangement: position q holds the record that stood at moved[q]
-	for (int q0 = lo; q0 < hi; q0 += 256) {
-		int v[4];
+	for (int q0 = lo; q0 < hi; q0 += 512) {
+		int v[8];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; v[k] = q < hi ? (int)id[moved[q]] : 0; }
+		for (int k = 0; k < 8; ++k) { const int q = q0 + 64 * k + lane; v[k] = moved[q < hi ? q : lo]; }
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const int q = q0 + 64 * k + lane; if (q < hi) moved[q] = v[k]; }
+		for (int k = 0; k < 8; ++k) v[k] = (int)id[v[k]];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { const int q = q0 + 64 * k + lane; if (q < hi) moved[q] = v[k]; }
 	}
 	rp_wave_sync();
 	for (int q = lo + lane; q < hi; q += 64) id[q] = (IdT)moved[q];
