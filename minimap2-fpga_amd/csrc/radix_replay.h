@@ -86,7 +86,9 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 		for (int r = 3; r >= 0; --r) if (mask[r]) head = 64 * r + (int)__builtin_ctzll(mask[r]);
 		rp_wave_sync();
 		if (lane == 0) {
-			const uint64_t mb = (uint64_t)(uintptr_t)moved - 4ull * dgA;
+			const uint64_t mb0 = (uint64_t)(uintptr_t)moved - 4ull * dgA;
+			// (a scalar operand: the pointer is the same in every lane, but the compiler does not always see that and would hand the block a VGPR pair)
+			const uint64_t mb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mb0 >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mb0);
 			asm volatile(
 				"v_mov_b32 v56, %1\n\tv_mov_b32 v57, %2\n\tv_mov_b32 v58, %3\n\tv_mov_b32 v59, %4\n\tv_mov_b32 v60, %0\n\t"
 				"s_branch 5f\n"

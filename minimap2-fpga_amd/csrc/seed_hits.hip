@@ -399,14 +399,18 @@ __device__ uint64_t *block_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo
 // ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
 // The sequential part of the replay (the walk of replay_walk) reads digits only, so a read needs ONE byte of LDS per anchor (the index
 // array, the permutation of a pass and the lists of the closed form live in global memory and are touched by all lanes); size classes keep
-// the occupancy of the common (short) reads high: up to 12 288 anchors one wave replays a read, longer reads -- whose replay a batch waits
-// for -- run the independent buckets of each level and the final sort on the four waves of a workgroup, with up to 128 K digits in LDS
-// (gfx950: 160 KB per workgroup).  CAP = 0: reads beyond that, digits in global memory.
+// the occupancy of the common (short) reads high: up to 6 144 anchors one wave replays a read, longer reads -- whose replay a batch waits
+// for -- run the independent buckets of each level, the sweeps and the final order on two (up to 12 288 anchors) or eight waves of a
+// workgroup, with up to 128 K digits in LDS (gfx950: 160 KB per workgroup).  CAP = 0: reads beyond that, digits in global memory.
 constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 65536, TIE_CAP4 = 131072;
-constexpr int TIE_MW_WAVES = 4;
+constexpr int TIE_MW_WAVES = 8;
+#ifndef MM2C_TIE_SW
+#define MM2C_TIE_SW 2
+#endif
+constexpr int TIE_SW = MM2C_TIE_SW;            // waves per read of the 6 145 .. 12 288 class (its reads are few and long enough to set the time of a chunk; the classes below it are many reads: one wave each)
 
 template <int CAP, int PREV, int NW>
-__global__ __launch_bounds__(64 * NW, NW > 1 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TIE_CAP0 ? 4 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
+__global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TIE_CAP0 ? 4 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
 {
 	__shared__ __attribute__((aligned(8))) uint8_t s_dg[CAP + 8];            // (the walk looks one byte beyond the digit it takes)
 	__shared__ __attribute__((aligned(8))) int s_cur[576 * NW];
@@ -650,7 +654,7 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 		case 5: hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
 		case 4: hipLaunchKernelGGL((seed_ties<TIE_CAP4, TIE_CAP3, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
 		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
-		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
+		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1, TIE_SW>), dim3(grid[c]), dim3(64 * TIE_SW), 0, s, A); break;
 		case 1: hipLaunchKernelGGL((seed_ties<TIE_CAP1, TIE_CAP0, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
 		default: hipLaunchKernelGGL((seed_ties<TIE_CAP0, 0, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
 		}

@@ -115,17 +115,19 @@ def test_reads_too_long_for_the_lds_replay():
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_reads_of_the_multi_wave_replay_class(seed):
-    """12 289 .. 16 384 anchors with equal x (the short end of the four-wave class: the replay runs level by level on the four waves of a workgroup, replay_levels)"""
-    rng = np.random.default_rng(900 + seed)
+@pytest.mark.parametrize("lo,hi,n_matches", [(12288, 16384, 3400), (6144, 12288, 2300)])
+def test_reads_of_the_multi_wave_replay_classes(seed, lo, hi, n_matches):
+    """reads with equal x whose replay runs level by level on several waves of a workgroup (replay_levels): 12 289 .. 16 384 anchors (the short end of the
+    eight-wave class) and 6 145 .. 12 288 (two waves)"""
+    rng = np.random.default_rng(900 + seed + lo)
     reads = []
     for pos_range, rids, dup in ((40000, 2, 0.0), (1 << 22, 3, 0.3), (3000, 1, 0.1)):
         while True:
-            r = _random_read(rng, 3400, 8, rids, pos_range, qlen=40000, dup_frac=dup)
-            if 12288 < int(r[1]["n"].sum()) <= 16384:
+            r = _random_read(rng, n_matches, 8, rids, pos_range, qlen=40000, dup_frac=dup)
+            if lo < int(r[1]["n"].sum()) <= hi:
                 break
         reads.append(r)
-    assert _check(reads, f"mw {seed}") > 100
+    assert _check(reads, f"mw {seed} {lo}") > 100
 
 
 def test_anchor_offsets_that_do_not_match_the_hit_counts_are_reported():
