@@ -200,8 +200,8 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			return min3i(dq1, dr1, sp1) - 14 - (int)((float)dd * avg) + (cz >> 1);       // min(dq, dr, span) - (lin + (ilog2(dd) >> 1)): 1 - 15 = -14
 		};
 		// candidates j1 - 1 down to j0 of older tiles against the 64 anchors of the tile that starts at anchor t0 (per lane: x - 1, q - 1, span - 1, window start), in units
-		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (An anchor with equal-x predecessors in an older tile never takes
-		// the short cut, so dr == 0 needs no thought here.)
+		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (A predecessor with equal x, dr == 0, is rejected by pair_ok: dr - 1 is
+		// 0xffffffff and the unsigned |dr - dq| huge.)
 		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1, int ring_lo) {
 			int best_l = SENT, jb_l = -1, cnt_l = 0;
 			unsigned long long m_l = 0;                          // d1: which anchors of the tile before t0 are candidates (bit c: anchor t0 - 1 - c)
@@ -296,9 +296,10 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// scores is the one the strict `>` of chain.c:226 keeps.  Its rank = the number of candidates nearer than it, counted from the candidate masks of the own
 			// tile and of the tile before (deeper: bounded by the candidate count).  No candidate better than the span (p = -1): true of every visited subset as well.
 			// The rank is known only once the anchor's maximum is, so the anchors are walked as if all of them qualified and each is checked when it becomes final;
-			// the few that fail (a best predecessor more than max_skip candidates away) take the exact scan.  Not eligible at all: a window beyond the ring, an
-			// equal-x run that reaches into the tile before.
-			const bool tent_l = rl < cnt && !(FAR && lo_l < stamp_lo - 64 * COOP_FAR_TILES && lo_l < idx) && e_l <= rl && !no_pairs;
+			// the few that fail (a best predecessor more than max_skip candidates away) take the exact scan.  Not eligible at all: a window that reaches further back
+			// than the tiles phase A deals.  (An equal-x run that reaches into the tile before is no obstacle: a predecessor with equal x fails the pair filter -- dr - 1
+			// is 0xffffffff, the unsigned |dr - dq| huge -- in every tile; only the hand-written loop leaves such anchors to the C++ scan.)
+			const bool tent_l = rl < cnt && !(FAR && lo_l < stamp_lo - 64 * COOP_FAR_TILES && lo_l < idx) && !no_pairs;
 			mask_t tents = BALLOT(tent_l);
 			auto rank_ok = [&](int j) -> bool {                 // per lane: is candidate j (this lane's best) among the first max_skip + 1 of its scan?
 				int r;
