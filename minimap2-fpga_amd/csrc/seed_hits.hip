@@ -280,6 +280,103 @@ __device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo,
 	return from;
 }
 
+// ---- kernel 2a: the same sort for reads of up to SORT_LDS_CAP anchors whose differing bits of x fit 32, entirely in LDS ------------------------
+// seed_sort moves 8-byte keys through global memory, four scattered passes for every read of a batch at once: the lines are evicted half written
+// (thousands of reads in flight, two 40 KB buffers each) and the passes run at the speed of that traffic.  Here a workgroup of SORT_LDS_WAVES waves keeps
+// the read's squeezed keys (4 bytes) and two index buffers (2 bytes each) in LDS -- 8 bytes per anchor, three reads per CU -- and only the final gather
+// of the 16-byte anchors touches memory.  Stable LSD radix sort of the indices on the key's bytes: per step of 64 * NW indices every wave ranks its own 64
+// (peers by ballots) and publishes its per-digit counts; an index lands at the digit's cursor + the counts of the waves before its own + its rank.
+constexpr int SORT_LDS_CAP = 5120, SORT_LDS_WAVES = 4;
+
+__global__ __launch_bounds__(64 * SORT_LDS_WAVES) void seed_sort_lds(SeedArgs A, int blk0)
+{
+	constexpr int NW = SORT_LDS_WAVES, NT = 64 * NW;
+	__shared__ uint32_t s_key[SORT_LDS_CAP];
+	__shared__ uint16_t s_ia[SORT_LDS_CAP], s_ib[SORT_LDS_CAP];
+	__shared__ int s_cnt[256], s_w[256 * NW], s_carry[NW + 1];
+	const int read = A.d_order ? A.d_order[blk0 + blockIdx.x] : blk0 + (int)blockIdx.x;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const ReadGeom g = read_geom(A, read);
+	const int na = g.na;
+	if (A.d_anchor_off[read + 1] - g.a0 > SORT_LDS_CAP) return;                 // by capacity, as the launch order and seed_sort's test
+	if (A.status[read] != 0 || na == 0) { if (tid == 0) A.has_ties[read] = 0; return; }
+	const uint64_t diff = A.xdiff[read];
+	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
+	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
+	const int kb = b0 + b1 + bs;
+	if (kb > 32) return;                                                       // seed_sort takes it
+	const ulonglong2 *un = A.unsorted + g.a0;
+	ulonglong2 *out = A.d_anchors + g.o0;
+	int32_t *tiecnt = A.tiecnt + g.a0;
+	uint32_t *srt = A.tie_id + g.a0;
+	const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+	for (int i = tid; i < na; i += NT) {
+		const uint64_t x = un[i].x;
+		s_key[i] = (uint32_t)((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0));   // order preserving: the dropped bits are constant
+		s_ia[i] = (uint16_t)i;
+	}
+	uint16_t *from = s_ia, *to = s_ib;
+	for (int shift = 0; shift < kb; shift += 8) {
+		for (int d = tid; d < 256; d += NT) s_cnt[d] = 0;
+		for (int d = tid; d < 256 * NW; d += NT) s_w[d] = 0;
+		__syncthreads();                                                       // (also: the keys and indices of the pass before are in place)
+		for (int i = tid; i < na; i += NT) atomicAdd(&s_cnt[(s_key[i] >> shift) & 255], 1);   // the histogram does not depend on the order
+		__syncthreads();
+		if (wave == 0) {
+			int h[4], sum = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { h[u] = s_cnt[4 * lane + u]; sum += h[u]; }
+			int at = wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { s_cnt[4 * lane + u] = at; at += h[u]; }
+		}
+		__syncthreads();
+		for (int i0 = 0; i0 < na; i0 += NT) {
+			const int i = i0 + tid;
+			const bool valid = i < na;
+			const int id = valid ? (int)from[i] : 0;
+			const int d = valid ? (int)((s_key[id] >> shift) & 255) : 0;
+			uint64_t peers = __ballot(valid);
+#pragma unroll
+			for (int bb = 0; bb < 8; ++bb) {
+				const uint64_t bal = __ballot((d >> bb) & 1);
+				peers &= ((d >> bb) & 1) ? bal : ~bal;
+			}
+			const int rank = lanes_before(peers);
+			if (valid && rank == 0) s_w[256 * wave + d] = __popcll(peers);
+			__syncthreads();
+			if (valid) {
+				int before = 0;
+#pragma unroll
+				for (int w = 0; w < NW - 1; ++w) before += w < wave ? s_w[256 * w + d] : 0;
+				to[s_cnt[d] + before + rank] = (uint16_t)id;
+			}
+			__syncthreads();
+			if (valid && rank == 0) { atomicAdd(&s_cnt[d], __popcll(peers)); s_w[256 * wave + d] = 0; }
+			__syncthreads();
+		}
+		{ uint16_t *t = from; from = to; to = t; }
+	}
+	__syncthreads();
+	// gather, which anchor stands where, and tiecnt[i] = number of positions j < i with x[j] == x[j + 1] (as seed_sort leaves them)
+	int run = 0;
+	for (int i0 = 0; i0 < na; i0 += NT) {
+		const int i = i0 + tid;
+		const int id = i < na ? (int)from[i] : 0, idn = i + 1 < na ? (int)from[i + 1] : 0;
+		if (i < na) { out[i] = un[id]; srt[i] = (uint32_t)id; }
+		const int flag = (i + 1 < na && s_key[id] == s_key[idn]) ? 1 : 0;
+		const int incl = wave_incl_scan(flag, lane);
+		if (lane == 63) s_carry[wave + 1] = incl;
+		__syncthreads();
+		int before = run;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) { const int c = s_carry[w + 1]; before += w < wave ? c : 0; run += c; }
+		if (i < na) tiecnt[i] = before + incl - flag;
+		__syncthreads();
+	}
+	if (tid == 0) A.has_ties[read] = run > 0 ? 1 : 0;
+}
+
 // ---- kernel 2: sort + tie detection ---------------------------------------------------------------------------------
 // The anchors are not moved pass by pass: each becomes one 8-byte key = (the bits of x that differ inside the read, squeezed
 // together) << id_bits | position in the unsorted array.  Sorting the keys on the x bits with a stable sort and gathering the anchors
@@ -303,6 +400,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
 	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
 	const int kb = b0 + b1 + bs, idb = na > 1 ? 32 - __clz(na - 1) : 1;
+	if (A.lds_sort && A.d_anchor_off[read + 1] - a0 <= SORT_LDS_CAP && kb <= 32) return;   // seed_sort_lds has sorted this read (it goes by the read's capacity: the launch order does)
 	int run = 0;
 	if (kb + idb <= 64) {
 		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;                        // the two halves of the 16-byte-per-anchor scratch
@@ -605,6 +703,7 @@ __global__ __launch_bounds__(64) void seed_heap(SeedArgs A)
 } // namespace
 
 int seed_tie_lds_max() { return TIE_CAP4; }
+int seed_sort_lds_cap() { return SORT_LDS_CAP; }
 const int64_t *seed_tie_class_lower()
 {
 	static const int64_t lower[6] = { 64, TIE_CAP0, TIE_CAP1, TIE_CAP2, TIE_CAP3, TIE_CAP4 };
@@ -624,6 +723,14 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 		hipLaunchKernelGGL(seed_offsets, dim3(1), dim3(1024), 0, st, A);
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		if (n_launches) ++*n_launches;
+	}
+	if (A.lds_sort) {                                                            // reads of up to SORT_LDS_CAP anchors: at the end of the launch order (capacity descending)
+		const unsigned first = A.d_order ? (unsigned)A.n_sort_big : 0u;
+		if (first < nr) {
+			hipLaunchKernelGGL(seed_sort_lds, dim3(nr - first), dim3(64 * SORT_LDS_WAVES), 0, st, A, (int)first);
+			if ((e = hipGetLastError()) != hipSuccess) return e;
+			if (n_launches) ++*n_launches;
+		}
 	}
 	hipLaunchKernelGGL(seed_sort, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
