@@ -62,12 +62,13 @@ struct SeedArgs {
 	uint32_t *tie_id;                            // per anchor: the arrangement of the tie replay (position -> anchor of the unsorted array)
 	uint8_t *big_dg;                             // digits of the replay for reads too long for the LDS: total + n_reads bytes (nullptr when there is none)
 	int32_t lds_sort = 1;                        // reads of up to seed_sort_lds_cap() anchors whose differing x bits fit 32 are sorted in LDS (seed_sort_lds); 0: seed_sort for every read
-	int64_t n_sort_big = 0;                      // reads whose capacity exceeds that: the first workgroups of the launch order
+	int64_t n_sort_big = 0, n_sort_huge = 0;     // reads whose capacity exceeds seed_sort_lds_cap0() / seed_sort_lds_cap(): the first workgroups of the launch order
 	int32_t debug_cut = 0;                       // development aid (MM2C_TIE_CUT): seed_ties returns early / skips parts (results are then wrong)
 	int64_t n_above[6] = {0, 0, 0, 0, 0, 0};     // reads whose capacity exceeds the lower bound of each class of seed_ties (64, then the class sizes): the grid of that class
 };
 int seed_tie_lds_max();
 int seed_sort_lds_cap();
+int seed_sort_lds_cap0();
 const int64_t *seed_tie_class_lower();          // six lower bounds (exclusive) of the size classes of seed_ties, shortest class first
 // aux: three helper streams (or nullptr: everything on st), ev: four events without timing
 hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev);

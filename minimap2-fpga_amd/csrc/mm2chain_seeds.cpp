@@ -131,8 +131,8 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	S.tie_id = (uint32_t *)(b + o_bid); S.big_dg = big ? (uint8_t *)(b + o_bdg) : nullptr;
 	{
 		const int64_t *lower = mm2c::seed_tie_class_lower();                     // a read keeps at most its capacity: these bound the grids of the classes
-		const int64_t sort_cap = mm2c::seed_sort_lds_cap();
-		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 6; ++k) S.n_above[k] += cap > lower[k]; S.n_sort_big += cap > sort_cap; }
+		const int64_t sort_cap = mm2c::seed_sort_lds_cap0(), sort_cap2 = mm2c::seed_sort_lds_cap();
+		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 6; ++k) S.n_above[k] += cap > lower[k]; S.n_sort_big += cap > sort_cap; S.n_sort_huge += cap > sort_cap2; }
 		{ const char *ls = getenv("MM2C_LDS_SORT"); if (ls) S.lds_sort = atoi(ls) != 0; }
 	}
 	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);

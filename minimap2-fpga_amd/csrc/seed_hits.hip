@@ -282,23 +282,24 @@ __device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo,
 
 // ---- kernel 2a: the same sort for reads of up to SORT_LDS_CAP anchors whose differing bits of x fit 32, entirely in LDS ------------------------
 // seed_sort moves 8-byte keys through global memory, four scattered passes for every read of a batch at once: the lines are evicted half written
-// (thousands of reads in flight, two 40 KB buffers each) and the passes run at the speed of that traffic.  Here a workgroup of SORT_LDS_WAVES waves keeps
-// the read's squeezed keys (4 bytes) and two index buffers (2 bytes each) in LDS -- 8 bytes per anchor, three reads per CU -- and only the final gather
+// (thousands of reads in flight, two 40 KB buffers each) and the passes run at the speed of that traffic.  Here a workgroup of four or eight waves keeps
+// the read's squeezed keys (4 bytes) and two index buffers (2 bytes each) in LDS -- 8 bytes per anchor -- and only the final gather
 // of the 16-byte anchors touches memory.  Stable LSD radix sort of the indices on the key's bytes: per step of 64 * NW indices every wave ranks its own 64
 // (peers by ballots) and publishes its per-digit counts; an index lands at the digit's cursor + the counts of the waves before its own + its rank.
-constexpr int SORT_LDS_CAP = 5120, SORT_LDS_WAVES = 4;
+constexpr int SORT_LDS_CAP0 = 5120, SORT_LDS_CAP = 16384;                    // two size classes: four waves and 45 KB (three reads per CU), eight waves and 138 KB (one)
 
-__global__ __launch_bounds__(64 * SORT_LDS_WAVES) void seed_sort_lds(SeedArgs A, int blk0)
+template <int CAP, int PREV, int NW>
+__global__ __launch_bounds__(64 * NW) void seed_sort_lds(SeedArgs A, int blk0)
 {
-	constexpr int NW = SORT_LDS_WAVES, NT = 64 * NW;
-	__shared__ uint32_t s_key[SORT_LDS_CAP];
-	__shared__ uint16_t s_ia[SORT_LDS_CAP], s_ib[SORT_LDS_CAP];
+	constexpr int NT = 64 * NW;
+	__shared__ uint32_t s_key[CAP];
+	__shared__ uint16_t s_ia[CAP], s_ib[CAP];
 	__shared__ int s_cnt[256], s_w[256 * NW], s_carry[NW + 1];
 	const int read = A.d_order ? A.d_order[blk0 + blockIdx.x] : blk0 + (int)blockIdx.x;
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const ReadGeom g = read_geom(A, read);
 	const int na = g.na;
-	if (A.d_anchor_off[read + 1] - g.a0 > SORT_LDS_CAP) return;                 // by capacity, as the launch order and seed_sort's test
+	{ const int64_t cap = A.d_anchor_off[read + 1] - g.a0; if (cap > CAP || cap <= PREV) return; }   // by capacity, as the launch order and seed_sort's test
 	if (A.status[read] != 0 || na == 0) { if (tid == 0) A.has_ties[read] = 0; return; }
 	const uint64_t diff = A.xdiff[read];
 	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(64) void seed_heap(SeedArgs A)
 
 int seed_tie_lds_max() { return TIE_CAP4; }
 int seed_sort_lds_cap() { return SORT_LDS_CAP; }
+int seed_sort_lds_cap0() { return SORT_LDS_CAP0; }
 const int64_t *seed_tie_class_lower()
 {
 	static const int64_t lower[6] = { 64, TIE_CAP0, TIE_CAP1, TIE_CAP2, TIE_CAP3, TIE_CAP4 };
@@ -724,10 +726,16 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		if (n_launches) ++*n_launches;
 	}
-	if (A.lds_sort) {                                                            // reads of up to SORT_LDS_CAP anchors: at the end of the launch order (capacity descending)
-		const unsigned first = A.d_order ? (unsigned)A.n_sort_big : 0u;
-		if (first < nr) {
-			hipLaunchKernelGGL(seed_sort_lds, dim3(nr - first), dim3(64 * SORT_LDS_WAVES), 0, st, A, (int)first);
+	if (A.lds_sort) {                                                            // the launch order is by capacity, descending: each class is a range of it
+		const unsigned huge = A.d_order ? (unsigned)A.n_sort_huge : 0u, big = A.d_order ? (unsigned)A.n_sort_big : 0u;
+		if (big < nr) {
+			hipLaunchKernelGGL((seed_sort_lds<SORT_LDS_CAP0, 0, 4>), dim3(nr - big), dim3(256), 0, st, A, (int)big);
+			if ((e = hipGetLastError()) != hipSuccess) return e;
+			if (n_launches) ++*n_launches;
+		}
+		const unsigned end1 = A.d_order ? big : nr;
+		if (huge < end1) {
+			hipLaunchKernelGGL((seed_sort_lds<SORT_LDS_CAP, SORT_LDS_CAP0, 8>), dim3(end1 - huge), dim3(512), 0, st, A, (int)huge);
 			if ((e = hipGetLastError()) != hipSuccess) return e;
 			if (n_launches) ++*n_launches;
 		}
