@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void seed_sort_lds(SeedArgs A, int blk0)
 	constexpr int NT = 64 * NW;
 	__shared__ uint32_t s_key[CAP];
 	__shared__ uint16_t s_ia[CAP], s_ib[CAP];
-	__shared__ int s_cnt[256], s_w[256 * NW], s_carry[NW + 1];
+	__shared__ int s_cnt[256], s_w[256 * NW], s_carry[NW + 1], s_hist[4 * 256];
 	const int read = A.d_order ? A.d_order[blk0 + blockIdx.x] : blk0 + (int)blockIdx.x;
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const ReadGeom g = read_geom(A, read);
@@ -311,22 +311,23 @@ __global__ __launch_bounds__(64 * NW) void seed_sort_lds(SeedArgs A, int blk0)
 	int32_t *tiecnt = A.tiecnt + g.a0;
 	uint32_t *srt = A.tie_id + g.a0;
 	const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+	for (int d = tid; d < 4 * 256; d += NT) s_hist[d] = 0;
+	__syncthreads();
 	for (int i = tid; i < na; i += NT) {
 		const uint64_t x = un[i].x;
-		s_key[i] = (uint32_t)((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0));   // order preserving: the dropped bits are constant
+		const uint32_t sq = (uint32_t)((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0));   // order preserving: the dropped bits are constant
+		s_key[i] = sq;
 		s_ia[i] = (uint16_t)i;
+		for (int pass = 0; 8 * pass < kb; ++pass) atomicAdd(&s_hist[256 * pass + ((sq >> (8 * pass)) & 255)], 1);  // the histograms of all passes, counted while the keys are made
 	}
 	uint16_t *from = s_ia, *to = s_ib;
 	for (int shift = 0; shift < kb; shift += 8) {
-		for (int d = tid; d < 256; d += NT) s_cnt[d] = 0;
 		for (int d = tid; d < 256 * NW; d += NT) s_w[d] = 0;
-		__syncthreads();                                                       // (also: the keys and indices of the pass before are in place)
-		for (int i = tid; i < na; i += NT) atomicAdd(&s_cnt[(s_key[i] >> shift) & 255], 1);   // the histogram does not depend on the order
-		__syncthreads();
+		__syncthreads();                                                       // (also: the keys, histograms and the indices of the pass before are in place)
 		if (wave == 0) {
 			int h[4], sum = 0;
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { h[u] = s_cnt[4 * lane + u]; sum += h[u]; }
+			for (int u = 0; u < 4; ++u) { h[u] = s_hist[32 * shift + 4 * lane + u]; sum += h[u]; }
 			int at = wave_incl_scan(sum, lane) - sum;
 #pragma unroll
 			for (int u = 0; u < 4; ++u) { s_cnt[4 * lane + u] = at; at += h[u]; }
@@ -498,15 +499,15 @@ __device__ uint64_t *block_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo
 // ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
 // The sequential part of the replay (the walk of replay_walk) reads digits only, so a read needs ONE byte of LDS per anchor (the index
 // array, the permutation of a pass and the lists of the closed form live in global memory and are touched by all lanes); size classes keep
-// the occupancy of the common (short) reads high: up to 6 144 anchors one wave replays a read, longer reads -- whose replay a batch waits
+// the occupancy of the common (short) reads high: up to 5 120 anchors one wave replays a read, longer reads -- whose replay a batch waits
 // for -- run the independent buckets of each level, the sweeps and the final order on two (up to 12 288 anchors) or eight waves of a
 // workgroup, with up to 128 K digits in LDS (gfx950: 160 KB per workgroup).  CAP = 0: reads beyond that, digits in global memory.
-constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 6144, TIE_CAP2 = 12288, TIE_CAP3 = 65536, TIE_CAP4 = 131072;
+constexpr int TIE_CAP0 = 2560, TIE_CAP1 = 5120, TIE_CAP2 = 12288, TIE_CAP3 = 65536, TIE_CAP4 = 131072;
 constexpr int TIE_MW_WAVES = 8;
 #ifndef MM2C_TIE_SW
 #define MM2C_TIE_SW 2
 #endif
-constexpr int TIE_SW = MM2C_TIE_SW;            // waves per read of the 6 145 .. 12 288 class (its reads are few and long enough to set the time of a chunk; the classes below it are many reads: one wave each)
+constexpr int TIE_SW = MM2C_TIE_SW;            // waves per read of the 5 121 .. 12 288 class (its reads are few and long enough to set the time of a chunk; the classes below it are many reads: one wave each)
 
 template <int CAP, int PREV, int NW>
 __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TIE_CAP0 ? 4 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
