@@ -286,7 +286,7 @@ __device__ uint64_t *wave_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo,
 // the read's squeezed keys (4 bytes) and two index buffers (2 bytes each) in LDS -- 8 bytes per anchor -- and only the final gather
 // of the 16-byte anchors touches memory.  Stable LSD radix sort of the indices on the key's bytes: per step of 64 * NW indices every wave ranks its own 64
 // (peers by ballots) and publishes its per-digit counts; an index lands at the digit's cursor + the counts of the waves before its own + its rank.
-constexpr int SORT_LDS_CAP0 = 5120, SORT_LDS_CAP = 16384;                    // two size classes: four waves and 45 KB (three reads per CU), eight waves and 138 KB (one)
+constexpr int SORT_LDS_CAP0 = 5120, SORT_LDS_CAP = 16384;                    // two size classes: four waves and 49 KB (three reads per CU), eight waves and 141 KB (one)
 
 template <int CAP, int PREV, int NW>
 __global__ __launch_bounds__(64 * NW) void seed_sort_lds(SeedArgs A, int blk0)
