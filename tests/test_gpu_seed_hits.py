@@ -130,6 +130,22 @@ def test_reads_of_the_multi_wave_replay_classes(seed, lo, hi, n_matches):
     assert _check(reads, f"mw {seed} {lo}") > 100
 
 
+def test_lds_sort_and_global_sort_leave_the_same_anchor_lists(monkeypatch):
+    """reads of up to 16 384 anchors whose differing x bits fit 32 are sorted in LDS (seed_sort_lds), the others through global memory (seed_sort); MM2C_LDS_SORT=0 sends every
+    read through seed_sort.  Both routes against the oracle on the same reads: short and middle-sized ones, with and without equal x, one target and many (more than 32 differing bits)."""
+    import mm2chain
+    rng = np.random.default_rng(4242)
+    reads = [_random_read(rng, 900, 6, 1, 1 << 22), _random_read(rng, 1200, 8, 2, 3000, dup_frac=0.2), _random_read(rng, 2600, 8, 3, 1 << 20, qlen=40000, dup_frac=0.1),
+             _random_read(rng, 700, 5, 300, 1 << 30), _random_read(rng, 40, 3, 1, 500), _random_read(rng, 1500, 7, 1, 40000, dup_frac=0.3)]
+    sizes = [int(r[1]["n"].sum()) for r in reads]
+    assert max(sizes) > 5120 and min(sizes) < 200, sizes
+    ties = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MM2C_LDS_SORT", flag)                                 # read when a seed plan is made
+        ties[flag] = _check(reads, f"MM2C_LDS_SORT={flag}")
+    assert ties["1"] == ties["0"] > 100
+
+
 def test_anchor_offsets_that_do_not_match_the_hit_counts_are_reported():
     import mm2chain
     rng = np.random.default_rng(3)
