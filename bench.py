@@ -77,13 +77,15 @@ def measured_traffic(profile, total_anchors, preset="map-ont"):
         return None
 
 
-def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0):
+def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0, device_list=None):
     """BASELINE.json's second metric, end-to-end map-ont wall-clock (the reference's pipeline: main.c:406-410 -> mm_map_file, map.c:526-620), on a
     config-3 stand-in (hg38 is not available offline): tools/make_synth_genome.py writes a synthetic genome with planted repeats and simulated ONT
     reads, and three hosts built over the reference's own non-path objects (oracle/ref_host/Makefile -> oracle/_ref/) map them with the same -t / -K:
     mm2_refhost chains on the CPU threads (the stated baseline), mm2_batchhost is INTEGRATION.md path C (matches in, chains out, one library call per
     mini-batch), mm2_gpuhost is path B (one synchronous library call per read through mm_chain_dp).  Wall seconds around each process, the PAF
-    of all three must be byte-identical.  Bounded: each run under `timeout`, the whole leg skipped once `budget_s` is used up.  N = 1, outside the timed region."""
+    of all three must be byte-identical.  Bounded: each run under `timeout`, the whole leg skipped once `budget_s` is used up.  Outside the timed region, on rank 0.
+    device_list (N > 1: "0,1,...", the ranks' devices, after the ranks have ended): the two GPU hosts run as ONE process each over all of them (MM2C_DEVICES, the
+    in-process form of DESIGN 5: mini-batches split across the devices in path C, every device its own call combiner in path B)."""
     import hashlib
     import re
     import subprocess
@@ -101,13 +103,16 @@ def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0):
                               stdout=subprocess.DEVNULL)
         out = {"workload": f"map-ont, synthetic {genome_mb} Mb genome with planted repeats (4 sequences), {reads} simulated ONT reads (10 kb, 10 % error), "
                            f"-t {threads}, mini-batches of {mini_batch} bases (-K)", "stand_in_for": "BASELINE config 3 (hg38 + 100k ONT reads: not available offline)",
-               "threads": threads, "reads": reads, "genome_mb": genome_mb, "generate_s": round(time.perf_counter() - t0, 2), "hosts": {}}
+               "threads": threads, "reads": reads, "genome_mb": genome_mb, "generate_s": round(time.perf_counter() - t0, 2),
+               "devices_of_the_gpu_hosts": device_list or "0", "hosts": {}}
         md5s = {}
         for name, exe in exes.items():
             if time.perf_counter() - t_all > budget_s:
                 out["hosts"][name] = {"skipped": f"the leg's budget of {budget_s:.0f} s was used up"}
                 continue
             env = dict(os.environ, MM2_MINI_BATCH=str(mini_batch), MM2C_QUIET="1")
+            if device_list and name != "cpu_chaining":
+                env["MM2C_DEVICES"] = device_list
             paf = os.path.join(w, name + ".paf")
             t0 = time.perf_counter()
             with open(paf, "wb") as fo:
@@ -129,6 +134,9 @@ def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0):
             m = re.search(r"GPU chaining: (.*)", err)
             if m:
                 rec["per_read_calls"] = m.group(1).strip()
+            m = re.search(r"per device slot: (.*)", err)
+            if m:
+                rec["per_device_slot"] = m.group(1).strip()
             if r.returncode != 0:
                 rec["stderr_tail"] = err[-400:]
             out["hosts"][name] = rec
@@ -569,20 +577,27 @@ def main():
                                          f"{cores} threads, tasks round-robin, {s_all:.1f} s wall",
                                "value_1thread": int(off_np[n1]) / s_one}
     # ---- end to end (BASELINE.json's second metric): after everything else, the GPU memory of this process given back first
-    if world == 1 and not args.strong and not args.no_e2e and not args.no_secondary and args.preset == "map-ont":
+    # N > 1: the other ranks have ended by now (they return right after the verification all-reduce) and this rank leaves the process group first; the two
+    # GPU hosts then run as one process each over the ranks' devices (MM2C_DEVICES)
+    if world > 1:
+        dist.destroy_process_group()
+    if not args.strong and not args.no_e2e and (world > 1 or not args.no_secondary) and args.preset == "map-ont":
         try:
             del d_f, d_p, anchors
             plan.close(); plan = None
             mm2chain.tune("trim", 0)
             torch.cuda.empty_cache()
-            out["e2e_map_ont"] = e2e_map_ont(host_cores(), args.e2e_reads, args.e2e_genome_mb, args.e2e_mini_batch)
+            dev_list = None
+            if world > 1:
+                mm2chain.shutdown()
+                dev_list = ",".join("0" if os.environ.get("MM2C_BENCH_ONE_DEVICE") == "1" else str(d["ordinal"]) for d in devices)
+                time.sleep(1.0)                                     # the other ranks' processes are on their way out
+            out["e2e_map_ont"] = e2e_map_ont(host_cores(), args.e2e_reads, args.e2e_genome_mb, args.e2e_mini_batch, device_list=dev_list)
         except Exception as e:
             out["e2e_map_ont"] = {"error": repr(e)}
     print(json.dumps(out))
     if plan is not None:
         plan.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

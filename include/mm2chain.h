@@ -89,8 +89,8 @@ int  mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *
  * empty-window positions (default 256, 0 = never cut); "plan_cut" 0/1 = plans cut their tasks of at least "plan_cut_min" anchors (default
  * 8192) into such pieces on the device before the DP (default 1); "pipeline_chunk_anchors" = chunk size of the two-stream pipeline used for
  * host batches of at least twice that size (default 20 Mi anchors); "multi_min_anchors" = smallest host batch that is split across the
- * devices of mm2c_init_devices (default 2^20); "trim" = give the cached device memory back to the runtime.  Results never depend on a knob.  "coop_waves" 8 = a host-buffer pass of at most "coop_max_tasks" (1024) pieces gives every piece a workgroup of
- * several waves that share its LDS rings (csrc/chain_dp_coop.h: candidates counted and the older tiles reduced in parallel, the exact scan only where the early exit of chain.c:231 can fire;
+ * devices of mm2c_init_devices (default 2^20); "trim" = give the cached device memory back to the runtime.  Results never depend on a knob.  "coop_waves" > 1 (default 16, the only width built: any value above 1 means 16) = a host-buffer pass of at most "coop_max_tasks" (1024) pieces gives every piece a workgroup of
+ * 16 waves that share its LDS rings (csrc/chain_dp_coop.h: candidates counted and the older tiles reduced in parallel, the exact scan only where the early exit of chain.c:231 can fire;
  * env MM2C_COOP_WAVES), 0 = one wave per piece always; "coop_plans" 1 = plans of few tasks take that kernel too (tests); "combiner_lanes" 1..4 = passes the call combiner of the per-read
  * entries may have in flight at once (default 3; env MM2C_COMBINER_LANES), "combine_max_anchors" = a call of more anchors than this runs alone (env MM2C_COMBINE_MAX). */
 int  mm2c_tune(const char *key, int value);
@@ -184,6 +184,27 @@ void  mm2c_pinned_free(void *ptr);
  */
 int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
                          int32_t *f, int32_t *p, int tid);
+
+/*
+ * The same call with the reference's busy protocol (chain_hardware.cpp:54-75, PROCESS_ON_SW_IF_HW_BUSY, chain_hardware.h:50): the caller hands in the two
+ * predictions chain.c:80-81 computes (milliseconds) and the call is ACCEPTED by the first device slot, scanning from tid % n, on which
+ *     (predicted device time of the calls already inside the slot) / (passes the slot runs at once) + hw_time_pred < sw_time_pred;
+ * when no slot will do it returns 1 = "declined": nothing was computed, f / p are untouched, and the caller runs its own loop (chain.c:106,112-164).
+ * Only a host that HAS such a loop may call it: the reference's chain.o through run_chaining_on_hw (INTEGRATION.md path A).  This library's own mm_chain_dp
+ * (path B) never does -- it has no software DP.  Predictions that are not both positive never decline.  "decline_when_busy" 0 (mm2c_tune) = always accept.
+ */
+int mm2c_chain_task_host_pred(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
+                              int32_t *f, int32_t *p, int tid, float hw_time_pred, float sw_time_pred);
+
+/* Per device slot (the order of mm2c_init_devices / MM2C_DEVICES; slot 0 = the primary device): what its call combiner has served since mm2c_init --
+ * the reference keeps a queue, a lock and a buffer set per kernel (chain_hardware.cpp:9-23); here every device has its own, and a per-read call goes to
+ * the slot with the least anchors outstanding.  declined: calls mm2c_chain_task_host_pred turned away (counted on slot 0). */
+typedef struct { int32_t device; int32_t reserved; uint64_t passes, calls, anchors, declined; } mm2c_slot_stats_t;
+int mm2c_get_slot_stats(int slot, mm2c_slot_stats_t *out);
+/* the routing rule on its own (pure; no device is touched): given the anchors outstanding on each of n_slots device slots, the slot a call from worker `tid` goes to
+ * -- the least loaded one, ties to the first such slot at or after tid % n_slots (so idle devices are taken in turn, chain_hardware.cpp:58-72 scans its kernels
+ * from 0 instead).  A negative tid counts as 0. */
+int mm2c_route_slot(int n_slots, const int64_t *outstanding, int tid);
 
 /* ---- host mirror of the reference function around the path ------------------------------------------------------ */
 /*

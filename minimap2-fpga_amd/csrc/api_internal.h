@@ -52,8 +52,11 @@ struct Global {
 	std::atomic<int64_t> pipeline_pieces{8}, pipeline_min_chunk{4 << 20};   // host paths: a batch of a few chunks' worth is cut into about `pieces` chunks of at least `min_chunk` anchors
 	std::atomic<int64_t> cut_below_tasks{4096};         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
-	std::atomic<int> coop_waves{8};                     // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never)
+	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: 16 waves per task (chain_dp_coop; 0 or 1: never; the width is fixed, the value only switches)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> decline_when_busy{1};              // mm2c_chain_task_host_pred / run_chaining_on_hw: the reference's busy protocol (chain_hardware.cpp:54-75); 0: always accept
+	std::atomic<int> direct_pass{1};                    // small staged passes: the two copies are kernels and the host polls a flag word (host_stage.hip; 0: copy commands + stream wait)
+	std::atomic<size_t> direct_max_anchors{1u << 18};   // ... passes of up to this many anchors
 	std::atomic<int> combiner_lanes{3};                 // passes of the call combiner in flight at once (1 .. 4)
 	std::atomic<int> coop_plans{0};                     // plans take the cooperative kernel too when they have few tasks (tests; default: the host-buffer entries only)
 	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
@@ -117,6 +120,7 @@ struct SeedSlot {
 // ([anchors | piece offsets | launch order | p base | avg | status]) and one for everything that is downloaded ([f | p]), each
 // mirrored by a pinned host staging buffer, so that a call is one H2D copy, the kernels, one D2H copy and one sync.
 struct ThreadCtx {
+	int device = -1;                           // >= 0: the context belongs to this device whoever runs on it (a lane of a device slot's call combiner)
 	WholeSlot whole[2];
 	SeedSlot seed[2];
 	hipStream_t st = nullptr, st2 = nullptr;   // st2: second compute stream of the pipelined big-batch path
@@ -126,11 +130,13 @@ struct ThreadCtx {
 	mm2c::LaunchInfo last_info = {};           // which instantiation the context's last DP launch chose (copied to the process-wide record, mm2c_last_host_variant)
 	char *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;   // device
 	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
+	unsigned *h_flag = nullptr;                                      // pinned host: the word stage_out raises when a direct pass is done (host_stage.hip)
+	unsigned seq = 0;                                                // number of the context's last direct pass (the value the flag takes)
 	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
 	void release()
 	{
 		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
-		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out);
+		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); if (h_flag) (void)hipHostFree(h_flag);
 		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
 		if (st3) (void)hipStreamDestroy(st3); if (st_up) (void)hipStreamDestroy(st_up);
 		for (hipEvent_t e : evs) (void)hipEventDestroy(e);
@@ -165,7 +171,7 @@ bool should_split(int64_t total_anchors);
 int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int(int, int64_t, int64_t)> &fn);
 hipError_t create_partner_stream(hipStream_t *st);
 int grow_device(char **p, size_t *cap, size_t need);
-int grow_pinned(char **p, size_t *cap, size_t need);
+int grow_pinned(char **p, size_t *cap, size_t need, bool gpu_addressed = false);
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 int check_params(const mm2c_params_t *p);
 mm2c::KParams to_kparams(const mm2c_params_t *p);
@@ -201,6 +207,9 @@ inline int resolve_stream(void *stream, int device, hipStream_t *out)
 }
 void dev_cache_release();
 void release_combiner();                            // mm2chain_host.cpp
+int get_slot_stats(int slot, uint64_t *passes, uint64_t *calls, uint64_t *anchors);   // per-device combiner counters (mm2chain_host.cpp)
+int book_pred(int tid, float hw_ms, float sw_ms);   // path A's decline: the slot that books the call, or -1 (mm2chain_host.cpp)
+void release_pred(int slot, float hw_ms);
 void release_seed_aux();                            // mm2chain_seeds.cpp
 // a pooled set of helper streams (distinct priorities = hardware queues of their own) and fork / join events, kept between plans (mm2chain_seeds.cpp)
 struct AuxSet { hipStream_t aux[3] = {}; hipEvent_t fork[4] = {}; int device = -1; uint64_t epoch = 0; };   // epoch: G.epoch when the set was made (a set of an earlier one is destroyed, not pooled)

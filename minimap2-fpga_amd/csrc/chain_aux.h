@@ -73,5 +73,10 @@ const int64_t *seed_tie_class_lower();          // six lower bounds (exclusive) 
 // aux: three helper streams (or nullptr: everything on st), ev: four events without timing
 hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, hipStream_t *aux, hipEvent_t *ev);
 
+// ---- the copies of a small per-read pass as kernels (host_stage.hip): page-locked host staging buffer -> device arena, device results -> page-locked host buffer
+// + a flag word the host polls.  bytes are rounded up to 16: both buffers must have that room.  d_done: one unsigned of device scratch.
+hipError_t launch_stage_in(const void *h_src, void *d_dst, size_t bytes, unsigned *d_done, hipStream_t st);
+hipError_t launch_stage_out(const void *d_src, void *h_dst, size_t bytes, unsigned *d_done, unsigned *h_flag, unsigned seq, hipStream_t st);
+
 } // namespace mm2c
 #endif

@@ -69,6 +69,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if (only_flagged && status[task] == 0) return;
 	const int64_t base0 = offsets[task];
 	const int n = __builtin_amdgcn_readfirstlane((int)(offsets[task + 1] - base0));
+	// the one-word keys of the straight-line pushes (score << 7 | origin) need |score| < 2^23: at most 255 gained per link and a gap cost that cannot overflow
+	// the word either (<= gap_scale * (2.55 * bw + 17) before the shift)
+	const bool key32_ok = n < (1 << 15) && P.span_override <= 255 && P.gap_scale >= 0.f && P.gap_scale <= 4.f && P.bw <= (1 << 17);
 	if (n <= 0) return;
 	const uint4 *a = a_all + base0;
 	const int32_t *st = st_all + base0;
@@ -333,8 +336,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			bool all_done = false;
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
 			if (cnt == 64 && tents == ~0ull) {
-				if (n < (1 << 15)) {
-					// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size (a chain gains at most span <= 255 per anchor), so score and origin fit ONE word:
+				if (key32_ok) {
+					// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size when a chain gains at most 255 per anchor (the 8-bit span of chain.c:189; key32_ok
+					// rules out a larger q_span_override and a negative gap_scale, under which a link can ADD its gap cost), so score and origin fit ONE word:
 					// score << 7 | code, code 0 = the older tiles' best, 1 + k = candidate k of this tile, 127 = the span itself (p = -1).  A signed maximum then is the whole
 					// rule: the higher score, among equal scores the nearer origin, and never an equal score over the span.  A push is: read a lane, mask, add, maximum.
 					int a32 = (int)(acc >> 32) * 128 + ((int)(unsigned)acc == -1 ? 127 : 0);

@@ -266,14 +266,16 @@ int grow_device(char **p, size_t *cap, size_t need)
 	return 0;
 }
 
-int grow_pinned(char **p, size_t *cap, size_t need)
+int grow_pinned(char **p, size_t *cap, size_t need, bool gpu_addressed)
 {
 	if (need <= *cap) return 0;
 	const size_t want = std::max(need, *cap * 2);
 	if (*p) { ScopedNs timed(SS.free_ns); ++SS.n_free; (void)hipHostFree(*p); }
 	*p = nullptr; *cap = 0;
 	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
-	HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
+	// gpu_addressed: kernels read / write the buffer themselves (host_stage.hip) and the host reads results behind a flag word, not behind a stream wait: mapped
+	// into the device's address space and coherent (fine-grained) by request rather than by the runtime's default
+	HIP_TRY(hipHostMalloc((void **)p, want, gpu_addressed ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
 	*cap = want;
 	return 0;
 }
@@ -433,6 +435,8 @@ int mm2c_init(int device_ordinal)
 	if (cm) G.combine_max_anchors = (size_t)std::max(0, atoi(cm));
 	const char *cl = getenv("MM2C_COMBINER_LANES");      // experiments: passes of the call combiner in flight
 	if (cl) G.combiner_lanes = std::max(1, std::min(4, atoi(cl)));
+	const char *dp = getenv("MM2C_DIRECT_PASS");         // 0: small per-read passes use copy commands and a stream wait instead of the staging kernels and the polled flag (experiments)
+	if (dp) G.direct_pass = atoi(dp) != 0;
 	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
 	if (cw) G.coop_waves = std::max(0, atoi(cw));
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
@@ -613,7 +617,7 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	if (strcmp(key, "coop_waves") == 0) {
-		if (value < 0 || value > 64) return fail(MM2C_E_ARG, "coop_waves must be 0 .. 64 (0 / 1: one wave per task always; otherwise the cooperative kernel's 8 waves)");
+		if (value < 0 || value > 64) return fail(MM2C_E_ARG, "coop_waves must be 0 .. 64 (0 / 1: one wave per task always; any other value: the cooperative kernel, which is built for 16 waves per task)");
 		G.coop_waves = value;
 		return 0;
 	}
@@ -625,6 +629,14 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "combiner_lanes") == 0) {
 		if (value < 1 || value > 4) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 4");
 		G.combiner_lanes = value;
+		return 0;
+	}
+	if (strcmp(key, "decline_when_busy") == 0) {
+		G.decline_when_busy = value != 0;
+		return 0;
+	}
+	if (strcmp(key, "direct_pass") == 0) {
+		G.direct_pass = value != 0;
 		return 0;
 	}
 	if (strcmp(key, "coop_plans") == 0) {

@@ -9,6 +9,7 @@
 // gap_scale / n_segs, see mm2c_chain_task_host for the extended entry used by our own mm_chain_dp.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include "mm2chain.h"
 
 typedef struct { uint64_t x, y; } mm128_t;   // minimap.h:53
@@ -18,11 +19,13 @@ int run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_spa
                        float hw_time_pred, float sw_time_pred)
 {
 	(void)num_subparts; (void)total_subparts;   // FPGA pipeline bookkeeping (chain.c:62-78), not needed on a GPU
-	(void)hw_time_pred; (void)sw_time_pred;     // the busy/queue model of chain_hardware.cpp:54-93 is gone: never declines
 	if (n == 0) return 0;                       // chain_hardware.cpp:30-32
 	mm2c_params_t par;
 	mm2c_params_fpga_v2(&par, max_dist_x, max_dist_y, bw, q_span);
-	int rc = mm2c_chain_task_host(&par, n, (const mm2c_anchor_t *)a, avg_qspan, f, p, tid);
+	// the busy protocol of chain_hardware.cpp:54-75 (PROCESS_ON_SW_IF_HW_BUSY): 1 = declined, the caller's own loop runs (chain.c:106,112-164).  The caller of THIS
+	// symbol is the reference's chain.o, which has that loop; predictions that are not positive (a caller without the model) never decline.
+	int rc = mm2c_chain_task_host_pred(&par, n, (const mm2c_anchor_t *)a, avg_qspan, f, p, tid, hw_time_pred, sw_time_pred);
+	if (rc == 1) return 1;                      // chain_hardware.cpp:75
 	if (rc != 0) {                              // chain_hardware.cpp:34-37, 208-235: message + exit
 		fprintf(stderr, "Error: GPU chaining failed (n = %ld): %s\n", n, mm2c_last_error());
 		exit(EXIT_FAILURE);
@@ -41,3 +44,15 @@ bool hardware_init(long buf_size, char *binary_name)
 }
 
 void cleanup() { mm2c_shutdown(); }             // main.c:430
+
+// chain_hardware.h:72 (defined chain_hardware.cpp:208-235): a status other than success prints the message and ends the process.  No reference object imports it
+// (only chain_hardware.cpp itself calls it); exported so that the header's four prototypes all resolve against this library.  The status is an OpenCL code in the
+// reference; here any non-zero value is a failure and the library's own last error is printed beside the caller's text.
+void checkError(int err, const std::string message)
+{
+	if (err == 0) return;                       // CL_SUCCESS
+	fprintf(stderr, "%s\n", message.c_str());
+	const char *last = mm2c_last_error();
+	if (last && *last) fprintf(stderr, "%s\n", last);
+	exit(EXIT_FAILURE);
+}

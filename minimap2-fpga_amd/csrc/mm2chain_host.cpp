@@ -19,6 +19,8 @@ struct HostReq {
 // where the wall time of the small staged passes goes (MM2C_PASS_TIMING=1: printed when the combiner is released, mm2c_shutdown): assembling the pass on the host,
 // the runtime calls that put it on the stream, the wait for it, handing the results back
 static std::atomic<uint64_t> g_pt_build{0}, g_pt_submit{0}, g_pt_wait{0}, g_pt_out{0}, g_pt_n{0};
+static std::atomic<uint64_t> g_pt_cls_ns[8], g_pt_cls_calls[8], g_pt_cls_reqs{0};   // ... and the callers' wall time by size of the call (< 256, < 512, ... anchors)
+static const bool g_pt_on = getenv("MM2C_PASS_TIMING") != nullptr;
 static inline uint64_t pt_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Runs one GPU pass over the union of the requests (all with the same scalars).
@@ -29,7 +31,6 @@ static inline uint64_t pt_now() { return (uint64_t)std::chrono::duration_cast<st
 //  * avg_qspan_scaled is a whole-task quantity (chain.c:48-49): computed here per task unless handed in.
 //  * one upload arena [anchors | piece offsets | launch order | p base | avg | status(0)] and one download arena [f | p],
 //    mirrored in pinned memory for small passes: one H2D copy, the kernels, one D2H copy, one sync.
-static bool is_combiner_ctx(const ThreadCtx *c);
 int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 {
 	int rc;
@@ -86,7 +87,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	seg_off.push_back(total);
 	if ((rc = build_order(n_seg, seg_off.data(), order))) return rc;
 
-	HIP_TRY(hipSetDevice(is_combiner_ctx(c) ? G.device : cur_device()));   // the context's stream and arenas belong to that device
+	HIP_TRY(hipSetDevice(c->device >= 0 ? c->device : cur_device()));   // the context's stream and arenas belong to that device (a combiner context: its slot's)
 	// chunk size of the two-stream pipeline: "pipeline_chunk_anchors" (a chunk that fills the GPU on its own) for batches many times that size;
 	// a batch of a few chunks' worth is cut into about eight pieces of at least 4 Mi anchors instead, whose kernels overlap on the two streams --
 	// the upload of a piece then hides behind the kernels of the one before (one pass over 2 * 10^7 anchors: 1.44 G anchors/s, PCIe and kernels in series)
@@ -102,9 +103,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	const size_t meta_bytes = in_bytes - o_off;
 	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
-	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8))) return rc;
-	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8))) return rc;
-	if ((rc = grow_pinned(&c->h_in, &c->cap_hin, staged ? in_bytes : meta_bytes))) return rc;
+	if ((rc = grow_device(&c->d_out, &c->cap_out, (size_t)total * 8 + 16))) return rc;   // (+ 16: stage_out moves whole 16-byte pieces)
+	if ((rc = grow_device(&c->d_scratch, &c->cap_scratch, (size_t)total * 8 + 64))) return rc;   // [t | st | counter of the direct pass]
+	if ((rc = grow_pinned(&c->h_in, &c->cap_hin, staged ? in_bytes : meta_bytes, true))) return rc;
 	char *hm = staged ? c->h_in + o_off : c->h_in;                 // where the metadata block starts in the staging buffer
 	memcpy(hm, seg_off.data(), ((size_t)n_seg + 1) * 8);
 	memcpy(hm + (o_ord - o_off), order.data(), (size_t)n_seg * 4);
@@ -112,6 +113,13 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	memcpy(hm + (o_avg - o_off), seg_avg.data(), (size_t)n_seg * 4);
 	memset(hm + (o_stat - o_off), 0, in_bytes - o_stat);           // status, classes, class counters
 	uint64_t pt1 = 0;
+	// a small staged pass: the copies are kernels on the pass's own stream and the host polls a flag word (host_stage.hip)
+	const bool direct = staged && G.direct_pass.load() != 0 && (size_t)total <= G.direct_max_anchors;
+	unsigned *d_done = (unsigned *)(c->d_scratch + align16((size_t)total * 8));
+	if (direct && !c->h_flag) {
+		HIP_TRY(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocCoherent));
+		*c->h_flag = 0; c->seq = 0;
+	}
 	if (staged) {
 		size_t at = o_a;
 		for (int r = 0; r < n_req; ++r) {
@@ -120,7 +128,8 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			at += nb;
 		}
 		pt1 = pt_now();
-		HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));                  // cf. chain_hardware.cpp:110,114
+		if (direct) HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
+		else HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));            // cf. chain_hardware.cpp:110,114
 	} else if (n_req == 1 && total >= 2 * pipe_chunk) {
 		// big batch: a three-stage pipeline over chunks of whole pieces.  One stream uploads the chunks back to back (PCIe never idles), the
 		// kernels of chunk k start when its upload has landed -- on one of three compute streams in turn, so that the kernels of consecutive
@@ -212,10 +221,30 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
 	note_host_variant(c->last_info);
 	if (staged) {
-		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8))) return rc;
-		HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
-		const uint64_t pt2 = pt_now();
-		HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
+		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8 + 16, true))) return rc;
+		uint64_t pt2;
+		if (direct) {
+			if (++c->seq == 0) c->seq = 1;
+			HIP_TRY(mm2c::launch_stage_out(c->d_out, c->h_out, (size_t)total * 8, d_done, c->h_flag, c->seq, c->st));
+			pt2 = pt_now();
+			// the flag is the last thing the pass writes (after a system-scope fence behind every store of f / p).  The calling thread has nothing else to do (the call is
+			// synchronous, chain_hardware.cpp:175 clFinish), so it polls; a pass that does not report within 50 ms is waited for through the runtime, which also surfaces
+			// an error of the stream
+			bool seen = false;
+			for (uint64_t spins = 0; ; ++spins) {
+				if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == c->seq) { seen = true; break; }
+				__builtin_ia32_pause();
+				if ((spins & 1023) == 1023 && pt_now() - pt2 > 50000000ull) break;
+			}
+			if (!seen) {
+				HIP_TRY(hipStreamSynchronize(c->st));
+				if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != c->seq) return fail(MM2C_E_HIP, "a direct pass ended without raising its flag (pass %u)", c->seq);
+			} else if ((c->seq & 31) == 0) (void)hipStreamQuery(c->st);   // lets the runtime retire the finished commands of a stream nobody ever waits on
+		} else {
+			HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, (size_t)total * 8, hipMemcpyDeviceToHost, c->st));           // cf. chain_hardware.cpp:167,170
+			pt2 = pt_now();
+			HIP_TRY(hipStreamSynchronize(c->st));                                                               // cf. chain_hardware.cpp:175
+		}
 		const uint64_t pt3 = pt_now();
 		size_t at = 0;
 		for (int r = 0; r < n_req; ++r) {
@@ -224,7 +253,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			memcpy(reqs[r]->p + reqs[r]->off[0], c->h_out + (size_t)total * 4 + at * 4, n * 4);
 			at += n;
 		}
-		g_pt_build += pt1 - pt0; g_pt_submit += pt2 - pt1; g_pt_wait += pt3 - pt2; g_pt_out += pt_now() - pt3; ++g_pt_n;
+		g_pt_build += pt1 - pt0; g_pt_submit += pt2 - pt1; g_pt_wait += pt3 - pt2; g_pt_out += pt_now() - pt3; ++g_pt_n; g_pt_cls_reqs += (uint64_t)n_req;
 	} else {
 		size_t at = 0;
 		for (int r = 0; r < n_req; ++r) {
@@ -257,7 +286,11 @@ void note_host_variant(const mm2c::LaunchInfo &I)
 // chain_hardware.cpp:54-93.)  Big requests skip the combiner and run on the caller's own stream.
 // Up to N_LANES passes in flight, each on a context (stream + arenas) of its own: with the cooperative kernel a pass is short on the GPU (tens of microseconds), and the
 // host side of the next one -- collecting the requests, staging their anchors, the runtime calls -- can run beside it ("combiner_lanes", default 3: measured 5.53-5.67 / 5.40 / 5.26 / 5.53 s for 1 / 2 / 3 / 4 on the 120 000-read run).
+// ONE COMBINER PER DEVICE SLOT (round 5): the reference keeps a queue, a lock, a buffer set and an expected end time per kernel and picks one per call
+// (chain_hardware.cpp:9-23,54-72); here every device of mm2c_init_devices / MM2C_DEVICES has its own combiner -- lanes, streams, arenas on that device -- and a
+// per-read call goes to the slot with the least work outstanding (anchors of the calls inside it), the scan starting at tid % n so that idle devices are taken in turn.
 constexpr int N_LANES = 4;
+constexpr int MAX_SLOTS = 64;
 struct Combiner {
 	std::mutex mu;
 	std::condition_variable cv;
@@ -266,54 +299,122 @@ struct Combiner {
 	bool busy[N_LANES] = {};
 	ThreadCtx ctx[N_LANES];             // stream + arenas of a pass in flight (exclusive to its leader)
 	uint64_t epoch[N_LANES] = { ~0ull, ~0ull, ~0ull, ~0ull };
-} CB;
-
-static bool is_combiner_ctx(const ThreadCtx *c) { return c >= &CB.ctx[0] && c < &CB.ctx[N_LANES]; }
+	std::atomic<int64_t> outstanding{0};            // anchors of the calls that have entered this slot and not yet left it (what the routing balances)
+	std::atomic<uint64_t> passes{0}, calls{0}, anchors{0};   // served since mm2c_init (mm2c_get_slot_stats)
+	std::atomic<double> pred_ms{0.0};               // path A: predicted device time (hw_time_pred) of the calls inside the slot (run_chaining_on_hw's decline, chain_hardware.cpp:54-75)
+};
+static Combiner CB[MAX_SLOTS];
+std::atomic<uint64_t> g_declined{0};
 
 void release_combiner()
 {
-	if (getenv("MM2C_PASS_TIMING") && g_pt_n.load())
+	if (g_pt_on && g_pt_n.load()) {
+		static const char *cls[8] = { "<256", "<512", "<1024", "<2048", "<4096", "<8192", "<16384", ">=16384" };
+		for (int k = 0; k < 8; ++k)
+			if (g_pt_cls_calls[k].load()) fprintf(stderr, "[mm2chain] calls of %s anchors: %llu, %.1f us each\n", cls[k], (unsigned long long)g_pt_cls_calls[k].load(), g_pt_cls_ns[k].load() / 1e3 / g_pt_cls_calls[k].load());
+		fprintf(stderr, "[mm2chain] %.2f requests per staged pass\n", (double)g_pt_cls_reqs.load() / g_pt_n.load());
 		fprintf(stderr, "[mm2chain] %llu staged passes: assembled on the host %.1f us each, put on the stream %.1f us, waited for %.1f us, results handed back %.1f us\n",
 		        (unsigned long long)g_pt_n.load(), g_pt_build.load() / 1e3 / g_pt_n.load(), g_pt_submit.load() / 1e3 / g_pt_n.load(), g_pt_wait.load() / 1e3 / g_pt_n.load(), g_pt_out.load() / 1e3 / g_pt_n.load());
-	std::lock_guard<std::mutex> lk(CB.mu);
-	for (int k = 0; k < N_LANES; ++k) { CB.ctx[k].release(); CB.epoch[k] = ~0ull; }
+	}
+	for (int s = 0; s < MAX_SLOTS; ++s) {
+		std::lock_guard<std::mutex> lk(CB[s].mu);
+		for (int k = 0; k < N_LANES; ++k) {
+			if (CB[s].ctx[k].st && CB[s].ctx[k].device >= 0) (void)hipSetDevice(CB[s].ctx[k].device);
+			CB[s].ctx[k].release(); CB[s].epoch[k] = ~0ull;
+		}
+		CB[s].passes = 0; CB[s].calls = 0; CB[s].anchors = 0; CB[s].outstanding = 0; CB[s].pred_ms = 0.0;
+	}
+	g_declined = 0;
 }
 
-int submit_combined(HostReq *me)
+// The slot a per-read call goes to: the one with the least anchors outstanding, idle slots in turn from tid % n (negative tid: as 0).  Adds the call's anchors to the
+// slot; the caller hands them back with leave_slot().
+int enter_slot(int tid, int64_t n_anchors)
 {
-	std::unique_lock<std::mutex> lk(CB.mu);
-	CB.pending.push_back(me);
+	const int nd = std::max(1, std::min(n_devices(), MAX_SLOTS));
+	int best = 0;
+	if (nd > 1) {
+		int64_t out[MAX_SLOTS];
+		for (int s = 0; s < nd; ++s) out[s] = CB[s].outstanding.load(std::memory_order_relaxed);
+		best = mm2c_route_slot(nd, out, tid);
+	}
+	CB[best].outstanding.fetch_add(n_anchors, std::memory_order_relaxed);
+	return best;
+}
+void leave_slot(int slot, int64_t n_anchors) { CB[slot].outstanding.fetch_sub(n_anchors, std::memory_order_relaxed); }
+
+int get_slot_stats(int slot, uint64_t *passes, uint64_t *calls, uint64_t *anchors)
+{
+	if (slot < 0 || slot >= MAX_SLOTS) return -1;
+	*passes = CB[slot].passes.load(); *calls = CB[slot].calls.load(); *anchors = CB[slot].anchors.load();
+	return 0;
+}
+
+// Path A's decline (chain_hardware.cpp:54-75): the reference accepts a call on a kernel when (the time until that kernel is free) + hw_time_pred < sw_time_pred and
+// otherwise tries the next kernel, returning 1 when none will do.  Here a device serves several calls at once (combined passes, `combiner_lanes` of them in
+// flight), so "the time until it is free" is the predicted device time of the calls inside the slot divided by the lanes.  Returns the slot that took the call (its
+// hw_time_pred is then booked until release_pred) or -1 = declined.  Predictions that are not positive (a caller that has no model) never decline.
+int book_pred(int tid, float hw_ms, float sw_ms)
+{
+	const int nd = std::max(1, std::min(n_devices(), MAX_SLOTS));
+	const int first = (int)((unsigned)(tid < 0 ? 0 : tid) % (unsigned)nd);
+	const double lanes = (double)std::max(1, std::min<int>(N_LANES, G.combiner_lanes));
+	for (int k = 0; k < nd; ++k) {
+		const int s = (first + k) % nd;
+		double cur = CB[s].pred_ms.load(std::memory_order_relaxed);
+		for (;;) {
+			const double total = cur / lanes + (double)hw_ms;
+			if (!(hw_ms > 0.f && sw_ms > 0.f) || total < (double)sw_ms) {
+				if (CB[s].pred_ms.compare_exchange_weak(cur, cur + (double)hw_ms, std::memory_order_relaxed)) return s;
+				continue;                                            // another caller booked meanwhile: look again
+			}
+			break;
+		}
+	}
+	return -1;
+}
+void release_pred(int slot, float hw_ms)
+{
+	double cur = CB[slot].pred_ms.load(std::memory_order_relaxed);
+	while (!CB[slot].pred_ms.compare_exchange_weak(cur, std::max(0.0, cur - (double)hw_ms), std::memory_order_relaxed)) {}
+}
+
+int submit_combined(HostReq *me, int slot)
+{
+	Combiner &cb = CB[slot];
+	std::unique_lock<std::mutex> lk(cb.mu);
+	cb.pending.push_back(me);
 	for (;;) {
 		if (me->done) return me->rc;
-		if (!me->taken && CB.leaders < std::max(1, std::min<int>(N_LANES, G.combiner_lanes))) break;   // (a request that sits in another leader's pass waits for that pass)
-		CB.cv.wait(lk);
+		if (!me->taken && cb.leaders < std::max(1, std::min<int>(N_LANES, G.combiner_lanes))) break;   // (a request that sits in another leader's pass waits for that pass)
+		cb.cv.wait(lk);
 	}
 	int lane_k = 0;
-	while (lane_k < N_LANES - 1 && CB.busy[lane_k]) ++lane_k;
-	CB.busy[lane_k] = true;
+	while (lane_k < N_LANES - 1 && cb.busy[lane_k]) ++lane_k;
+	cb.busy[lane_k] = true;
 	// leader: collect the pending requests that share my scalars, up to the staging size.  Nothing in here may leave the followers waiting
 	// or `leader_active` set: allocation failures (std::bad_alloc from the vectors here and inside run_requests) become an error code for
 	// every request of the batch, and no exception crosses the extern "C" boundary.
-	++CB.leaders;
+	++cb.leaders;
 	std::vector<HostReq *> batch, rest;
 	int rc = 0;
 	try {
 		size_t tot = 0;
-		for (HostReq *q : CB.pending) {
+		for (HostReq *q : cb.pending) {
 			const size_t n = (size_t)(q->off[q->n_tasks] - q->off[0]);
 			if ((q == me || (memcmp(q->par, me->par, sizeof(mm2c_params_t)) == 0 && tot + n <= G.stage_max_anchors)) ) { batch.push_back(q); tot += n; q->taken = true; }
 			else rest.push_back(q);
 		}
-		CB.pending.swap(rest);
+		cb.pending.swap(rest);
 	} catch (...) {
 		// could not even form the batch: serve only myself (the others stay pending for the next leader)
-		for (HostReq *q : CB.pending) if (q != me) q->taken = false;
+		for (HostReq *q : cb.pending) if (q != me) q->taken = false;
 		batch.clear();
-		for (size_t k = 0; k < CB.pending.size(); ++k) if (CB.pending[k] == me) { CB.pending.erase(CB.pending.begin() + (long)k); break; }
+		for (size_t k = 0; k < cb.pending.size(); ++k) if (cb.pending[k] == me) { cb.pending.erase(cb.pending.begin() + (long)k); break; }
 		me->rc = fail(MM2C_E_ARG, "out of host memory in the call combiner"); me->done = true;
 		strncpy(me->err, g_err, sizeof(me->err) - 1); me->err[sizeof(me->err) - 1] = 0;
-		--CB.leaders; CB.busy[lane_k] = false;
-		CB.cv.notify_all();
+		--cb.leaders; cb.busy[lane_k] = false;
+		cb.cv.notify_all();
 		return me->rc;
 	}
 	lk.unlock();
@@ -321,25 +422,32 @@ int submit_combined(HostReq *me)
 		{
 			std::lock_guard<std::mutex> gl(G.mu);
 			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
-			else if (CB.epoch[lane_k] != G.epoch) {                   // first pass after (re)initialisation: fresh stream and arenas
-				CB.ctx[lane_k] = ThreadCtx();
-				hipError_t e = hipSetDevice(G.device);                       // the combiner belongs to the primary device, whoever leads first
-				if (e == hipSuccess) e = hipStreamCreateWithFlags(&CB.ctx[lane_k].st, hipStreamNonBlocking);
+			else if (slot >= (int)G.devices.size()) rc = fail(MM2C_E_ARG, "device slot %d of %d", slot, (int)G.devices.size());
+			else if (cb.epoch[lane_k] != G.epoch) {                   // first pass after (re)initialisation: fresh stream and arenas ON THE SLOT'S DEVICE
+				cb.ctx[lane_k] = ThreadCtx();
+				cb.ctx[lane_k].device = G.devices[(size_t)slot];
+				hipError_t e = hipSetDevice(cb.ctx[lane_k].device);
+				if (e == hipSuccess) e = hipStreamCreateWithFlags(&cb.ctx[lane_k].st, hipStreamNonBlocking);
 				if (e != hipSuccess) rc = fail(MM2C_E_HIP, "combiner stream: %s", hipGetErrorString(e));
-				else CB.epoch[lane_k] = G.epoch;
+				else cb.epoch[lane_k] = G.epoch;
 			}
 		}
-		if (rc == 0) rc = run_requests(&CB.ctx[lane_k], batch.data(), (int)batch.size());
+		if (rc == 0) rc = run_requests(&cb.ctx[lane_k], batch.data(), (int)batch.size());
 	} catch (...) {
 		rc = fail(MM2C_E_ARG, "out of host memory in a combined chaining pass");
+	}
+	if (rc == 0) {
+		uint64_t tot = 0;
+		for (HostReq *q : batch) tot += (uint64_t)(q->off[q->n_tasks] - q->off[0]);
+		cb.passes += 1; cb.calls += (uint64_t)batch.size(); cb.anchors += tot;
 	}
 	lk.lock();
 	for (HostReq *q : batch) {
 		q->rc = rc; q->done = true;
 		if (rc != 0) { strncpy(q->err, g_err, sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
 	}
-	--CB.leaders; CB.busy[lane_k] = false;
-	CB.cv.notify_all();
+	--cb.leaders; cb.busy[lane_k] = false;
+	cb.cv.notify_all();
 	return me->rc;
 }
 
@@ -347,8 +455,8 @@ int submit_combined(HostReq *me)
 
 extern "C" {
 
-int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
-                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+static int chain_batch_host_tid(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                                const float *h_avg_qspan, int32_t *h_f, int32_t *h_p, int tid)
 {
 	int rc;
 	const auto t_begin = std::chrono::steady_clock::now();
@@ -360,7 +468,7 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	if (!h_anchors || !h_f || !h_p) return fail(MM2C_E_ARG, "host pointer is NULL");
 	if (should_split(total))      // several devices: one contiguous range of tasks per device, side by side (f / p are indexed by the caller's offsets)
 		return run_split(n_tasks, h_offsets, [&](int, int64_t k0, int64_t k1) {
-			return mm2c_chain_batch_host(par, k1 - k0, h_offsets + k0, h_anchors, h_avg_qspan ? h_avg_qspan + k0 : nullptr, h_f, h_p);
+			return chain_batch_host_tid(par, k1 - k0, h_offsets + k0, h_anchors, h_avg_qspan ? h_avg_qspan + k0 : nullptr, h_f, h_p, tid);
 		});
 	HostReq req;
 	req.par = par; req.n_tasks = n_tasks; req.off = h_offsets; req.a = h_anchors; req.avg = h_avg_qspan; req.f = h_f; req.p = h_p;
@@ -368,7 +476,10 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 	// the combiner's context (stream, arenas) lives on the primary device: the worker of a split batch drives another one and runs on the
 	// context of its own device slot, however small its range is
 	if (!in_split_worker() && (size_t)total <= G.combine_max_anchors) {
-		rc = submit_combined(&req);
+		// the device slot with the least work inside it takes the call (one combiner per device)
+		const int slot = enter_slot(tid, total);
+		rc = submit_combined(&req, slot);
+		leave_slot(slot, total);
 		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
 	} else {
 		ScopedNs timed_total(SS.total_ns); ++SS.calls;
@@ -377,8 +488,16 @@ int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64
 		HostReq *one = &req;
 		rc = run_requests(c, &one, 1);
 	}
-	G.host_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	const uint64_t call_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+	G.host_call_ns += call_ns;
+	if (g_pt_on) { int k = 0; while (k < 7 && total >= (256LL << k)) ++k; g_pt_cls_ns[k] += call_ns; ++g_pt_cls_calls[k]; }
 	return rc;
+}
+
+int mm2c_chain_batch_host(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
+                          const float *h_avg_qspan, int32_t *h_f, int32_t *h_p)
+{
+	return chain_batch_host_tid(par, n_tasks, h_offsets, h_anchors, h_avg_qspan, h_f, h_p, -1);
 }
 
 int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_sc, int64_t n_tasks, const int64_t *h_offsets,
@@ -551,14 +670,52 @@ int mm2c_last_host_variant(char *buf, size_t len)
 	return 0;
 }
 
+int mm2c_chain_task_host_pred(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
+                              int32_t *f, int32_t *p, int tid, float hw_time_pred, float sw_time_pred)
+{
+	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
+	if (!G.decline_when_busy.load() || !(hw_time_pred > 0.f && sw_time_pred > 0.f)) return mm2c_chain_task_host(par, n, a, avg_qspan_scaled, f, p, tid);
+	const int slot = book_pred(tid, hw_time_pred, sw_time_pred);
+	if (slot < 0) { ++g_declined; return 1; }                                                                // chain_hardware.cpp:75
+	const int rc = mm2c_chain_task_host(par, n, a, avg_qspan_scaled, f, p, tid);
+	release_pred(slot, hw_time_pred);
+	return rc;
+}
+
+int mm2c_route_slot(int n_slots, const int64_t *outstanding, int tid)
+{
+	if (n_slots <= 1 || !outstanding) return 0;
+	const int first = (int)((unsigned)(tid < 0 ? 0 : tid) % (unsigned)n_slots);
+	int best = first;
+	int64_t least = INT64_MAX;
+	for (int k = 0; k < n_slots; ++k) {
+		const int s = (first + k) % n_slots;
+		if (outstanding[s] < least) { least = outstanding[s]; best = s; }
+	}
+	return best;
+}
+
+int mm2c_get_slot_stats(int slot, mm2c_slot_stats_t *out)
+{
+	if (!out) return fail(MM2C_E_ARG, "NULL argument");
+	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (slot < 0 || slot >= n_devices()) return fail(MM2C_E_ARG, "device slot %d of %d", slot, n_devices());
+	memset(out, 0, sizeof(*out));
+	out->device = G.devices[(size_t)slot];
+	get_slot_stats(slot, &out->passes, &out->calls, &out->anchors);
+	out->declined = slot == 0 ? g_declined.load() : 0;
+	return 0;
+}
+
 int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
                          int32_t *f, int32_t *p, int tid)
 {
-	(void)tid;  // the reference uses tid for its FIFO (chain_hardware.cpp:65,83); each host thread owns a stream here
+	// tid: the kt_for worker id (map.c:427,449).  The reference uses it for its FIFO (chain_hardware.cpp:65,83); here it is where the scan over the device slots
+	// starts (idle devices are taken in turn, thread k first looks at device k % n)
 	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
 	if (n < 0) return fail(MM2C_E_ARG, "n < 0");
 	const int64_t off[2] = { 0, n };
-	return mm2c_chain_batch_host(par, 1, off, a, &avg_qspan_scaled, f, p);
+	return chain_batch_host_tid(par, 1, off, a, &avg_qspan_scaled, f, p, tid);
 }
 
 } // extern "C"

@@ -27,6 +27,11 @@ class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("anchors", C.c_uint64), ("launches", C.c_uint64), ("segments", C.c_uint64), ("host_call_ns", C.c_uint64), ("passes", C.c_uint64)]
 
 
+class SlotStats(C.Structure):
+    """mm2c_slot_stats_t"""
+    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32), ("passes", C.c_uint64), ("calls", C.c_uint64), ("anchors", C.c_uint64), ("declined", C.c_uint64)]
+
+
 class StageStats(C.Structure):
     """mm2c_stage_stats_t"""
     _fields_ = [(k, C.c_uint64) for k in ("calls", "chunks", "total_ns", "alloc_ns", "n_alloc", "free_ns", "n_free", "setup_ns", "h2d_ns", "seed_ns", "dp_ns",
@@ -63,6 +68,9 @@ C_SYMBOLS = {
     "mm2c_pinned_alloc": (C.c_void_p, [C.c_size_t]),
     "mm2c_pinned_free": (None, [C.c_void_p]),
     "mm2c_chain_task_host": (C.c_int, [C.POINTER(Params), C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
+    "mm2c_chain_task_host_pred": (C.c_int, [C.POINTER(Params), C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]),
+    "mm2c_get_slot_stats": (C.c_int, [C.c_int, C.POINTER(SlotStats)]),
+    "mm2c_route_slot": (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
     "mm_chain_dp": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                  C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
     "mm2c_plan_chains_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -107,6 +115,7 @@ CXX_SYMBOLS = {
                                                                    C.c_int, C.c_float, C.c_float]),
     "_Z13hardware_initlPc": (C.c_bool, [C.c_long, C.c_char_p]),
     "_Z7cleanupv": (None, []),
+    "_Z10checkErroriNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEE": (None, [C.c_int, C.c_void_p]),   # chain_hardware.h:72 (a std::string by value: not callable from ctypes, only checked for presence)
 }
 
 _lib = None

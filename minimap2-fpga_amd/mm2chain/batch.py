@@ -259,6 +259,26 @@ def chain_task(params: Params, anchors, avg_qspan_scaled, tid=0):
     return f, p
 
 
+def chain_task_pred(params: Params, anchors, avg_qspan_scaled, tid, hw_time_pred, sw_time_pred):
+    """mm2c_chain_task_host_pred: the same call under the reference's busy protocol (chain_hardware.cpp:54-75).  Returns (ret, f, p); ret 1 = declined, f / p untouched."""
+    lib = N.load()
+    a = np.ascontiguousarray(anchors).view(np.uint64).reshape(-1, 2)
+    n = a.shape[0]
+    f = np.full(n, -77, dtype=np.int32)
+    p = np.full(n, -77, dtype=np.int32)
+    rc = lib.mm2c_chain_task_host_pred(C.byref(params), n, _np_ptr(a), float(avg_qspan_scaled), _np_ptr(f), _np_ptr(p), tid, float(hw_time_pred), float(sw_time_pred))
+    if rc != 1:
+        N.check(rc, "mm2c_chain_task_host_pred")
+    return rc, f, p
+
+
+def slot_stats(slot):
+    """mm2c_get_slot_stats as a dict: what the call combiner of device slot `slot` has served since init"""
+    st = N.SlotStats()
+    N.check(N.load().mm2c_get_slot_stats(int(slot), C.byref(st)), "mm2c_get_slot_stats")
+    return {k: int(getattr(st, k)) for k, _ in st._fields_ if k != "reserved"}
+
+
 def _split_chains(n_tasks, u_off, u, b_off, b):
     return [(u[u_off[k]:u_off[k + 1]].copy(), b[b_off[k]:b_off[k + 1]].copy()) for k in range(n_tasks)]
 

@@ -55,7 +55,11 @@ int main(int argc, char *argv[])
 	mm_verbose = 1;
 #ifdef MM2_GPU_CHAINING
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);   /* the host's own environment, before its first HIP call: the library's pipelines want a hardware queue per stream */
-	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
+	{
+		double t0 = realtime();
+		if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
+		if (getenv("MM2_TIMING")) fprintf(stderr, "[mm2_gpuhost] mm2c_init: %.3f s\n", realtime() - t0);
+	}
 #endif
 	if (getenv("MM2_PRINT_SEEDS")) mm_dbg_flag |= MM_DBG_PRINT_SEED;   /* main.c:193 --print-seeds */
 	mm_realtime0 = realtime();
@@ -81,7 +85,20 @@ int main(int argc, char *argv[])
 	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu pieces, %llu passes, %llu launches, %.3f s inside the chaining calls (summed over threads), %.1f us per call\n",
 	                                                 (unsigned long long)st.tasks, (unsigned long long)st.anchors, (unsigned long long)st.segments, (unsigned long long)st.passes, (unsigned long long)st.launches,
 	                                                 st.host_call_ns * 1e-9, st.tasks ? st.host_call_ns * 1e-3 / st.tasks : 0.0); }
-	mm2c_shutdown();                                     /* cleanup, main.c:430 */
+	{
+		int s, nd = mm2c_device_count();
+		fprintf(stderr, "[mm2_gpuhost] per device slot:");
+		for (s = 0; s < nd; ++s) {
+			mm2c_slot_stats_t ss;
+			if (mm2c_get_slot_stats(s, &ss) == 0) fprintf(stderr, " slot %d (device %d) %llu passes %llu calls %llu anchors;", s, ss.device, (unsigned long long)ss.passes, (unsigned long long)ss.calls, (unsigned long long)ss.anchors);
+		}
+		fprintf(stderr, "\n");
+	}
+	{
+		double t0 = realtime();
+		mm2c_shutdown();                                 /* cleanup, main.c:430 */
+		if (getenv("MM2_TIMING")) fprintf(stderr, "[mm2_gpuhost] mm2c_shutdown: %.3f s; %.3f s since start\n", realtime() - t0, realtime() - mm_realtime0);
+	}
 #endif
 	return fflush(stdout) == EOF;
 }

@@ -155,3 +155,37 @@ def test_in_process_device_split_covers_and_balances():
         # ranges end at the first task boundary at or beyond their share
         for s in range(1, n_parts):
             assert int(off[b[s]] - off[0]) >= total * s // n_parts or b[s] == n_tasks
+
+
+def test_per_read_calls_are_routed_to_the_least_loaded_device_slot():
+    """mm2c_route_slot, the rule by which a per-read call (run_chaining_on_hw / mm_chain_dp, one blocking call per read) picks a device's call combiner -- the
+    reference picks one of its kernels per call (chain_hardware.cpp:58-72).  Fake device counts, no GPU: the least loaded slot wins, idle slots are taken in turn
+    from tid % n, and a simulated stream of calls (each stays for a time proportional to its anchors) spreads its anchors evenly."""
+    import ctypes as C
+    from mm2chain import _native as N
+    lib = N.load()
+
+    def route(out, tid):
+        a = np.ascontiguousarray(out, dtype=np.int64)
+        return lib.mm2c_route_slot(a.size, a.ctypes.data_as(C.c_void_p), tid)
+
+    assert route([0], 5) == 0 and route([7, 7, 7, 7], 6) == 2 and route([7, 7, 7, 7], -3) == 0
+    assert route([5, 0, 9, 0], 0) == 1 and route([5, 0, 9, 0], 2) == 3 and route([5, 0, 9, 0], 3) == 3
+    assert route([1, 2, 3, 0, 4, 5, 6, 7], 11) == 3
+    assert lib.mm2c_route_slot(1, None, 4) == 0 and lib.mm2c_route_slot(8, None, 4) == 0
+    rng = np.random.default_rng(8)
+    for n_slots in (2, 4, 8):
+        out = np.zeros(n_slots, np.int64)
+        served = np.zeros(n_slots, np.int64)
+        inside = []                                                 # (leaves at, slot, anchors)
+        now = 0
+        for call in range(20000):
+            n = int(rng.integers(200, 20000))
+            now += int(rng.integers(0, 3000))
+            for t, s, m in [c for c in inside if c[0] <= now]:
+                out[s] -= m
+            inside = [c for c in inside if c[0] > now]
+            s = route(out, call % 16)
+            out[s] += n; served[s] += n
+            inside.append((now + n, s, n))
+        assert served.min() > 0.8 * served.mean(), (n_slots, served)

@@ -141,3 +141,88 @@ def test_bench_gpus_2_starts_two_ranks_on_the_gpu():
         assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
         assert out["verified_vs_oracle"] is True and out["value"] > 0
         assert out["scaling"] == ("strong" if extra else "weak")
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_per_read_calls_are_served_by_every_device_context(n_ctx):
+    """The reference's dispatch surface -- one blocking call per read from many host threads (map.c:561 -> chain.c:103 -> run_chaining_on_hw) -- with several
+    devices configured: every device slot has its own call combiner (lanes, streams, arenas on that device) and a call goes to the least loaded slot
+    (chain_hardware.cpp:9-23,58-72: a queue, a lock, a buffer set per kernel, one picked per call).  The box has one GPU, listed n_ctx times.  Twelve threads,
+    both entries (the reference symbol = V2, the extended entry = V1); every slot must have served passes, and every result must equal the oracle's."""
+    import threading
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    off, a = _stream("mixed", 96, (150, 5000), seed=91 + n_ctx)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    Pv2 = params.make_params(max_skip=2**31 - 1, max_iter=1024)
+    f_v2, p_v2 = oracle_batch(Pv2, off, a)
+    mm2chain.shutdown()
+    mm2chain.init_devices([0] * n_ctx)
+    errs = []
+    try:
+        assert mm2chain.device_count() == n_ctx
+
+        def worker(tid):
+            try:
+                for rep in range(3):
+                    for k in range(tid, 96, 12):
+                        t = a[off[k]:off[k + 1]]
+                        avg = ob.avg_qspan(t)
+                        f, p = mm2chain.chain_task(P, t, avg, tid=tid)
+                        assert_same(f, p, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"V1 read {k} thread {tid}")
+                        ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=tid)
+                        assert ret == 0
+                        assert_same(f, p, f_v2[off[k]:off[k + 1]], p_v2[off[k]:off[k + 1]], None, f"V2 read {k} thread {tid}")
+            except Exception as e:                                  # noqa: BLE001 -- reported below, on the main thread
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:3]
+        st = [mm2chain.slot_stats(s) for s in range(n_ctx)]
+        assert all(s["device"] == 0 for s in st)
+        assert sum(s["calls"] for s in st) == 96 * 3 * 2, st
+        assert sum(s["anchors"] for s in st) == int(off[-1]) * 3 * 2, st
+        assert all(s["passes"] > 0 and s["calls"] > 0 for s in st), f"a device slot served nothing: {st}"
+        with pytest.raises(Exception):
+            mm2chain.slot_stats(n_ctx)
+    finally:
+        mm2chain.shutdown()
+        mm2chain.init(0)
+
+
+def test_busy_protocol_of_the_reference_symbol():
+    """chain_hardware.cpp:54-75 (PROCESS_ON_SW_IF_HW_BUSY): run_chaining_on_hw returns 1 = declined when waiting for the device plus hw_time_pred would take longer
+    than sw_time_pred; the caller's own loop (chain.c:106,112-164) then runs.  Here: a prediction pair the idle device cannot meet is declined with f / p untouched,
+    one it can meet is computed (== the oracle), predictions that are not positive never decline, and the knob turns the protocol off."""
+    import mm2chain
+    from mm2chain import params
+    off, a = _stream("mixed", 2, 1500, seed=12)
+    t = a[off[0]:off[1]]
+    avg = ob.avg_qspan(t)
+    Pv2 = params.make_params(max_skip=2**31 - 1, max_iter=1024)
+    f_ref, p_ref, _ = ob.chain_fpv(Pv2, t, avg)
+    d0 = mm2chain.slot_stats(0)["declined"]
+    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=2.0, sw_time_pred=0.5)
+    assert ret == 1 and mm2chain.slot_stats(0)["declined"] == d0 + 1
+    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.4, sw_time_pred=0.5)
+    assert ret == 0
+    assert_same(f, p, f_ref, p_ref, None, "accepted call")
+    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.0, sw_time_pred=-1.0)
+    assert ret == 0
+    assert_same(f, p, f_ref, p_ref, None, "no model: never declined")
+    P = params.map_ont()
+    rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 9.0, 1.0)
+    assert rc == 1 and np.all(f == -77) and np.all(p == -77)          # declined: nothing written
+    try:
+        mm2chain.tune("decline_when_busy", 0)
+        rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 9.0, 1.0)
+        f1, p1, _ = ob.chain_fpv(P, t, avg)
+        assert rc == 0
+        assert_same(f, p, f1, p1, None, "protocol off")
+    finally:
+        mm2chain.tune("decline_when_busy", 1)

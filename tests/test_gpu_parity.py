@@ -159,9 +159,22 @@ def test_drive_every_fold_of_the_hand_written_loop(compact, gap_scale, knobs):
         assert "loop=asm" in v[0] and f"compact={compact}" in v[0] and f"TAB={int(gap_scale != 1.0)}" in v[0], v
 
 
-@pytest.mark.parametrize("case", ["profiles", "fold-drivers", "tile-paths", "compact-corners", "random-scalars", "ava-ont", "tiny-and-ragged"])
+def _steep_colinear_task(rng, n, step_lo, step_hi, jitter_lo, jitter_hi):
+    """one colinear chain whose links are `step` apart in x and differ by `jitter` between x and q: every anchor's best predecessor is its neighbour, the gap cost of a
+    link is (int)(jitter * avg) + log2(jitter) / 2"""
+    step = rng.integers(step_lo, step_hi + 1, n)
+    jit = rng.integers(jitter_lo, jitter_hi + 1, n) * rng.choice([-1, 1], n)
+    pos = (1 << 20) + np.cumsum(step)
+    q = 100 + np.cumsum(np.maximum(step + jit, 1))
+    assert pos[-1] < (1 << 31) and q[-1] < (1 << 31)
+    x = (np.uint64(1) << np.uint64(32)) | pos.astype(np.uint64)
+    y = (np.uint64(15) << np.uint64(32)) | q.astype(np.uint64)
+    return np.stack((x, y), 1)
+
+
+@pytest.mark.parametrize("case", ["profiles", "fold-drivers", "tile-paths", "compact-corners", "random-scalars", "ava-ont", "tiny-and-ragged", "steep-scores"])
 def test_several_waves_per_task_equal_the_oracle(case, knobs):
-    """chain_dp_coop (csrc/chain_dp_coop.h): a workgroup of 8 waves per task.  Candidates are counted and the older tiles reduced in parallel; an anchor with at
+    """chain_dp_coop (csrc/chain_dp_coop.h): a workgroup of 16 waves per task.  Candidates are counted and the older tiles reduced in parallel; an anchor with at
     most max_skip candidates in its window cannot take the `break` of chain.c:231, so its result is the plain maximum (nearest j on ties, chain.c:226); every
     other anchor takes the exact scan (hand-written loop or C++).  Both kinds, the hand-over between them inside a tile, windows beyond the ring, equal-x runs,
     per-anchor spans, max_skip from -1 to INT_MAX, the gap-cost table: same f / p as the oracle."""
@@ -210,6 +223,11 @@ def test_several_waves_per_task_equal_the_oracle(case, knobs):
         runs.append((params.ava_ont(), off, a))
         off, a = _stream("dense", 2, 5000, seed=63, locus=9000)           # windows of 1 400 anchors: beyond the ring of 16 tiles
         runs += [(params.map_ont(), off, a), (params.make_params(max_skip=INT32_MAX, max_iter=1024), off, a)]
+    elif case == "steep-scores":
+        # round 4's advisor: the straight-line pushes carry score << 7 | origin in ONE word, right only while a chain gains at most 255 per link.  A negative
+        # gap_scale turns the gap cost into a gain (chain.c:219): -15 * ((int)(300 * .15) + 4) = +735 on top of the span per link, 30 000 links: f passes 2^23
+        t = _steep_colinear_task(rng, 30000, 20, 60, 200, 420)
+        runs.append((params.make_params(gap_scale=-15.0, bw=500), None, [t, t[:700]]))
     else:
         sizes = [1, 2, 63, 64, 65, 127, 128, 129, 1000, 0, 5, 4097]
         tasks = [synth.make_stream("mixed", 1, max(n, 1), seed=900 + k)[1].numpy().view(np.uint64)[:n] for k, n in enumerate(sizes)]
@@ -222,6 +240,8 @@ def test_several_waves_per_task_equal_the_oracle(case, knobs):
         v = []
         f, p = gpu_batch(P, off, a, variant=v)
         assert_same(f, p, f_ref, p_ref, off, f"several waves per task, {case}, {params.as_dict(P)}: {v[0]}")
+        if case == "steep-scores":
+            assert int(f_ref.max()) > (1 << 23), "the task was meant to carry scores beyond the one-word key"
         simple = P.gap_scale == 1.0 or P.bw <= 511
         assert v[0].startswith("chain_dp_coop<W=16") == (simple and P.bw >= 0 and min(P.max_dist_x, P.max_dist_y) - 1 >= P.bw), (v, params.as_dict(P))
 
@@ -472,6 +492,23 @@ def test_fpga_v2_through_the_reference_symbol():
         assert_same(f, p, f_lit, p_lit, None, "v2 literal")
         f_v1, p_v1, _ = ob.chain_fpv(params.make_params(max_skip=INT32_MAX, max_iter=1024), t, avg)
         assert_same(f, p, f_v1, p_v1, None, "v2 as v1")
+
+
+def test_reference_symbol_with_a_span_beyond_255():
+    """run_chaining_on_hw takes q_span as an int (chain_hardware.h:68) and nothing bounds it: with q_span 5000 a link gains up to 5000 and a 30 000-anchor chain
+    carries scores beyond 2^23 -- the lone call runs the cooperative kernel, whose one-word keys (score << 7 | origin) must not be taken then (round 4's advisor).
+    Checked against the literal emulation of the .cl kernel."""
+    import mm2chain
+    rng = np.random.default_rng(77)
+    t = _steep_colinear_task(rng, 30000, 1500, 4000, 0, 40)
+    avg = 50.0
+    ns, tot, _ = ob.predict(t, 5000)
+    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 5000, avg, t, ns, tot, tid=0)
+    assert ret == 0
+    f_lit, p_lit = ob.chain_hw_literal(5000, 5000, 500, 5000, avg, t)
+    assert int(f_lit.max()) > (1 << 23)
+    assert_same(f, p, f_lit, p_lit, None, "q_span 5000 through the reference symbol")
+    assert mm2chain.last_host_variant().startswith("chain_dp_coop<W=16"), mm2chain.last_host_variant()
 
 
 def test_host_paths_cut_tasks_at_empty_windows():
