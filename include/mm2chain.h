@@ -59,9 +59,17 @@ typedef struct {
 int  mm2c_init(int device_ordinal);           /* -1: current device -- or, when the environment variable MM2C_DEVICES is set ("all" or a
                                                * comma-separated list of ordinals), those devices as with mm2c_init_devices: the route for a host
                                                * whose init hook carries no ordinals (hardware_init, chain_hardware.h:69).  Idempotent. */
+/* mm2c_init on a thread of its own: returns at once, the runtime start-up (about 0.2 s) and the loading of the kernels' code objects run while the host
+ * does its own start-up work -- a minimap2 host reads or builds its index between hardware_init (main.c:367) and the first chaining call (main.c:371-406).
+ * Every entry that needs the device waits for that thread first; a failure shows there (and in mm2c_init_wait) as MM2C_E_NODEVICE with the reason, the way
+ * a runtime error of the reference surfaces at the call (chain_hardware.cpp:208-235).  mm2c_init_wait: 0 once the library is ready.  mm2c_warm_up: loads
+ * the code objects onto every configured device now instead of at each translation unit's first launch (what the asynchronous form does after its init). */
+int  mm2c_init_async(int device_ordinal);
+int  mm2c_init_wait(void);
+int  mm2c_warm_up(void);
 /* Several devices in one process (the reference scaffolds NUM_HW_KERNELS command queues / buffer sets / locks, chain_hardware.cpp:9-23,
- * chain_hardware.h:57): mm2c_init_devices instead of mm2c_init.  ordinals[0] is the primary device (plans, the per-read entries and
- * the call combiner run there); the host-batch entries (mm2c_chain_batch_host, mm2c_mm_chain_dp_batch_host, mm2c_seed_chain_batch_host)
+ * chain_hardware.h:57): mm2c_init_devices instead of mm2c_init.  ordinals[0] is the primary device (plans run there); the per-read entries (run_chaining_on_hw, mm_chain_dp,
+ * mm2c_chain_task_host) go to the device slot with the least work inside it, every slot with a call combiner of its own (mm2c_get_slot_stats); the host-batch entries (mm2c_chain_batch_host, mm2c_mm_chain_dp_batch_host, mm2c_seed_chain_batch_host)
  * split a batch of at least "multi_min_anchors" anchors (mm2c_tune, default 2^20) into one contiguous range of tasks per device with
  * about equal anchor counts (mm2c_split_tasks) and run the ranges side by side, each on its own stream set and arenas.  Chaining tasks
  * are independent (chain.c:42-45), so there is no exchange between devices.  An ordinal may be listed more than once. */

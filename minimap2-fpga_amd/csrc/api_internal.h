@@ -67,6 +67,11 @@ struct Global {
 	uint64_t epoch = 0;                     // bumped by shutdown so stale thread-local pointers are dropped
 };
 extern Global G;
+// mm2c_init_async: the initialisation runs on a thread of its own while the host does something else (a minimap2 host loads its index, main.c:371-399, before the
+// first chaining call); every entry that needs the device joins that thread first.  async_init_join is a no-op when none is pending and on the thread itself.
+void async_init_join();
+inline bool lib_ready() { async_init_join(); return G.ready; }
+int fail_not_ready();                          // MM2C_E_NODEVICE with the reason: never initialised, or the asynchronous initialisation's own error
 
 // mm2c_stage_stats_t, as atomics (the entries run on many host threads)
 struct StageStats {

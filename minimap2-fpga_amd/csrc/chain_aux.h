@@ -78,5 +78,11 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 hipError_t launch_stage_in(const void *h_src, void *d_dst, size_t bytes, unsigned *d_done, hipStream_t st);
 hipError_t launch_stage_out(const void *d_src, void *h_dst, size_t bytes, unsigned *d_done, unsigned *h_flag, unsigned seq, hipStream_t st);
 
+// force the runtime to load each translation unit's code object onto the current device now (mm2c_warm_up)
+hipError_t warm_chain_kernels();
+hipError_t warm_epilogue_kernels();
+hipError_t warm_seed_kernels();
+hipError_t warm_stage_kernels();
+
 } // namespace mm2c
 #endif

@@ -1038,4 +1038,10 @@ hipError_t launch_chain_epilogue(const EpiArgs &A, hipStream_t st, int *n_launch
 	return hipGetLastError();
 }
 
+hipError_t warm_epilogue_kernels()
+{
+	hipFuncAttributes at;
+	return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&epi_offsets));
+}
+
 } // namespace mm2c

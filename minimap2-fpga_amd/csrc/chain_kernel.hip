@@ -874,4 +874,10 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	return e;
 }
 
+hipError_t warm_chain_kernels()
+{
+	hipFuncAttributes at;
+	return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&chain_window_start_wide));
+}
+
 } // namespace mm2c

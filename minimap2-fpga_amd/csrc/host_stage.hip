@@ -56,4 +56,10 @@ hipError_t launch_stage_out(const void *d_src, void *h_dst, size_t bytes, unsign
 	return hipGetLastError();
 }
 
+hipError_t warm_stage_kernels()
+{
+	hipFuncAttributes at;
+	return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&stage_in));
+}
+
 } // namespace mm2c

@@ -26,6 +26,27 @@ int fail(int code, const char *fmt, ...)
 Global G;
 StageStats SS;
 
+// ---- mm2c_init_async: initialisation beside the host's own start-up work
+static std::mutex g_async_mu;
+static std::thread *g_async_th = nullptr;         // (never destroyed: a host that exits without mm2c_shutdown must not meet std::terminate in a static destructor)
+static std::atomic<bool> g_async_pending{false};
+static char g_async_err[512] = "";
+static thread_local bool tl_is_init_thread = false;   // set on the initialisation thread itself: its own calls into the library must not wait for it
+
+void async_init_join()
+{
+	if (tl_is_init_thread || !g_async_pending.load(std::memory_order_acquire)) return;
+	std::lock_guard<std::mutex> lk(g_async_mu);
+	if (g_async_th && g_async_th->joinable()) g_async_th->join();
+	g_async_pending.store(false, std::memory_order_release);
+}
+
+int fail_not_ready()
+{
+	if (g_async_err[0]) return fail(MM2C_E_NODEVICE, "the asynchronous initialisation (mm2c_init_async) failed: %s", g_async_err);
+	return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+}
+
 // Device memory of plans and one-shot calls goes through a small cache: a batched caller creates and destroys plans of similar size
 // for every mini-batch, and hipMalloc / hipFree of gigabytes cost milliseconds each (hipFree also waits for the device).  A freed
 // block is kept and handed to the next request it fits (the smallest cached block of 1x .. 3x the size: the last chunk of a pipelined batch is
@@ -186,8 +207,9 @@ int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int
 
 int get_thread_ctx(ThreadCtx **out)
 {
+	async_init_join();
 	std::lock_guard<std::mutex> lk(G.mu);
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (tl_slot >= 0) {
 		// the worker of a split batch: the persistent context of its device slot (the caller holds the slot's lock)
 		ThreadCtx *c = &g_slot_ctx[tl_slot];
@@ -229,8 +251,9 @@ int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
 		if (hold.owns_lock()) break;
 	}
 	if (k == N_BATCH_CTX) { k = 0; hold = std::unique_lock<std::mutex>(g_batch_mu[0]); }   // both busy: wait for the first
+	async_init_join();
 	std::lock_guard<std::mutex> lk(G.mu);
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (!g_batch_ctx[k].st || g_batch_epoch[k] != G.epoch) {
 		g_batch_ctx[k] = ThreadCtx();
 		DeviceScope on(G.device);
@@ -371,6 +394,7 @@ const char *mm2c_last_error(void) { return g_err; }
 
 int mm2c_init(int device_ordinal)
 {
+	async_init_join();                               // (a no-op on the initialisation thread itself)
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (G.ready) return 0;
 	// the pipelines of the host-buffer entries run an upload stream and three compute streams side by side; with the runtime's default of four
@@ -447,9 +471,62 @@ int mm2c_init(int device_ordinal)
 	return 0;
 }
 
+int mm2c_init_async(int device_ordinal)
+{
+	async_init_join();                               // one at a time
+	std::lock_guard<std::mutex> lk(g_async_mu);
+	if (G.ready) return 0;
+	g_async_err[0] = 0;
+	try {
+		g_async_pending.store(true, std::memory_order_release);
+		delete g_async_th; g_async_th = nullptr;
+		g_async_th = new std::thread([device_ordinal]() {
+			tl_is_init_thread = true;
+			int rc = mm2c_init(device_ordinal);
+			if (rc == 0) rc = mm2c_warm_up();
+			if (rc != 0) { strncpy(g_async_err, g_err, sizeof(g_async_err) - 1); g_async_err[sizeof(g_async_err) - 1] = 0; }
+		});
+	} catch (...) {
+		g_async_pending.store(false, std::memory_order_release);
+		return fail(MM2C_E_ARG, "could not start the initialisation thread");
+	}
+	return 0;
+}
+
+int mm2c_init_wait(void)
+{
+	async_init_join();
+	return G.ready ? 0 : fail_not_ready();
+}
+
+// loads the code objects of the path's kernels onto every configured device now (the runtime otherwise does it at the first launch of each translation unit: the
+// first chaining calls of a run would pay for it)
+int mm2c_warm_up(void)
+{
+	if (!lib_ready()) return fail_not_ready();
+	std::vector<int> devs;
+	{ std::lock_guard<std::mutex> lk(G.mu); devs = G.devices; }
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	hipError_t e = hipSuccess;
+	for (size_t k = 0; k < devs.size() && e == hipSuccess; ++k) {
+		bool seen = false;
+		for (size_t j = 0; j < k; ++j) seen = seen || devs[j] == devs[k];
+		if (seen) continue;
+		e = hipSetDevice(devs[k]);
+		if (e == hipSuccess) e = mm2c::warm_chain_kernels();
+		if (e == hipSuccess) e = mm2c::warm_epilogue_kernels();
+		if (e == hipSuccess) e = mm2c::warm_seed_kernels();
+		if (e == hipSuccess) e = mm2c::warm_stage_kernels();
+	}
+	if (prev >= 0) (void)hipSetDevice(prev);
+	return e == hipSuccess ? 0 : fail(MM2C_E_HIP, "warm-up: %s", hipGetErrorString(e));
+}
+
 int mm2c_init_devices(int n, const int *ordinals)
 {
 	if (n < 1 || n > 64 || !ordinals) return fail(MM2C_E_ARG, "1 to 64 device ordinals expected");
+	async_init_join();
 	{
 		std::lock_guard<std::mutex> lk(G.mu);
 		if (G.ready) return fail(MM2C_E_ARG, "mm2c_init_devices after initialisation: call mm2c_shutdown first");
@@ -466,7 +543,7 @@ int mm2c_init_devices(int n, const int *ordinals)
 	return rc;
 }
 
-int mm2c_device_count(void) { return G.ready ? (int)G.devices.size() : 0; }
+int mm2c_device_count(void) { return lib_ready() ? (int)G.devices.size() : 0; }
 
 /* Contiguous ranges of tasks with about equal anchor counts: range s = tasks [bounds[s], bounds[s+1]).  A range ends at the first task
  * boundary at or beyond s+1 parts of the total (so no range exceeds its share by more than one task); ranges may be empty. */
@@ -487,6 +564,7 @@ int mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64
 
 void mm2c_shutdown(void)
 {
+	async_init_join();
 	std::lock_guard<std::mutex> bl0(g_batch_mu[0]);   // same order as get_batch_ctx: a batch context's lock (a caller holds at most one), then the library's
 	std::lock_guard<std::mutex> bl1(g_batch_mu[1]);
 	std::lock_guard<std::mutex> lk(G.mu);
@@ -510,7 +588,7 @@ void mm2c_shutdown(void)
 
 int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_bytes)
 {
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, cur_device()));
 	if (name && name_len) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
@@ -521,7 +599,7 @@ int mm2c_device_info(char *name, size_t name_len, int *cu_count, size_t *hbm_byt
 
 int mm2c_debug_label_hits(unsigned long long *hits, int reset)
 {
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (!hits) return fail(MM2C_E_ARG, "hits is NULL");
 	const hipError_t e = mm2c::label_hits_read(hits, reset != 0);
 	if (e == hipErrorNotSupported) return fail(MM2C_E_ARG, "this library was not built with -DMM2C_LABEL_COUNT (minimap2-fpga_amd/variants/labelcount.so is)");
@@ -531,7 +609,7 @@ int mm2c_debug_label_hits(unsigned long long *hits, int reset)
 
 int mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *arch, size_t arch_len)
 {
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	const int dev = cur_device();
 	if (ordinal) *ordinal = dev;
 	if (pci_bus_id && bus_len) {
@@ -728,7 +806,7 @@ void mm2c_reset_stage_stats(void)
 mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets)
 {
 	if (check_params(par)) return nullptr;
-	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (!lib_ready()) { fail_not_ready(); return nullptr; }
 	std::vector<int32_t> order;
 	if (build_order(n_tasks, h_offsets, order)) return nullptr;
 	mm2c_plan *pl = new mm2c_plan();
@@ -795,7 +873,7 @@ int mm2c_plan_set_device_offsets(mm2c_plan_t *pl, const int64_t *d_offsets)
 int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_avg_qspan, int32_t *d_f, int32_t *d_p, void *stream)
 {
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (pl->n_tasks == 0 || pl->total == 0) return 0;
 	if (!d_anchors || !d_f || !d_p) return fail(MM2C_E_ARG, "device pointer is NULL");
 	DeviceScope on(pl->device);
@@ -862,7 +940,7 @@ int mm2c_plan_predict_device(mm2c_plan_t *pl, const void *d_anchors, uint8_t *d_
                              int64_t *d_total_trip_count, void *stream)
 {
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (pl->n_tasks == 0) return 0;
 	if (!d_anchors && pl->total > 0) return fail(MM2C_E_ARG, "device pointer is NULL");
 	DeviceScope on(pl->device);
@@ -917,7 +995,7 @@ int mm2c_plan_chains_device(mm2c_plan_t *pl, const void *d_anchors, const int32_
                             int64_t *d_u_off, uint64_t *d_u, int64_t *d_b_off, void *d_b, void *stream)
 {
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (!d_u_off || !d_b_off) return fail(MM2C_E_ARG, "device pointer is NULL");
 	DeviceScope on(pl->device);
 	HIP_TRY(on.err);
@@ -975,7 +1053,7 @@ int mm2c_plan_last_epilogue_ms(mm2c_plan_t *pl, float *ms)
 void *mm2c_pinned_alloc(size_t bytes)
 {
 	void *p = nullptr;
-	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (!lib_ready()) { fail_not_ready(); return nullptr; }
 	DeviceScope on(cur_device());
 	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
 	if (on.err != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {

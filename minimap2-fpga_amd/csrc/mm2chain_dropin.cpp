@@ -36,6 +36,10 @@ int run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_spa
 bool hardware_init(long buf_size, char *binary_name)
 {
 	(void)buf_size; (void)binary_name;          // BUFFER_N / xclbin path (main.c:367): buffers grow on demand, no bitstream
+	// MM2C_ASYNC_INIT=1: the runtime start-up (0.2 s) runs on a thread of its own while main.c:371-399 reads the index; a device that then turns out to be missing
+	// ends the process at the first chaining call (message + exit, as chain_hardware.cpp:208-235) instead of making this function return false
+	const char *as = getenv("MM2C_ASYNC_INIT");
+	if (as && atoi(as) != 0) return mm2c_init_async(-1) == 0;
 	if (mm2c_init(-1) != 0) {
 		fprintf(stderr, "ERROR: %s\n", mm2c_last_error());
 		return false;                           // main.c:367-369 returns -1 on false

@@ -419,9 +419,10 @@ int submit_combined(HostReq *me, int slot)
 	}
 	lk.unlock();
 	try {
+		async_init_join();
 		{
 			std::lock_guard<std::mutex> gl(G.mu);
-			if (!G.ready) rc = fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+			if (!lib_ready()) rc = fail_not_ready();
 			else if (slot >= (int)G.devices.size()) rc = fail(MM2C_E_ARG, "device slot %d of %d", slot, (int)G.devices.size());
 			else if (cb.epoch[lane_k] != G.epoch) {                   // first pass after (re)initialisation: fresh stream and arenas ON THE SLOT'S DEVICE
 				cb.ctx[lane_k] = ThreadCtx();
@@ -698,7 +699,7 @@ int mm2c_route_slot(int n_slots, const int64_t *outstanding, int tid)
 int mm2c_get_slot_stats(int slot, mm2c_slot_stats_t *out)
 {
 	if (!out) return fail(MM2C_E_ARG, "NULL argument");
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (slot < 0 || slot >= n_devices()) return fail(MM2C_E_ARG, "device slot %d of %d", slot, n_devices());
 	memset(out, 0, sizeof(*out));
 	out->device = G.devices[(size_t)slot];

@@ -29,12 +29,16 @@ std::vector<AuxSet> g_aux_free;
 namespace mm2c_api {
 hipError_t aux_acquire(int device, AuxSet *out)
 {
+	uint64_t epoch_now;
 	{
+		// the library's epoch is written by mm2c_init / mm2c_shutdown under G.mu: read it under that lock, then the pool's (the order shutdown takes them in)
+		std::lock_guard<std::mutex> gl(G.mu);
+		epoch_now = G.epoch;
 		std::lock_guard<std::mutex> lk(g_aux_mu);
 		for (size_t i = 0; i < g_aux_free.size(); ++i)
-			if (g_aux_free[i].device == device && g_aux_free[i].epoch == G.epoch) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return hipSuccess; }
+			if (g_aux_free[i].device == device && g_aux_free[i].epoch == epoch_now) { *out = g_aux_free[i]; g_aux_free.erase(g_aux_free.begin() + (long)i); return hipSuccess; }
 	}
-	AuxSet a; a.device = device; a.epoch = G.epoch;
+	AuxSet a; a.device = device; a.epoch = epoch_now;
 	hipError_t e = hipSuccess;
 	// helper streams on hardware queues of their own: different priorities never share a queue (see create_partner_stream)
 	int least = 0, greatest = 0;
@@ -63,6 +67,8 @@ void aux_release(const AuxSet &a)
 {
 	if (a.device < 0) return;
 	// a plan that outlived mm2c_shutdown() brings back handles of the library's previous life: they are destroyed here, never handed to a plan of the next one
+	// (decided under the library's lock: a shutdown or re-initialisation running beside this release either sees the set in the pool or comes after it was destroyed)
+	std::lock_guard<std::mutex> gl(G.mu);
 	if (a.epoch != G.epoch || !G.ready) { aux_destroy(a); return; }
 	std::lock_guard<std::mutex> lk(g_aux_mu);
 	g_aux_free.push_back(a);
@@ -80,7 +86,7 @@ extern "C" {
 
 mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_off, const int64_t *h_anchor_off)
 {
-	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (!lib_ready()) { fail_not_ready(); return nullptr; }
 	if (n_reads < 0 || n_reads > INT32_MAX || (n_reads > 0 && (!h_match_off || !h_anchor_off))) { fail(MM2C_E_ARG, "bad argument"); return nullptr; }
 	std::vector<int32_t> order;
 	if (build_order(n_reads, h_anchor_off, order)) return nullptr;            // validates the anchor offsets; biggest read first
@@ -164,7 +170,7 @@ int mm2c_seedplan_run_device(mm2c_seedplan_t *pl, const mm2c_match_t *d_matches,
                              void *d_anchors, void *stream)
 {
 	if (!pl) return fail(MM2C_E_ARG, "plan is NULL");
-	if (!G.ready) return fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device");
+	if (!lib_ready()) return fail_not_ready();
 	if (pl->n_reads == 0) return 0;
 	if (!d_qlen || (pl->n_matches > 0 && !d_matches) || (pl->total > 0 && (!d_hits || !d_anchors))) return fail(MM2C_E_ARG, "device pointer is NULL");
 	static_assert(sizeof(mm2c_match_t) == sizeof(mm2c::Match), "mm2c_match_t layout");
@@ -315,7 +321,7 @@ struct mm2c_hitpool {
 
 mm2c_hitpool_t *mm2c_hitpool_create(const uint64_t *h_hits, int64_t n_hits)
 {
-	if (!G.ready) { fail(MM2C_E_NODEVICE, "mm2c_init() has not been called or found no HIP device"); return nullptr; }
+	if (!lib_ready()) { fail_not_ready(); return nullptr; }
 	if (n_hits < 0 || (n_hits > 0 && !h_hits)) { fail(MM2C_E_ARG, "bad argument"); return nullptr; }
 	mm2c_hitpool *hp = new mm2c_hitpool();
 	hp->n = n_hits;

@@ -785,4 +785,10 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	return hipSuccess;
 }
 
+hipError_t warm_seed_kernels()
+{
+	hipFuncAttributes at;
+	return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&seed_offsets));
+}
+
 } // namespace mm2c

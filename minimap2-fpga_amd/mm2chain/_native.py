@@ -42,6 +42,9 @@ class StageStats(C.Structure):
 C_SYMBOLS = {
     "mm2c_init": (C.c_int, [C.c_int]),
     "mm2c_init_devices": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "mm2c_init_async": (C.c_int, [C.c_int]),
+    "mm2c_init_wait": (C.c_int, []),
+    "mm2c_warm_up": (C.c_int, []),
     "mm2c_device_count": (C.c_int, []),
     "mm2c_split_tasks": (C.c_int, [C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "mm2c_shutdown": (None, []),

@@ -347,7 +347,8 @@ int main(int argc, char *argv[])
 	mm_verbose = 1;
 	mm_realtime0 = realtime();
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);   /* the host's own environment, before its first HIP call: the library's pipelines want a hardware queue per stream */
-	if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
+	/* hardware_init's place (main.c:367); the runtime start-up runs beside the index loading below, the first library call waits for it (MM2_SYNC_INIT: the old blocking form) */
+	if ((getenv("MM2_SYNC_INIT") ? mm2c_init(-1) : mm2c_init_async(-1)) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
 	t_init = realtime() - mm_realtime0;
 	defaults(&io, &mo);
 	if (getenv("MM2_MINI_BATCH")) mo.mini_batch_size = atoll(getenv("MM2_MINI_BATCH"));              /* main.c -K */

@@ -57,7 +57,8 @@ int main(int argc, char *argv[])
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);   /* the host's own environment, before its first HIP call: the library's pipelines want a hardware queue per stream */
 	{
 		double t0 = realtime();
-		if (mm2c_init(-1) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }   /* hardware_init, main.c:367 */
+		/* hardware_init's place (main.c:367); the runtime start-up runs beside the index loading below, the first chaining call waits for it (MM2_SYNC_INIT: the blocking form) */
+		if ((getenv("MM2_SYNC_INIT") ? mm2c_init(-1) : mm2c_init_async(-1)) != 0) { fprintf(stderr, "ERROR: %s\n", mm2c_last_error()); return 1; }
 		if (getenv("MM2_TIMING")) fprintf(stderr, "[mm2_gpuhost] mm2c_init: %.3f s\n", realtime() - t0);
 	}
 #endif

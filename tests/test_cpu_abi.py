@@ -73,6 +73,17 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
         mm2chain.seed_chain_batch(params.map_ont(), 3, 40, [0, 1], m, np.zeros(2, np.uint64), [100])
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.SeedPlan([0, 1], [0, 2])
+    # the asynchronous initialisation (runtime start-up beside the host's index loading) cannot report at once: the failure surfaces at the wait and at the
+    # first call that needs the device, with the reason; the busy-protocol entry does not turn it into "declined"
+    from mm2chain import _native as N
+    lib = N.load()
+    assert lib.mm2c_init_async(-1) == 0
+    assert lib.mm2c_init_wait() == -1 and b"asynchronous initialisation" in lib.mm2c_last_error()
+    with pytest.raises(mm2chain.Mm2cError, match="asynchronous initialisation"):
+        mm2chain.chain_task(params.map_ont(), a, 0.15)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.chain_task_pred(params.map_ont(), a, 0.15, 0, 0.1, 5.0)
+    assert lib.mm2c_device_count() == 0
 
 
 def test_argument_validation_happens_before_any_device_work():

@@ -162,6 +162,7 @@ def test_per_read_calls_are_served_by_every_device_context(n_ctx):
     errs = []
     try:
         assert mm2chain.device_count() == n_ctx
+        mm2chain.tune("multi_min_anchors", 1 << 20)                 # (the library's default; the tests above lower it, and knobs outlive a shutdown)
 
         def worker(tid):
             try:
