@@ -845,7 +845,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		MM2C_DPP_PREFIX_MAX("%[va]") \
 		"s_nop 0\n\t" \
 		"v_readlane_b32 %[best], %[va], 63\n\t" \
-		"s_nop 0\n\t" \
+		"s_nop 1\n\t"                                   /* a VALU-written SGPR read by a VALU: two wait states on gfx940 / gfx950 (tools/check_isa_hazards.py, SGPR_VALU) */ \
 		"v_cmp_eq_u32 vcc, %[best], %[sc]\n\t" \
 		"s_ff1_i32_b64 %[t0], vcc\n\t" \
 		"s_add_i32 %[t1], %[base], 63\n\t" \

@@ -99,13 +99,14 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 				"ds_read_u8 v51, v41 offset:1\n\t"                                // the digit behind the one taken
 				"ds_read_b64 v[48:49], v44\n\t"
 				"v_add_u32 v50, 1, v41\n\t"
-				"v_sub_u32 v55, v41, v57\n\t"                                     // source position
 				"v_cmp_eq_u32 vcc, v44, v40\n\t"
 				"s_waitcnt lgkmcnt(0)\n\t"
 				"ds_write_b64 v40, v[50:51]\n\t"
 				"v_cndmask_b32 v45, v48, v50, vcc\n\t"                            // d == c: the cell just written
 				"v_cndmask_b32 v46, v49, v51, vcc\n\t"
 				"v_cmp_eq_u32 vcc, v44, v52\n\t"                                  // d is the head: one place before its cursor
+				"v_sub_u32 v55, v41, v57\n\t"                                     // source position -- and with the s_nop the two wait states between a VALU write of VCC and
+				"s_nop 0\n\t"                                                    // a VALU that reads it (gfx940 / gfx950; tools/check_isa_hazards.py, SGPR_VALU)
 				"v_subb_co_u32 v54, vcc, v45, 0, vcc\n\t"
 				"v_lshlrev_b32 v54, 2, v54\n\t"
 				"global_store_dword v54, v55, %5\n\t"
@@ -115,13 +116,14 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 				"ds_read_u8 v51, v45 offset:1\n\t"
 				"ds_read_b64 v[48:49], v40\n\t"
 				"v_add_u32 v50, 1, v45\n\t"
-				"v_sub_u32 v55, v45, v57\n\t"
 				"v_cmp_eq_u32 vcc, v40, v44\n\t"
 				"s_waitcnt lgkmcnt(0)\n\t"
 				"ds_write_b64 v44, v[50:51]\n\t"
 				"v_cndmask_b32 v41, v48, v50, vcc\n\t"
 				"v_cndmask_b32 v42, v49, v51, vcc\n\t"
 				"v_cmp_eq_u32 vcc, v40, v52\n\t"
+				"v_sub_u32 v55, v45, v57\n\t"
+				"s_nop 0\n\t"
 				"v_subb_co_u32 v54, vcc, v41, 0, vcc\n\t"
 				"v_lshlrev_b32 v54, 2, v54\n\t"
 				"global_store_dword v54, v55, %5\n\t"
