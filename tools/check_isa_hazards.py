@@ -162,7 +162,7 @@ class Insn:
             else:
                 self.defs = alluse(range(min(1, n)))
                 self.uses = alluse(range(1, n))
-            if self.kind == "vmem" and re.search(r"\blds\b", self.mods):
+            if self.kind == "vmem" and (re.search(r"\blds\b", self.mods) or "_lds_" in m):
                 self.uses_m0_lds = True; self.defs = set(); self.uses = alluse(range(n))
             if m.startswith("ds_") and "addtid" in m:
                 self.uses_m0_lds = True
@@ -203,18 +203,12 @@ def parse_kernels(asm_text):
         target = None
         mn = text.split(None, 1)[0]
         if mn.startswith(("s_branch", "s_cbranch")) and not mn.startswith("s_cbranch_g_fork") and not mn.startswith("s_cbranch_join"):
-            t = re.search(r"<([^>+]+)(?:\+0x([0-9a-fA-F]+))?>\s*$", tail)
-            arg = text.split(None, 1)[1].strip() if " " in text else ""
-            if t and t.group(1) in labels:
-                target = labels[t.group(1)] + (int(t.group(2), 16) if t.group(2) else 0)
-            elif arg in labels:
-                target = labels[arg]
-            else:
-                try:
-                    imm = int(arg, 0) & 0xffff
-                    target = addr + 4 + 4 * (imm - 0x10000 if imm & 0x8000 else imm)
-                except ValueError:
-                    target = None
+            # SOPP: the low 16 bits of the instruction word are the signed dword offset from the next instruction (the operand text may be a label objdump knows,
+            # a label it does not show -- two symbols at one address -- or the raw number)
+            w = re.match(r"([0-9A-Fa-f]{8})\b", tail)
+            if w:
+                imm = int(w.group(1), 16) & 0xffff
+                target = addr + 4 + 4 * (imm - 0x10000 if imm & 0x8000 else imm)
         kernels[cur].append(Insn(addr, text, target))
     return kernels
 
