@@ -1,7 +1,7 @@
 /* batch_driver.c -- what worker_for / mm_map_frag (map.c:272-392,427-467) look like once they are restructured around the batch API
  * (SURVEY.md section 8 f2): seed ALL reads of a mini-batch -> ONE call that does collect_seed_hits + mm_chain_dp for all of them on the
  * GPU (mm2c_seed_chain_batch_host: matches in, chains out) -> post-process ALL reads -> print.
- * Test infrastructure and demonstration: it links the reference's own objects (sketch, index, hit, esterr, format, ...) and the
+ * An example host of the product (INTEGRATION.md path C) and the caller of the end-to-end checks: it links the reference's own objects (sketch, index, hit, esterr, format, ...) and the
  * product library; the control flow around the one GPU call restates mm_map_frag for the `-x map-ont`, PAF-without-CIGAR case:
  *   before: hash (map.c:285-287), mm_sketch (collect_minimizers map.c:61-74, sdust_thres = 0), collect_matches (map.c:84-120)
  *   after : mm_gen_regs (map.c:345), chain_post (map.c:249-259), mm_est_err (map.c:360), mm_set_mapq (map.c:364), output (map.c:584-596)

@@ -45,7 +45,7 @@ def test_short_pair_with_gpu_chaining():
 
 
 # ---- the batched host: worker_for restructured as seed all -> ONE GPU call (matches in, chains out) -> post all;
-# oracle/ref_host/batch_driver.c over the reference's own objects and mm2c_seed_chain_batch_host
+# examples/batch_host/batch_driver.c over the reference's own objects and mm2c_seed_chain_batch_host
 BATCH_EXE = os.path.join(ROOT, "oracle", "_ref", "mm2_batchhost")
 
 
