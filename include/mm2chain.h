@@ -75,6 +75,13 @@ int  mm2c_warm_up(void);
  * are independent (chain.c:42-45), so there is no exchange between devices.  An ordinal may be listed more than once. */
 int  mm2c_init_devices(int n, const int *ordinals);
 int  mm2c_device_count(void);
+/* Host feed of several devices from one process: the worker thread of every device slot is persistent and pinned to the CPUs of the NUMA node its device hangs
+ * off ("pin_workers", default 1), so that the page-locked staging buffers it allocates and the copies it drives stay on that socket.  mm2c_numa_cpulist reads
+ * the mapping the way the workers do -- <sysfs_root>/bus/pci/devices/<pci bus id>/numa_node, then <sysfs_root>/devices/system/node/node<N>/cpulist -- and returns
+ * the node (cpulist text in buf) or -1 when there is no NUMA information; it touches no device (sysfs_root "/sys"; tests hand it a made-up tree).
+ * mm2c_slot_worker_node: the node slot's worker was pinned to, -1 = not started or not pinned. */
+int  mm2c_numa_cpulist(const char *sysfs_root, const char *pci_bus_id, char *buf, size_t len);
+int  mm2c_slot_worker_node(int slot);
 int  mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64_t *bounds /* n_parts + 1 */);
 void mm2c_shutdown(void);                     /* not while another thread is inside a compute entry */
 const char *mm2c_last_error(void);            /* thread-local message of the last failing call */

@@ -54,6 +54,7 @@ struct Global {
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: 16 waves per task (chain_dp_coop; 0 or 1: never; the width is fixed, the value only switches)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> pin_workers{1};                    // the worker thread of a device slot is pinned to the CPUs of the device's NUMA node (sysfs; 0: left to the scheduler)
 	std::atomic<int> decline_when_busy{1};              // mm2c_chain_task_host_pred / run_chaining_on_hw: the reference's busy protocol (chain_hardware.cpp:54-75); 0: always accept
 	std::atomic<int> direct_pass{1};                    // small staged passes: the two copies are kernels and the host polls a flag word (host_stage.hip; 0: copy commands + stream wait)
 	std::atomic<size_t> direct_max_anchors{1u << 18};   // ... passes of up to this many anchors

@@ -9,6 +9,9 @@
 #include "api_internal.h"
 #include "mm2chain_split.h"
 #include <string>
+#include <cctype>
+#include <pthread.h>
+#include <sched.h>
 
 namespace mm2c_api {
 
@@ -163,10 +166,9 @@ thread_local ThreadCtx *tl_ctx = nullptr;
 thread_local uint64_t tl_epoch = 0;
 thread_local int tl_slot = -1;                     // >= 0: this thread is the worker of a split batch and drives G.devices[tl_slot]
 
-// per device slot: the context the worker of a split batch uses (persistent, so that its arenas are allocated once), and the lock that
-// makes concurrent split batches take turns on it
+// per device slot: the context the worker of a split batch uses (persistent, so that its arenas are allocated once); concurrent split batches
+// take turns on it through the slot's one worker thread
 static ThreadCtx g_slot_ctx[64];
-static std::mutex g_slot_mu[64];
 static uint64_t g_slot_epoch[64];
 
 int n_devices() { return (int)G.devices.size(); }
@@ -174,34 +176,125 @@ bool in_split_worker() { return tl_slot >= 0; }
 int cur_device() { return tl_slot >= 0 && tl_slot < (int)G.devices.size() ? G.devices[(size_t)tl_slot] : G.device; }
 bool should_split(int64_t total_anchors) { return tl_slot < 0 && G.devices.size() > 1 && total_anchors >= G.multi_min_anchors; }
 
+// ---- the workers of split batches: ONE PERSISTENT THREAD PER DEVICE SLOT (round 5; rounds 2-4 started a std::thread per call), pinned to the CPUs of the NUMA node its
+// device hangs off -- the page-locked staging buffers of the slot's context are allocated by this thread (first touch on that node), and the copies it drives cross no
+// socket link.  The node comes from sysfs: /sys/bus/pci/devices/<pci bus id>/numa_node, its CPUs from /sys/devices/system/node/node<N>/cpulist, intersected with the
+// CPUs the process may use; no NUMA information (numa_node -1, a container without the files) leaves the thread where the scheduler puts it.
+struct SplitJob { std::function<int()> fn; int rc = 0; std::string err; bool done = false; };
+struct SlotWorker {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<SplitJob *> queue;           // jobs of concurrent split batches take turns (what g_slot_mu did for the per-call threads)
+	bool quit = false, started = false;
+	int pinned_node = -1;                    // NUMA node the thread was pinned to, -1: not pinned
+};
+static SlotWorker g_workers[64];
+
+static bool parse_cpulist(const char *txt, cpu_set_t *out)
+{
+	CPU_ZERO(out);
+	bool any = false;
+	for (const char *c = txt; *c && *c != '\n';) {
+		char *end = nullptr;
+		const long lo = strtol(c, &end, 10);
+		if (end == c || lo < 0) return false;
+		long hi = lo;
+		if (*end == '-') { const char *h = end + 1; hi = strtol(h, &end, 10); if (end == h || hi < lo) return false; }
+		for (long k = lo; k <= hi && k < CPU_SETSIZE; ++k) { CPU_SET((int)k, out); any = true; }
+		c = (*end == ',') ? end + 1 : end;
+		if (*end != ',' && *end != 0 && *end != '\n') return false;
+	}
+	return any;
+}
+
+static void pin_to_device_node(int device, SlotWorker &w)
+{
+	if (!G.pin_workers.load()) return;
+	char bus[64] = "";
+	if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return;
+	for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+	const char *root = getenv("MM2C_SYSFS_ROOT");
+	char list[4096];
+	const int node = mm2c_numa_cpulist(root && *root ? root : "/sys", bus, list, sizeof(list));
+	if (node < 0) return;
+	cpu_set_t want, have, both;
+	if (!parse_cpulist(list, &want) || sched_getaffinity(0, sizeof(have), &have) != 0) return;
+	CPU_AND(&both, &want, &have);
+	if (CPU_COUNT(&both) == 0) return;
+	if (pthread_setaffinity_np(pthread_self(), sizeof(both), &both) == 0) w.pinned_node = node;
+}
+
+static void slot_worker_main(int s)
+{
+	SlotWorker &w = g_workers[s];
+	tl_slot = s;
+	{
+		int dev = -1;
+		{ std::lock_guard<std::mutex> lk(G.mu); if (s < (int)G.devices.size()) dev = G.devices[(size_t)s]; }
+		if (dev >= 0) pin_to_device_node(dev, w);
+	}
+	std::unique_lock<std::mutex> lk(w.mu);
+	for (;;) {
+		w.cv.wait(lk, [&] { return w.quit || !w.queue.empty(); });
+		if (w.queue.empty()) { if (w.quit) return; continue; }
+		SplitJob *j = w.queue.front();
+		w.queue.erase(w.queue.begin());
+		lk.unlock();
+		try { j->rc = j->fn(); }
+		catch (...) { j->rc = fail(MM2C_E_ARG, "out of host memory in the worker of a split batch"); }
+		if (j->rc != 0) j->err = g_err;
+		lk.lock();
+		j->done = true;
+		w.cv.notify_all();
+	}
+}
+
+// ends the workers (mm2c_shutdown, before it takes the library's lock: a worker's job may need it)
+static void stop_slot_workers()
+{
+	for (SlotWorker &w : g_workers) {
+		{
+			std::lock_guard<std::mutex> lk(w.mu);
+			if (!w.started) continue;
+			w.quit = true;
+		}
+		w.cv.notify_all();
+		if (w.th.joinable()) w.th.join();
+		std::lock_guard<std::mutex> lk(w.mu);
+		w.started = false; w.quit = false; w.pinned_node = -1;
+	}
+}
+
 int run_split(int64_t n_tasks, const int64_t *h_offsets, const std::function<int(int, int64_t, int64_t)> &fn)
 {
 	const int nd = (int)std::min<size_t>(G.devices.size(), 64);
 	std::vector<int64_t> bounds((size_t)nd + 1);
 	if (mm2c_split_tasks(n_tasks, h_offsets, nd, bounds.data()) != 0) return MM2C_E_ARG;
-	std::vector<int> rcs((size_t)nd, 0);
-	std::vector<std::string> errs((size_t)nd);
-	std::vector<std::thread> th;
+	std::vector<SplitJob> jobs((size_t)nd);
+	std::vector<int> posted;
 	bool spawn_failed = false;
-	try {
-		th.reserve((size_t)nd);
-		for (int s = 0; s < nd; ++s) {
-			if (bounds[(size_t)s] == bounds[(size_t)s + 1]) continue;
-			th.emplace_back([&, s]() {
-				std::lock_guard<std::mutex> hold(g_slot_mu[s]);            // one split batch at a time per device context
-				tl_slot = s;
-				try { rcs[(size_t)s] = fn(s, bounds[(size_t)s], bounds[(size_t)s + 1]); }
-				catch (...) { rcs[(size_t)s] = fail(MM2C_E_ARG, "out of host memory in the worker of a split batch"); }
-				if (rcs[(size_t)s] != 0) errs[(size_t)s] = g_err;
-				tl_slot = -1;
-			});
+	for (int s = 0; s < nd && !spawn_failed; ++s) {
+		if (bounds[(size_t)s] == bounds[(size_t)s + 1]) continue;
+		SlotWorker &w = g_workers[s];
+		const int64_t k0 = bounds[(size_t)s], k1 = bounds[(size_t)s + 1];
+		jobs[(size_t)s].fn = [&fn, s, k0, k1]() { return fn(s, k0, k1); };
+		std::lock_guard<std::mutex> lk(w.mu);
+		if (!w.started) {
+			try { w.th = std::thread(slot_worker_main, s); w.started = true; }
+			catch (...) { spawn_failed = true; break; }          // std::system_error from thread creation: the jobs already posted are waited for below
 		}
-	} catch (...) {
-		spawn_failed = true;                                           // std::system_error from thread creation: the workers already started are joined below
+		w.queue.push_back(&jobs[(size_t)s]);
+		posted.push_back(s);
+		w.cv.notify_all();
 	}
-	for (auto &t : th) t.join();
-	if (spawn_failed) return fail(MM2C_E_ARG, "could not start the worker threads of a split batch");
-	for (int s = 0; s < nd; ++s) if (rcs[(size_t)s] != 0) return fail(rcs[(size_t)s], "device %d: %s", G.devices[(size_t)s], errs[(size_t)s].c_str());
+	for (int s : posted) {
+		SlotWorker &w = g_workers[s];
+		std::unique_lock<std::mutex> lk(w.mu);
+		w.cv.wait(lk, [&] { return jobs[(size_t)s].done; });
+	}
+	if (spawn_failed) return fail(MM2C_E_ARG, "could not start the worker thread of a device slot");
+	for (int s : posted) if (jobs[(size_t)s].rc != 0) return fail(jobs[(size_t)s].rc, "device %d: %s", G.devices[(size_t)s], jobs[(size_t)s].err.c_str());
 	return 0;
 }
 
@@ -211,7 +304,7 @@ int get_thread_ctx(ThreadCtx **out)
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!lib_ready()) return fail_not_ready();
 	if (tl_slot >= 0) {
-		// the worker of a split batch: the persistent context of its device slot (the caller holds the slot's lock)
+		// the worker of a split batch: the persistent context of its device slot (the slot's one worker thread)
 		ThreadCtx *c = &g_slot_ctx[tl_slot];
 		HIP_TRY(hipSetDevice(cur_device()));
 		if (!c->st || g_slot_epoch[tl_slot] != G.epoch) {
@@ -244,7 +337,7 @@ static uint64_t g_batch_epoch[N_BATCH_CTX] = { ~0ull, ~0ull };
 
 int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
 {
-	if (tl_slot >= 0) return get_thread_ctx(out);                   // the slot's lock is held by run_split
+	if (tl_slot >= 0) return get_thread_ctx(out);                   // this IS the slot's worker thread
 	int k = 0;
 	for (; k < N_BATCH_CTX; ++k) {
 		hold = std::unique_lock<std::mutex>(g_batch_mu[k], std::try_to_lock);
@@ -471,6 +564,36 @@ int mm2c_init(int device_ordinal)
 	return 0;
 }
 
+/* /sys/bus/pci/devices/<bus id>/numa_node and /sys/devices/system/node/node<N>/cpulist under `sysfs_root`: pure file reading, no device is touched */
+int mm2c_numa_cpulist(const char *sysfs_root, const char *pci_bus_id, char *buf, size_t len)
+{
+	if (!sysfs_root || !pci_bus_id || !buf || len == 0) return -1;
+	buf[0] = 0;
+	char path[512];
+	snprintf(path, sizeof(path), "%s/bus/pci/devices/%s/numa_node", sysfs_root, pci_bus_id);
+	FILE *fp = fopen(path, "r");
+	if (!fp) return -1;
+	int node = -1;
+	if (fscanf(fp, "%d", &node) != 1) node = -1;
+	fclose(fp);
+	if (node < 0) return -1;
+	snprintf(path, sizeof(path), "%s/devices/system/node/node%d/cpulist", sysfs_root, node);
+	fp = fopen(path, "r");
+	if (!fp) return -1;
+	const bool ok = fgets(buf, (int)len, fp) != nullptr;
+	fclose(fp);
+	if (!ok) { buf[0] = 0; return -1; }
+	for (char *c = buf; *c; ++c) if (*c == '\n') *c = 0;
+	return buf[0] ? node : -1;
+}
+
+int mm2c_slot_worker_node(int slot)
+{
+	if (slot < 0 || slot >= 64) return -1;
+	std::lock_guard<std::mutex> lk(g_workers[slot].mu);
+	return g_workers[slot].started ? g_workers[slot].pinned_node : -1;
+}
+
 int mm2c_init_async(int device_ordinal)
 {
 	async_init_join();                               // one at a time
@@ -565,6 +688,7 @@ int mm2c_split_tasks(int64_t n_tasks, const int64_t *offsets, int n_parts, int64
 void mm2c_shutdown(void)
 {
 	async_init_join();
+	stop_slot_workers();
 	std::lock_guard<std::mutex> bl0(g_batch_mu[0]);   // same order as get_batch_ctx: a batch context's lock (a caller holds at most one), then the library's
 	std::lock_guard<std::mutex> bl1(g_batch_mu[1]);
 	std::lock_guard<std::mutex> lk(G.mu);
@@ -707,6 +831,10 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "combiner_lanes") == 0) {
 		if (value < 1 || value > 4) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 4");
 		G.combiner_lanes = value;
+		return 0;
+	}
+	if (strcmp(key, "pin_workers") == 0) {
+		G.pin_workers = value != 0;
 		return 0;
 	}
 	if (strcmp(key, "decline_when_busy") == 0) {

@@ -46,6 +46,8 @@ C_SYMBOLS = {
     "mm2c_init_wait": (C.c_int, []),
     "mm2c_warm_up": (C.c_int, []),
     "mm2c_device_count": (C.c_int, []),
+    "mm2c_numa_cpulist": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "mm2c_slot_worker_node": (C.c_int, [C.c_int]),
     "mm2c_split_tasks": (C.c_int, [C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "mm2c_shutdown": (None, []),
     "mm2c_last_error": (C.c_char_p, []),

@@ -189,3 +189,34 @@ def test_per_read_calls_are_routed_to_the_least_loaded_device_slot():
             out[s] += n; served[s] += n
             inside.append((now + n, s, n))
         assert served.min() > 0.8 * served.mean(), (n_slots, served)
+
+
+def test_device_to_cpu_set_mapping_reads_the_numa_node_of_the_pci_device(tmp_path):
+    """Host feed of several GPUs from one process: the worker thread of a device slot is pinned to the CPUs of the NUMA node its device hangs off
+    (mm2c_numa_cpulist: <sysfs>/bus/pci/devices/<bus id>/numa_node -> <sysfs>/devices/system/node/node<N>/cpulist).  A made-up sysfs tree: two sockets,
+    a device on each, one device without NUMA information (-1, what a single-socket box or a container shows) and one that is not there."""
+    import ctypes as C
+    from mm2chain import _native as N
+    lib = N.load()
+    root = tmp_path / "sys"
+    for bus, node in (("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0000:f4:00.0", -1)):
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    for node, cpus in ((0, "0-47,96-143"), (1, "48-95,144-191")):
+        d = root / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+    def lookup(bus):
+        buf = C.create_string_buffer(256)
+        return lib.mm2c_numa_cpulist(str(root).encode(), bus.encode(), buf, 256), buf.value.decode()
+
+    assert lookup("0000:05:00.0") == (0, "0-47,96-143")
+    assert lookup("0000:85:00.0") == (1, "48-95,144-191")
+    assert lookup("0000:f4:00.0")[0] == -1                       # no NUMA information: the worker stays where the scheduler puts it
+    assert lookup("0000:99:00.0")[0] == -1                       # no such device
+    (root / "bus" / "pci" / "devices" / "0000:05:00.0" / "numa_node").write_text("7\n")
+    assert lookup("0000:05:00.0")[0] == -1                       # a node without a cpulist file
+    assert lib.mm2c_numa_cpulist(None, b"x", C.create_string_buffer(8), 8) == -1
+    assert lib.mm2c_slot_worker_node(0) == -1 and lib.mm2c_slot_worker_node(99) == -1     # no worker has been started in this process
