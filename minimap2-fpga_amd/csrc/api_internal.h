@@ -43,6 +43,7 @@ struct Global {
 	std::atomic<int> wide_pct{40};                      // plans: tasks with the 32-bit ring hold more than this % of the anchors -> no task takes the compact ring
 	std::atomic<int> split_streams{1};                  // plans: the instantiations a batch is split over (32-bit / compact ring) run side by side on two streams
 	std::atomic<int> compact_ring{1};                   // tile kernel: the compact x / q ring for the tasks whose q values allow it (0: never; the parity tests run both)
+	std::atomic<int> q24_ring{1};                       // tile kernel: the long ring of class-1 tasks in the q24 form (0: 32-bit slots; the parity tests run both)
 	std::atomic<int> force_tab{0};                      // tile kernel: gap cost from the LDS table also when gap_scale == 1 (tests; slower)
 	std::atomic<int> far_ring{1};                       // plans: tasks whose scans are expected to leave the short LDS ring run with a ring twice as long (0: never, 2: all)
 	std::atomic<int> epi_fused{1};                      // device epilogue: tasks that fit the LDS take the fused kernel (0: kernels A, B, C for every task)
@@ -157,8 +158,8 @@ inline void format_variant(const mm2c::LaunchInfo &I, char *buf, size_t len)
 {
 	if (I.tile && I.coop) snprintf(buf, len, "chain_dp_coop<W=%d,NX=%d,NF=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=0 cut=0 compact=0 coop=%d", I.coop, I.nx, I.nf, I.gs1,
 	                               I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.coop);
-	else if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
-	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16);
+	else if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d q24=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
+	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16, I.q24);
 	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);
 }
 void note_host_variant(const mm2c::LaunchInfo &I);   // mm2chain_host.cpp

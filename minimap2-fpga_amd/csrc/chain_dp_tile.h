@@ -84,13 +84,18 @@ __device__ __forceinline__ void write_lane2(int &v0, int &v1, int a0, int a1, in
 // task's q values span at most 65535 - max_dq no other difference can alias into that range mod 2^16 -- the prepass checks that per task
 // (chain_window_start: bit 1 of the task's class sends it to the 32-bit instantiation).  Half the LDS per ring anchor: the ring of 16 tiles
 // costs what the ring of 8 did.
-template <int NX, int NF, bool GEN, bool TAB, bool C16 = false>
+// RING 2 (q24 ring, round 5): the same 4-byte slot {x & 0xffff, q << 16} plus ONE MORE BYTE per ring anchor, bits 16-23 of q, in a byte ring of its own (QH): 5 bytes per
+// ring anchor instead of 8.  dr from the low halves as above; q of the ring anchor is put together from the slot's high half and its byte (one v_perm_b32) and subtracted
+// in 32 bits: exact for every task whose q values are below 2^24 (reads of up to 16.7 Mb: the prepass clears the long-ring class of any other task).  It is the form of
+// the LONG ring (ring-size class 1: tasks whose scans leave the short ring -- long noisy reads, all-vs-all overlaps): 16 tiles in 7 KB instead of 10 KB, 22 waves per CU
+// instead of 16, which is what bounded those streams (16 384 reads of 20 000 anchors were exactly four rounds of 16 x 256 wave slots).
+template <int NX, int NF, bool GEN, bool TAB, int RING = 0>
 struct Lds {
 	static constexpr int SN = 64 * NX;           // anchors with a stamp slot = anchors in the x / q ring
-	static constexpr int XS = C16 ? 4 : 8;       // bytes of an x / q slot
+	static constexpr int XS = RING ? 4 : 8;      // bytes of an x / q slot
 	static constexpr int TILE = 64 * XS;         // ... of a tile in the x / q ring
 	static constexpr int RB = SN * XS;           // ... of the x / q ring
-	static constexpr int XQ = 0, FP = RB, ST = FP + NF * 512, GAP = ST + SN,
+	static constexpr int XQ = 0, FP = RB, ST = FP + NF * 512, QH = ST + SN, GAP = QH + (RING == 2 ? SN : 0),
 	                     G = GAP + (TAB ? 1024 : 0), BYTES = G + (GEN ? NX * 64 : 0);
 	static constexpr int FMASK = NF * 512 - 1;   // slot of a tile in the f / p ring = its x / q slot mod NF (NF a power of two dividing NX)
 	static constexpr int SBITS = __builtin_ctz(SN);
@@ -240,6 +245,11 @@ __device__ __forceinline__ void ring_dr_dq(const AnchorCtx &X, const TileMem &M,
 	if (LY::XS == 8) {
 		const int2 xq = *(const int2 *)(M.lds + LY::XQ + addr);
 		dr1 = X.xi1 - xq.x; dq1 = X.qi1 - xq.y;
+	} else if (LY::QH != LY::GAP) {              // q24 ring: the low halves of x, all 24 bits of q (the byte ring is indexed by the anchor: slot = addr / 4)
+		const unsigned xq = *(const unsigned *)(M.lds + LY::XQ + addr);
+		const unsigned qh = *(const uint8_t *)(M.lds + LY::QH + (addr >> 2));
+		dr1 = (int)((unsigned)(X.xi1 + 1 - (int)(xq & 0xffffu)) & 0xffffu) - 1;
+		dq1 = X.qi1 - (int)((xq >> 16) | (qh << 16));
 	} else {
 		const unsigned xq = *(const unsigned *)(M.lds + LY::XQ + addr);
 		dr1 = (int)((unsigned)(X.xi1 + 1 - (int)(xq & 0xffffu)) & 0xffffu) - 1;
@@ -247,7 +257,7 @@ __device__ __forceinline__ void ring_dr_dq(const AnchorCtx &X, const TileMem &M,
 	}
 }
 
-template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool DR0, bool C16 = false>
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool DR0, int C16 = 0>
 __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X, const TileMem &M, int lane, int i0, int k, mask_t eq_run,
                                             int own_x, int own_q, int own_g, int own_f, int own_p, int addr0, Carry &c)
 {
@@ -384,6 +394,13 @@ __device__ __forceinline__ void scan_anchor(const KParams &P, const AnchorCtx &X
 #define MM2C_OWNFILTER_C MM2C_SUB16("%[dq]", "WORD_1", "%[tx]", "WORD_1") MM2C_SUB16("%[dr]", "WORD_0", "%[tx]", "WORD_0")
 #define MM2C_FARFILTER_C MM2C_SUB16("%[dq]", "WORD_1", "%[fq]", "WORD_0") MM2C_SUB16("%[dr]", "WORD_0", "%[fx]", "WORD_0")
 #define MM2C_RDXQ_C "v_readfirstlane_b32 %[xi1], %[tx1]\n\t"
+// q24 ring: the slot as in the compact form + the byte ring QH (bits 16-23 of q), addressed by the anchor's slot number = addr / 4.  x - 1 and q - 1 of the anchor travel
+// as two full scalars like in the 32-bit form (the own tile and tiles from memory are filtered exactly as there); only a RING tile differs: dr from the low halves,
+// q of the ring anchor = {slot.b2, slot.b3, byte, 0} by v_perm_b32 (selector 0x0c040302 in a VGPR: bytes 0-3 of the selector's source are S1's, 4-7 S0's, 0x0c = 0)
+#define MM2C_XQ1_Q "ds_read_b32 " MM2C_R_X ", %[addr1] offset:%[XQOFF]\n\t" "ds_read_u8 " MM2C_R_Q ", %[addr1q] offset:%[QHOFF]\n\t"
+#define MM2C_NEXT_XQ_Q "v_lshrrev_b32 %[u2], 2, %[addr]\n\t" "ds_read_b32 " MM2C_R_X ", %[addr] offset:%[XQOFF]\n\t" "ds_read_u8 " MM2C_R_Q ", %[u2] offset:%[QHOFF]\n\t" MM2C_BACK_C
+#define MM2C_RFILTER_Q "v_sub_u16_sdwa %[dr], %[xi1], " MM2C_R_X " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
+	"v_perm_b32 %[u1], " MM2C_R_Q ", " MM2C_R_X ", %[selq]\n\t" "v_sub_u32 %[dq], %[qi1], %[u1]\n\t"
 #define MM2C_OLDADDR_W "v_add_u32 %[vb], 0x400, %[addr]\n\t"
 #define MM2C_OLDADDR_C "v_add_lshl_u32 %[vb], %[addr], %[c200], 1\n\t"
 // x / q of the tile with first anchor fb from memory (anchors are 16 bytes: x low word at 0, q at 8), fb one tile back afterwards
@@ -691,7 +708,7 @@ __device__ unsigned long long g_label_hits[8 * 32];   // row = compact << 2 | ta
 template <int NX, int NF> \
 __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, float avg, const int32_t *f, const int32_t *p, int pbase, const uint4 *a, \
                                     int32_t *tg, int tx, int tx1, int tq, int tq1, int tspan, int tlo, int tlo0, int tw, int &own_f, int &own_p, \
-                                    int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v MM2C_LC_PARAM) \
+                                    int addr1, int addr2, int lomc, int ownst, int rl, int mdqbw_v, int bw_v, int sent_v, int addr1q, int selq_v MM2C_LC_PARAM) \
 { \
 	typedef Lds<NX, NF, false, TABV, C16V> LY; \
 	typedef Lds<NX, NF, false, true, C16V> LYT; \
@@ -972,6 +989,7 @@ __device__ __forceinline__ int NAME(int i0, int k_start, int cnt, int max_skip, 
 		: [i0] "s"(i0), [kstart] "s"(k_start), [cnt] "s"(cnt), [icnt1] "s"(i0 + cnt + 1), [i063] "s"(i0 + 63), [c200] "s"(0x200), [maxskip] "s"(max_skip), [avg] "s"(avg), [fptr] "s"(f), [pptr] "s"(p), [pbase] "s"(pbase), [aptr] "s"(a), [tptr] "s"(tg), \
 		  [tx] "v"(tx), [tx1] "v"(tx1), [tq] "v"(tq), [tq1] "v"(tq1), [tspan] "v"(tspan), [tlo] "v"(tlo), [tlo0] "v"(tlo0), [tw] "v"(tw), \
 		  [addr1] "v"(addr1), [addr2] "v"(addr2), [lomc] "v"(lomc), [ownst] "v"(ownst), [rl] "v"(rl), [mdqbw] "v"(mdqbw_v), [bw] "v"(bw_v), [sent] "v"(sent_v), \
+		  [addr1q] "v"(addr1q), [selq] "v"(selq_v), [QHOFF] "n"(LY::QH), \
 		  [XQOFF] "n"(LY::XQ), [FPOFF] "n"(LY::FP), [STOFF] "n"(LY::ST), [RBM1] "n"(LY::RB - 1), [FMASK] "n"(LY::FMASK), \
 		  [SNM1] "n"(LY::SN - 1), [RMASK] "n"(64 * NX - 1), [SBITS] "n"(LY::SBITS), [NFI] "n"(NF), [GAPOFF] "n"(LYT::GAP), [NXM1] "n"(NX - 1), [REACH] "n"(64 * NX) \
 		: "memory", "vcc", "scc", MM2C_R_X, MM2C_R_Q, MM2C_R_F, MM2C_R_P MM2C_FG_CLOB(CLOB)); \
@@ -994,15 +1012,21 @@ MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_c, false, true, MM2C_RING_C, MM2C_SCORE_CM
 MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_c, true, true, MM2C_RING_C, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LEAN)
 MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_far_c, false, true, MM2C_RING_C, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_FARS)
 MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_c, true, true, MM2C_RING_C, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_FARS)
+// ... and over the q24 ring (the long ring of class-1 tasks): everything but a ring tile's request and filter is the 32-bit form's or the compact form's
+#define MM2C_RING_Q MM2C_XQ1_Q, MM2C_NEXT_XQ_Q, MM2C_RFILTER_Q, MM2C_OLDADDR_C, MM2C_BACK_C, MM2C_OWNFILTER_W, MM2C_FARFILTER_W, MM2C_RDXQ_W, MM2C_FG_PLAIN, PF0
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_q, false, 2, MM2C_RING_Q, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_q, true, 2, MM2C_RING_Q, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_LEAN)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_cmp_far_q, false, 2, MM2C_RING_Q, MM2C_SCORE_CMP, MM2C_ADDF_CMP, MM2C_FARS)
+MM2C_SCAN_TILE_ASM_(scan_tile_asm_tab_far_q, true, 2, MM2C_RING_Q, MM2C_SCORE_TAB, MM2C_ADDF_TAB, MM2C_FARS)
 
 // ---------------------------------------------------------------- the kernel: one wave per task
 // LDS rings before the own tile: x / q of NX tiles, f / p of the NF nearest (NF a power of two dividing NX).
 // C16: the compact x / q ring (Lds<>), for the variants with the hand-written loop; the launcher picks it per task (cls bit 1 clear)
-template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, int C16 /* the ring form: 0 32-bit slots, 1 compact (16 + 16 bits), 2 q24 (16 + 24 bits) */>
 #ifdef MM2C_LABEL_COUNT
 #define MM2C_WAVES_PER_SIMD(C16V, BYTES) 1
 #else
-#define MM2C_WAVES_PER_SIMD(C16V, BYTES) ((C16V) && (BYTES) <= 6144 ? 7 : 1)
+#define MM2C_WAVES_PER_SIMD(C16V, BYTES) ((C16V) == 1 && (BYTES) <= 6144 ? 7 : (C16V) == 2 && (BYTES) <= 7424 ? 6 : 1)   /* q24 ring: 22 waves per CU by its LDS, at most 80 VGPRs then */
 #endif
 __global__ void __launch_bounds__(64, MM2C_WAVES_PER_SIMD(C16, (Lds<NX, NF, GEN, TAB, C16>::BYTES)))   // the compact ring leaves room for 7 waves per SIMD: at most 72 VGPRs then (it came out at 73)
 chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
@@ -1011,7 +1035,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
               int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live,
               const uint8_t *__restrict__ cls, int my_cls, int cls_mask)
 {
-	static_assert(!C16 || (SKIP && !GEN && (GS1 || TAB)), "the compact ring belongs to the variants of the hand-written loop");
+	static_assert(!C16 || (SKIP && !GEN && (GS1 || TAB)), "the compact and the q24 ring belong to the variants of the hand-written loop");
 	static_assert(NF >= 1 && NF < NX && (NF & (NF - 1)) == 0 && (NX & (NX - 1)) == 0, "rings of a power of two of tiles, addressed with masks");
 	static_assert(NF <= NX, "the f / p ring holds a prefix of the tiles of the x / q ring");
 	static_assert(64 * (NX - 1) < 1024, "bef (anchors of older tiles inside the ring window) travels in the 10-bit field bits 15-24 of the per-anchor word");
@@ -1063,7 +1087,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	X.avg = avg; X.rl = rl; X.seg_i = 0; X.far_mode = 0;
 	X.mdq1_v = P.max_dq - 1; X.bw_v = P.bw;
 	int sent_v = SENT, mdqbw_v = P.max_dq - 1 - P.bw;        // the score of a dead lane; the bound of the one-compare filter
-	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
+	int selq_v = 0x0c040302;                                 // q24 ring: the byte selector that puts {slot.b2, slot.b3, byte ring, 0} together (v_perm_b32)
+	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v), "+v"(selq_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
 	TileMem M;
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
 
@@ -1102,6 +1127,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int o = (idx & (SN - 1)) * LY::XS;   // the tile enters the x / q ring (its slot held the tile NX tiles back)
 			if (C16) *(int *)(lds + LY::XQ + o) = own_xq;
 			else *(int2 *)(lds + LY::XQ + o) = make_int2(own_x, own_q);
+			if (C16 == 2) *(uint8_t *)(lds + LY::QH + (idx & (SN - 1))) = (uint8_t)((unsigned)own_q >> 16);   // q24 ring: bits 16-23 of q (q < 2^24 for every task of this instantiation)
 			if (GEN) *(uint8_t *)(lds + LY::G + (o >> 3)) = (uint8_t)own_g;
 		}
 		if (FAR) {
@@ -1153,11 +1179,15 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int k = 0; k < cnt; ++k) {
 			if (ASM) {
 #define MM2C_CALL(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_x, tx1_l, own_q, tq1_l, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v MM2C_LC_ARG)
-				if (C16) {
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v, addr0 >> 2, selq_v MM2C_LC_ARG)
+				if (C16 == 2) {
+					// the q24 forms take what the 32-bit ones take (x, q, x - 1, q - 1 in full) + the byte ring's address of the tile before and the byte selector
+					if (FAR && tile_far) k = TAB ? MM2C_CALL(scan_tile_asm_tab_far_q, lo_l) : MM2C_CALL(scan_tile_asm_cmp_far_q, lo_l);
+					else k = TAB ? MM2C_CALL(scan_tile_asm_tab_q, lo_l) : MM2C_CALL(scan_tile_asm_cmp_q, lo_l);
+				} else if (C16) {
 					// the compact forms take packed words where the 32-bit ones take x and q: the tile's own {x, q} halves and the anchors' {x - 1, q - 1} halves
 #define MM2C_CALLC(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_xq, own_xq1, own_xq, own_xq1, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v MM2C_LC_ARG)
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v, 0, selq_v MM2C_LC_ARG)
 					if (FAR && tile_far) k = TAB ? MM2C_CALLC(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_far_c, lo_l);
 					else k = TAB ? MM2C_CALLC(scan_tile_asm_tab_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_c, lo_l);
 #undef MM2C_CALLC
@@ -1166,7 +1196,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #undef MM2C_CALL
 #ifdef MM2C_LABEL_COUNT
 				{	// this call's label hits go to the row of the instantiation that ran: compact << 2 | table << 1 | far
-					const int row = (C16 ? 4 : 0) | (TAB ? 2 : 0) | ((FAR && tile_far) ? 1 : 0);
+					const int row = (C16 == 1 ? 4 : 0) | (TAB ? 2 : 0) | ((FAR && tile_far) ? 1 : 0);   // (the q24 forms count into the 32-bit rows: the same labels, the same paths)
 					if (lane < 32 && lc_v != 0) atomicAdd(&g_label_hits[row * 32 + lane], (unsigned long long)(unsigned)lc_v);
 					lc_v = 0;
 				}

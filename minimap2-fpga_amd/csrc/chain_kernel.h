@@ -48,6 +48,7 @@ struct LaunchArgs {
 	int noskip_loop = 1;        // calls whose max-skip exit cannot fire (max_skip >= max_iter) run with max_skip = max_iter - 1 through the hand-written loop (0: the instantiations
 	                            // without the max-skip machinery, C++ loop; mm2c_tune("noskip_loop"), the parity tests run both)
 	int compact = 1;            // 0: never the compact x / q ring (mm2c_tune("compact_ring", 0); the parity tests run both)
+	int q24 = 1;                // 0: the long ring of class-1 tasks keeps its 32-bit slots (mm2c_tune("q24_ring", 0); the parity tests run both); 1: the q24 ring (16 + 24 bits, 7 KB)
 	unsigned long long *d_cls_stat = nullptr;   // CLS_STAT_SLOTS sets of four counters, zero on entry (chain_cls_settle), or nullptr
 	int wide_pct = 40;          // when the tasks that need the 32-bit x / q ring hold more than this share of the batch's anchors, every task takes it
 	int far_thr10 = 7;          // far_ring 1: a task takes the long ring when it expects more than far_thr10 / 10 tiles beyond the short ring per anchor
@@ -73,6 +74,7 @@ struct LaunchInfo {
 	int asm_loop;    // the hand-written per-tile loop (scan_tile_asm_*) runs, not scan_anchor<>
 	int classes;     // ring-size classes: class-1 tasks run the instantiation with 2 * nx tiles
 	int c16;         // tasks whose q values allow it run the instantiations with the compact x / q ring (per task: bit 1 of its class clear)
+	int q24;         // class-1 tasks (long ring) run the instantiation with the q24 ring (chain_dp_tile.h, Lds<> RING 2) instead of 32-bit slots
 	int cut;         // tasks are cut into pieces on the device first
 	int coop;        // waves per task of the cooperative kernel (chain_dp_coop), 0: one wave per task
 };

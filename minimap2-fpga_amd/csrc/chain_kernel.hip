@@ -249,7 +249,8 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
                    float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
                    unsigned long long *__restrict__ cls_stat /* CLS_STAT_SLOTS sets of [anchors of class-1 tasks, of all tasks, -, of tasks with the 32-bit ring], or nullptr */,
-                   unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */)
+                   unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */,
+                   int q24 /* the long ring is the q24 ring: a task with a q value of 2^24 or more stays out of class 1 (and carries bit 2) */)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
@@ -329,6 +330,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 		if ((lane & 63) == 0) { atomicMin(&s_qmin, q_min); atomicMax(&s_qmax, q_max); }
 		__syncthreads();
 		const int wide = (q_span_max == 0 || (unsigned)s_qmax - (unsigned)s_qmin > q_span_max) ? 2 : 0;
+		const int huge = (q24 && (s_qmin < 0 || s_qmax >= (1 << 24))) ? 4 : 0;    // (q as a signed word: a position of 2^31 or more shows as negative)
 		if (far_ring == 1) {
 			for (int o = 32; o > 0; o >>= 1) far_sum += __shfl_xor(far_sum, o);
 			if ((lane & 63) == 0 && far_sum) atomicAdd(&s_far, (unsigned long long)far_sum);
@@ -339,8 +341,8 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			// round 3 (faster ring path): dense 80.4 / 76.0, asm20 mixed 93.2 / 102.3, ava-ont mixed 113.5 / 91.6, headline 45.5 / 56.2 -> the bar sits between
 			// asm20 mixed (0.5) and dense (0.85)
 			if (lane == 0) {
-				const int c = (n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
-				cls_out[task] = (uint8_t)(c | wide);
+				const int c = (!huge && n >= 1024 && 10 * s_far > (unsigned long long)far_thr10 * (unsigned long long)n) ? 1 : 0;
+				cls_out[task] = (uint8_t)(c | wide | huge);
 				if (cls_stat) {
 					unsigned long long *cs = cls_stat + 4 * (task & (CLS_STAT_SLOTS - 1));   // 64 sets of counters: 65 536 tasks adding to ONE set cost the dense stream's prepass 0.6 ms
 					atomicAdd(&cs[1], (unsigned long long)n); if (c) atomicAdd(&cs[0], (unsigned long long)n);
@@ -348,7 +350,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 				}
 			}
 		} else if (lane == 0) {
-			cls_out[task] = (uint8_t)((far_ring == 2 ? 1 : 0) | wide);
+			cls_out[task] = (uint8_t)((far_ring == 2 && !huge ? 1 : 0) | wide | huge);
 			if (cls_stat) { unsigned long long *cs = cls_stat + 4 * (task & (CLS_STAT_SLOTS - 1)); atomicAdd(&cs[1], (unsigned long long)n); if (wide) atomicAdd(&cs[3], (unsigned long long)n); }
 		}
 	}
@@ -409,8 +411,8 @@ chain_cls_settle(int64_t n_tasks, uint8_t *__restrict__ cls, const unsigned long
 	int c = cls[t];
 	if (all_wide) c |= 2;
 	if (settle_ring) {
-		if (4 * far < all) c &= 2;                            // (bit 1, the 32-bit ring, is the task's own)
-		else if (4 * far > 3 * all) c |= 1;
+		if (4 * far < all) c &= 6;                            // (bit 1, the 32-bit ring, and bit 2, a q value beyond the q24 ring, are the task's own)
+		else if (4 * far > 3 * all && !(c & 4)) c |= 1;       // (a task the q24 long ring cannot hold stays in class 0, whatever the batch does)
 	}
 	cls[t] = (uint8_t)c;
 }
@@ -656,7 +658,7 @@ static hipError_t launch_one(const LaunchArgs &L, hipStream_t st, int only_flagg
 
 // ---- second-generation kernel (chain_dp_tile.h): x / q rings of NX tiles, f / p rings of NF tiles
 // with_cls: the kernel takes the tasks whose class (prepass) masked with cls_mask equals my_cls
-template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, bool C16>
+template <int NX, int NF, bool SKIP, bool GEN, bool GS1, bool FAR, bool TAB, int C16>
 static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStream_t st, int only_flagged, bool with_cls, int my_cls, int cls_mask)
 {
 	if (L.cut.max_pieces > 0) {
@@ -684,6 +686,13 @@ static unsigned compact_q_span(const LaunchArgs &L, bool asm_loop)
 	return 65535u - (unsigned)P.max_dq;
 }
 
+// the q24 ring (chain_dp_tile.h, Lds<> RING 2) is the form of the LONG ring (ring-size class 1): dr from the low halves of x needs max_dist_x < 2^16, q is exact for
+// tasks whose q values are below 2^24 -- the prepass keeps every other task out of class 1 (bit 2 of the class byte)
+static bool q24_ring(const LaunchArgs &L, bool skip, bool gen, bool gs1, bool tab)
+{
+	return L.q24 != 0 && use_classes(L, skip, gen) && (gs1 || tab) && L.P.max_dist_x >= 0 && L.P.max_dist_x <= 65535;
+}
+
 // The 32-bit rings: one ring size for every task, or -- ring-size classes, variants with the hand-written loop only -- the short ring for class 0 and a ring of
 // twice the length for class 1.  Where the compact x / q ring applies, the tasks whose q values allow it (bit 1 of the class clear) take the one instantiation
 // with it instead (a ring of MM2C_CNX tiles, whatever their ring-size class).  Every instantiation is launched over all tasks and returns at once for the tasks
@@ -701,13 +710,19 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 	hipError_t e = hipSuccess;
 	bool forked = false;                                   // the side stream has been made to wait for `st`: it is joined again whatever fails in between
 	if (fork) { e = hipEventRecord(L.ev_fork, st); if (e == hipSuccess) { e = hipStreamWaitEvent(sw, L.ev_fork, 0); forked = e == hipSuccess; } }
-	if (e == hipSuccess) e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, mask != 0, wide, mask);
+	if (e == hipSuccess) e = launch_tile_nx<MM2C_NX, MM2C_NF, SKIP, GEN, GS1, FAR, TAB, 0>(L, d_avg, sw, only_flagged, mask != 0, wide, mask);
 	if constexpr (!GEN && SKIP)
-		if (e == hipSuccess && classes) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, false>(L, d_avg, sw, only_flagged, true, wide | 1, mask); if (n_launches) ++*n_launches; }
+		if (e == hipSuccess && classes) {
+			bool done = false;
+			if constexpr (GS1 || TAB)
+				if (q24_ring(L, SKIP, GEN, GS1, TAB)) { e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, 2>(L, d_avg, sw, only_flagged, true, wide | 1, mask); done = true; }
+			if (!done) e = launch_tile_nx<2 * MM2C_NX, MM2C_NF1, SKIP, GEN, GS1, FAR, TAB, 0>(L, d_avg, sw, only_flagged, true, wide | 1, mask);
+			if (n_launches) ++*n_launches;
+		}
 	bool joined = false;
 	if (forked) joined = hipEventRecord(L.ev_join, sw) == hipSuccess;
 	if constexpr (SKIP && !GEN && (GS1 || TAB))
-		if (e == hipSuccess && c16) { e = launch_tile_nx<MM2C_CNX, MM2C_CNF, SKIP, GEN, GS1, FAR, TAB, true>(L, d_avg, st, only_flagged, true, 0, 2); if (n_launches) ++*n_launches; }
+		if (e == hipSuccess && c16) { e = launch_tile_nx<MM2C_CNX, MM2C_CNF, SKIP, GEN, GS1, FAR, TAB, 1>(L, d_avg, st, only_flagged, true, 0, 2); if (n_launches) ++*n_launches; }
 	if (forked) {
 		const hipError_t ej = joined ? hipStreamWaitEvent(st, L.ev_join, 0) : hipStreamSynchronize(sw);   // no event to wait on: the host waits for the side stream instead
 		if (e == hipSuccess) e = joined ? ej : hipErrorUnknown;
@@ -822,8 +837,9 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		info->asm_loop = t0 && skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // = ASM of chain_dp_tile
 		info->classes = t0 && use_classes(L, skip, want_gen);
 		info->c16 = t0 && compact_q_span(L, info->asm_loop != 0) != 0;
+		info->q24 = t0 && info->classes && q24_ring(L, skip, want_gen, gs1, tab);
 		info->cut = L.cut.max_pieces > 0;
-		if (coop) { info->nx = COOP_NX; info->nf = COOP_NF; info->r = 64 * (COOP_NX - 1); info->far_ = (int64_t)P.max_iter > 64 * (COOP_NX - 1); info->classes = 0; info->c16 = 0; }
+		if (coop) { info->nx = COOP_NX; info->nf = COOP_NF; info->r = 64 * (COOP_NX - 1); info->far_ = (int64_t)P.max_iter > 64 * (COOP_NX - 1); info->classes = 0; info->c16 = 0; info->q24 = 0; }
 	}
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
@@ -838,7 +854,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
 	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr,
-	                   coop ? 0u : c16_bound);                    // (the cooperative kernel has one ring form: no classes to find)
+	                   coop ? 0u : c16_bound,                     // (the cooperative kernel has one ring form: no classes to find)
+	                   (!coop && tile && q24_ring(L, skip, want_gen, gs1, tab)) ? 1 : 0);
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
 	if (e == hipSuccess && tile && !coop && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {

@@ -556,6 +556,8 @@ int mm2c_init(int device_ordinal)
 	if (dp) G.direct_pass = atoi(dp) != 0;
 	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
 	if (cw) G.coop_waves = std::max(0, atoi(cw));
+	const char *q4 = getenv("MM2C_Q24_RING");            // 0: the long ring of class-1 tasks keeps its 32-bit slots (experiments; the tests use mm2c_tune)
+	if (q4) G.q24_ring = atoi(q4) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
@@ -833,6 +835,10 @@ int mm2c_tune(const char *key, int value)
 		G.combiner_lanes = value;
 		return 0;
 	}
+	if (strcmp(key, "q24_ring") == 0) {
+		G.q24_ring = value != 0;
+		return 0;
+	}
 	if (strcmp(key, "pin_workers") == 0) {
 		G.pin_workers = value != 0;
 		return 0;
@@ -1016,7 +1022,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	L.d_cls = pl->d_cls; L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10;
 	L.d_cls_stat = (unsigned long long *)(pl->d_cls + (((size_t)std::max<int64_t>(pl->n_tasks, 1) + 15) & ~(size_t)15));
 	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32 * mm2c::CLS_STAT_SLOTS, st));
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.wide_pct = G.wide_pct; L.noskip_loop = G.noskip_loop;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.wide_pct = G.wide_pct; L.noskip_loop = G.noskip_loop;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
 	// a plan of few tasks: several waves per task instead of pieces cut on the device (chain_dp_coop.h; launch_chain_dp takes it for the variants of the hand-written loop)
 	L.coop_waves = (G.coop_plans && pl->n_tasks <= G.coop_max_tasks) ? G.coop_waves.load() : 0;   // (plans: only when asked for, mm2c_tune("coop_plans", 1))

@@ -174,7 +174,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.d_pbase = (const int32_t *)(c->d_in + o_pb) + s0; L.d_status = (int32_t *)(c->d_in + o_stat) + s0;
 			L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 			L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-			L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
+			L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.noskip_loop = G.noskip_loop;
 			if ((size_t)k < max_launches) {
 				L.d_cls = (uint8_t *)(c->d_in + o_cls) + s0; L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat + cstat_bytes * (size_t)k);
 				L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
@@ -210,7 +210,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_status = (int32_t *)(c->d_in + o_stat);
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
-	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
+	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.noskip_loop = G.noskip_loop;
 	L.d_cls = (uint8_t *)(c->d_in + o_cls); L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat);
 	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 	// a pass of few pieces (a lone call, a handful of combined calls) cannot fill the GPU with one wave per piece: several waves per piece (chain_dp_coop.h)
@@ -605,7 +605,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
 		L.d_f = d_f; L.d_p = d_p; L.d_t = d_p + tot; L.d_st = d_p + 2 * tot;
-		L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.noskip_loop = G.noskip_loop;
+		L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.noskip_loop = G.noskip_loop;
 		L.d_cls = (uint8_t *)(w.d_in + o_cls); L.d_cls_stat = (unsigned long long *)(w.d_in + o_clstat);       // the prepass classes, as plans have them
 		L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 		if (mp > 0 && mp <= (size_t)INT32_MAX) {

@@ -289,6 +289,43 @@ def test_ring_size_classes_in_one_batch(far_ring):
     assert_same(f, p, f_ref, p_ref, off, f"far_ring={far_ring}")
 
 
+@pytest.mark.parametrize("q24,gap_scale", [(1, 1.0), (0, 1.0), (1, 0.8)])
+def test_long_ring_in_the_q24_form(q24, gap_scale, knobs):
+    """Round 5: the long ring (ring-size class 1) keeps the low 16 bits of x and 24 bits of q per anchor -- a 4-byte slot and one byte of a ring of its own, 7 KB for
+    16 tiles instead of 10 -- exact for tasks whose q values are below 2^24; the prepass keeps any other task out of the class.  Every task in the long ring
+    (far_ring 2, compact ring off) under ava-ont scalars: q spread over 400 kb (differences that alias mod 2^16 in every tile), q moved up to just below 2^24 and
+    to 2^24 and beyond (those tasks must take the 32-bit short ring and still be right), multiples of 65536 added to random anchors, windows longer than the ring
+    (the `far` forms), equal-x runs, the gap-cost table (gap_scale 0.8 with bw <= 511)."""
+    from helpers import respan_q
+    from mm2chain import params, synth
+    P = params.make_params(max_dist_x=10000, max_dist_y=10000, bw=2000 if gap_scale == 1.0 else 500, gap_scale=gap_scale)
+    rng = np.random.default_rng(2424)
+    knobs("compact_ring", 0); knobs("far_ring", 2); knobs("q24_ring", q24); knobs("plan_cut_min", 15000)
+    tasks = []
+    for k, (prof, n, locus) in enumerate([("mixed", 6000, 400000), ("dense", 5000, 30000), ("colinear", 3000, 400000), ("mixed", 20000, 400000), ("dense", 2500, 9000),
+                                          ("mixed", 700, None), ("mixed", 1, None), ("mixed", 65, 4000)]):
+        base = synth.make_stream(prof, 1, n, seed=2400 + k, locus=locus)[1].numpy().view(np.uint64)
+        tasks.append(base)
+        if n <= 6000:
+            tasks += [respan_q(rng, base, 10000, mode) for mode in (2, 7)]                      # multiples of 65536 up to 2^24 added to random anchors
+            qmax = int((base[:, 1] & np.uint64(0xffffffff)).max()) if n else 0
+            for top in ((1 << 24) - 1, 1 << 24, (1 << 24) + 70000, (1 << 31) + 5):              # the largest q of the task: the last value the q24 ring holds, and beyond
+                t = base.copy()
+                t[:, 1] = (t[:, 1] & np.uint64(0xffffffff00000000)) | ((t[:, 1] & np.uint64(0xffffffff)) + np.uint64(top - qmax))
+                tasks.append(t)
+    # runs of equal x inside long windows
+    t = synth.make_stream("dense", 1, 4000, seed=2499, locus=20000)[1].numpy().view(np.uint64).copy()
+    t[1::3, 0] = t[0:-1:3, 0][: t[1::3, 0].shape[0]]
+    tasks.append(t[np.argsort(t[:, 0], kind="stable")])
+    a = np.concatenate(tasks)
+    off = np.concatenate(([0], np.cumsum([x.shape[0] for x in tasks]))).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    v = []
+    f, p = gpu_batch(P, off, a, variant=v)
+    assert_same(f, p, f_ref, p_ref, off, f"long ring, q24={q24}, gap_scale={gap_scale}: {v[0]}")
+    assert "loop=asm" in v[0] and "classes=1" in v[0] and f"q24={q24}" in v[0] and f"TAB={int(gap_scale != 1.0)}" in v[0], v
+
+
 @pytest.mark.parametrize("preset,compact,wide_pct", [("map-ont", 1, 100), ("map-ont", 1, 40), ("map-ont", 1, 0), ("map-ont", 0, 40), ("ava-ont", 1, 100), ("asm20", 1, 100)])
 def test_compact_ring_takes_the_tasks_whose_q_values_allow_it(preset, compact, wide_pct, knobs):
     """The tile kernel keeps the LOW 16 BITS of x and q of the ring anchors (4 bytes per anchor, Lds<..., C16>): exact while max_dist_x < 2^16 and the
@@ -927,12 +964,12 @@ def knobs():
     import mm2chain
     yield mm2chain.tune
     for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
-                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 0), ("coop_waves", 8), ("coop_max_tasks", 1024)):
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 0), ("coop_waves", 8), ("coop_max_tasks", 1024), ("q24_ring", 1)):
         mm2chain.tune(key, val)
 
 
 @pytest.mark.parametrize("route", ["asm", "asm-32-bit-ring", "asm-tab", "asm-tab-32-bit-ring", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024",
-                                   "coop", "coop-tab", "coop-v2-scalars"])
+                                   "coop", "coop-tab", "coop-v2-scalars", "asm-q24-ring", "asm-tab-q24-ring", "asm-long-32-bit-ring"])
 def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs):
     """The reference-produced vectors through the instantiations that carry the throughput.  With max_skip = 1023 and max_iter = 1024 the
     max-skip machinery of chain.c:226-233 is compiled in and runs (stamps, skip counter, the folds) but cannot fire: among at most 1024
@@ -942,8 +979,10 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
     ring-size classes off / forced, tasks cut into pieces on the device, and the first-generation kernel with each of its ring sizes.
     Which instantiation ran is asserted from mm2c_plan_last_variant."""
     from mm2chain import params
-    if route in ("asm-tab", "asm-tab-32-bit-ring"): knobs("force_tab", 1)
-    if route.endswith("32-bit-ring"): knobs("compact_ring", 0)
+    if route in ("asm-tab", "asm-tab-32-bit-ring", "asm-tab-q24-ring"): knobs("force_tab", 1)
+    if route.endswith("32-bit-ring") or route.endswith("q24-ring"): knobs("compact_ring", 0)
+    if route.endswith("q24-ring") or route == "asm-long-32-bit-ring": knobs("far_ring", 2)      # every task in the long ring: the q24 form (round 5), or its 32-bit form with the knob off
+    if route == "asm-long-32-bit-ring": knobs("q24_ring", 0)
     if route == "asm-short-ring-only": knobs("far_ring", 0)
     if route == "asm-long-ring-only": knobs("far_ring", 2)
     if route == "asm-device-cut": knobs("plan_cut_min", 1000); knobs("seg_min", 64)
@@ -966,7 +1005,8 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
         else:
             assert v[0].startswith("chain_dp_tile<") and "SKIP=1" in v[0] and "GEN=0" in v[0] and "FAR=1" in v[0] and "loop=asm" in v[0], v
             assert ("TAB=1" in v[0]) == (route.startswith("asm-tab") and bw <= 511), v
-            assert ("compact=1" in v[0]) == (not route.endswith("32-bit-ring")), v
+            assert ("compact=1" in v[0]) == (not route.endswith("32-bit-ring") and not route.endswith("q24-ring")), v
+            assert ("q24=1" in v[0]) == (route not in ("asm-short-ring-only", "asm-long-32-bit-ring")), v      # wherever there are ring-size classes the long ring is the q24 form
             assert ("classes=1" in v[0]) == (route != "asm-short-ring-only"), v
             assert ("cut=1" in v[0]) == (int(np.diff(off).max()) >= (1000 if route == "asm-device-cut" else 8192)), v   # plan_cut_min
         n += a.shape[0]

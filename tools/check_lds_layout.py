@@ -18,10 +18,11 @@ import msgpack
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def lds_bytes(nx, nf, gen, tab, c16):
-    """Lds<NX, NF, GEN, TAB, C16>::BYTES of csrc/chain_dp_tile.h: x / q ring (NX tiles of 64 slots of 8 bytes, 4 in the compact form), f / p ring
-    (NF tiles), one stamp byte per ring anchor, the gap-cost table, the segment-id ring"""
-    return nx * 64 * (4 if c16 else 8) + 2 * nf * 256 + 64 * nx + (1024 if tab else 0) + (64 * nx if gen else 0)
+def lds_bytes(nx, nf, gen, tab, ring):
+    """Lds<NX, NF, GEN, TAB, RING>::BYTES of csrc/chain_dp_tile.h: x / q ring (NX tiles of 64 slots of 8 bytes; 4 in the compact form, RING 1, and in the
+    q24 form, RING 2, which adds one byte per ring anchor for bits 16-23 of q), f / p ring (NF tiles), one stamp byte per ring anchor, the gap-cost
+    table, the segment-id ring"""
+    return nx * 64 * (4 if ring else 8) + 2 * nf * 256 + 64 * nx + (64 * nx if ring == 2 else 0) + (1024 if tab else 0) + (64 * nx if gen else 0)
 
 
 def elf_sections(elf):
@@ -78,8 +79,8 @@ def check(path, verbose=False):
     seen, bad = 0, []
     for triple, elf in code_objects(data):
         for name, lds in kernels_of(elf):
-            # _ZN4mm2c13chain_dp_tileILi8ELi2ELb1ELb0ELb1ELb1ELb0ELb1EEEv...: <NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>
-            m = re.match(r"_ZN4mm2c13chain_dp_tileILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])EEE", name)
+            # _ZN4mm2c13chain_dp_tileILi8ELi2ELb1ELb0ELb1ELb1ELb0ELi1EEEv...: <NX, NF, SKIP, GEN, GS1, FAR, TAB, RING>
+            m = re.match(r"_ZN4mm2c13chain_dp_tileILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])ELi([012])EEE", name)
             mc = re.match(r"_ZN4mm2c13chain_dp_coopILi(\d+)ELb([01])ELb([01])ELb([01])EEE", name)
             if mc:
                 # chain_dp_coop<W, GS1, FAR, TAB> (csrc/chain_dp_coop.h): the same hand-written loop over Lds<COOP_NX = 16, COOP_NF = 8, false, TAB, false>, with the
