@@ -31,6 +31,7 @@ for r in range(rounds):
                            gap_scale=float(rng.choice([1.0, 1.0, 0.5, 0.8, 2.25, 0.0])), is_cdna=int(rng.integers(0, 2)) if n_segs > 1 or rng.random() < .2 else 0,
                            n_segs=n_segs)
     mm2chain.tune("far_ring", int(rng.choice([1, 1, 2, 0])))   # ring-size classes of the tile kernel: chosen per task, all long, all short
+    mm2chain.tune("q24_ring", int(rng.choice([1, 1, 1, 0])))       # the long ring in its q24 form (round 5) or with 32-bit slots
     mm2chain.tune("compact_ring", int(rng.choice([1, 1, 1, 0])))   # the compact x / q ring for the tasks whose q values allow it, or never
     mm2chain.tune("wide_share_threshold", int(rng.choice([100, 100, 40, 0])))   # ... and the share of anchors in 32-bit-ring tasks from which every task takes that ring
     mm2chain.tune("split_streams", int(rng.choice([1, 2, 2, 0])))
@@ -52,13 +53,33 @@ for r in range(rounds):
                                      locus=int(rng.choice([3000, 20000, 100000])) if prof != "sparse" else None)
             tasks.append(a.numpy().view(np.uint64))
     tasks = [respan_q(rng, t, min(P.max_dist_x, P.max_dist_y), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7]))) for t in tasks]   # corners of the compact ring's bound on q
+    # the q24 ring's bound: now and then a task's q values are moved so that the largest sits at 2^24 - 1 or a little beyond (that task must stay out of the long ring)
+    for k in range(len(tasks)):
+        if tasks[k].shape[0] and rng.random() < 0.15:
+            t = tasks[k].copy()
+            q = (t[:, 1] & np.uint64(0xffffffff)).astype(np.int64)
+            q = q + ((1 << 24) - 1 + int(rng.integers(-2, 3)) - int(q.max()))
+            if q.min() >= 0:
+                t[:, 1] = (t[:, 1] & np.uint64(0xffffffff00000000)) | q.astype(np.uint64)
+                tasks[k] = t
     a = np.concatenate(tasks); off = np.concatenate(([0], np.cumsum([t.shape[0] for t in tasks]))).astype(np.int64)
     f_ref, p_ref = oracle_batch(P, off, a)
     f, p = gpu_batch(P, off, a)
+    # the host-buffer entries too (round 5: their small passes stage through kernels and a polled flag, csrc/host_stage.hip): the batch entry and a per-read call
+    if P.max_dist_x >= 0 and rng.random() < 0.5:
+        fh, ph = mm2chain.chain_batch_host(P, off, a)
+        if not (np.array_equal(fh, f_ref) and np.array_equal(ph, p_ref)):
+            bad += 1; print(f"MISMATCH (host batch entry) round {r} seed {seed0 + r}")
+        k = int(rng.integers(0, len(tasks)))
+        if tasks[k].shape[0]:
+            import oracle_binding as ob
+            ft, pt = mm2chain.chain_task(P, tasks[k], ob.avg_qspan(tasks[k]), tid=int(rng.integers(0, 16)))
+            if not (np.array_equal(ft, f_ref[off[k]:off[k + 1]]) and np.array_equal(pt, p_ref[off[k]:off[k + 1]])):
+                bad += 1; print(f"MISMATCH (per-read call) round {r} seed {seed0 + r} task {k}")
     n_anchor += a.shape[0]
     if not (np.array_equal(f, f_ref) and np.array_equal(p, p_ref)):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1); mm2chain.tune("coop_plans", 0)
+mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("q24_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1); mm2chain.tune("coop_plans", 0)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
