@@ -556,6 +556,8 @@ int mm2c_init(int device_ordinal)
 	if (dp) G.direct_pass = atoi(dp) != 0;
 	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
 	if (cw) G.coop_waves = std::max(0, atoi(cw));
+	const char *pc = getenv("MM2C_PIPE_COOP_CHUNKS");    // experiments: the last chunks of a pipelined host batch with several waves per piece
+	if (pc) G.pipe_coop_chunks = std::max(0, atoi(pc));
 	const char *q4 = getenv("MM2C_Q24_RING");            // 0: the long ring of class-1 tasks keeps its 32-bit slots (experiments; the tests use mm2c_tune)
 	if (q4) G.q24_ring = atoi(q4) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
@@ -833,6 +835,11 @@ int mm2c_tune(const char *key, int value)
 	if (strcmp(key, "combiner_lanes") == 0) {
 		if (value < 1 || value > 4) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 4");
 		G.combiner_lanes = value;
+		return 0;
+	}
+	if (strcmp(key, "pipe_coop_chunks") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "pipe_coop_chunks must be >= 0");
+		G.pipe_coop_chunks = value;
 		return 0;
 	}
 	if (strcmp(key, "q24_ring") == 0) {

@@ -179,6 +179,12 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 				L.d_cls = (uint8_t *)(c->d_in + o_cls) + s0; L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat + cstat_bytes * (size_t)k);
 				L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 			}
+			// the LAST chunks of the pipeline: nothing follows them that could hide the length of their longest task (one wave per task: 3.5 ms for 5 000 anchors on an
+			// otherwise empty GPU, the tail of the whole batch) -- chunks of few enough pieces take several waves per piece instead ("pipe_coop_chunks": how many, 0 = none)
+			if (k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) {
+				L.coop_waves = G.coop_waves.load();
+				for (int64_t q2 = s0; q2 < s1; ++q2) L.max_task_anchors = std::max<int64_t>(L.max_task_anchors, seg_off[(size_t)q2 + 1] - seg_off[(size_t)q2]);
+			}
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr, k == 0 ? &c->last_info : nullptr));
 			if (k == 0) note_host_variant(c->last_info);
 			// each compute stream downloads its own chunk (a separate download stream behind an event turned the copies into blit kernels that

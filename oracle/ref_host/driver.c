@@ -83,9 +83,9 @@ int main(int argc, char *argv[])
 	}
 	mm_idx_reader_close(r);
 #ifdef MM2_GPU_CHAINING
-	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu pieces, %llu passes, %llu launches, %.3f s inside the chaining calls (summed over threads), %.1f us per call\n",
+	{ mm2c_stats_t st; mm2c_get_stats(&st); fprintf(stderr, "[mm2_gpuhost] GPU chaining: %llu tasks, %llu anchors, %llu pieces, %llu passes, %llu launches, %.3f s inside the chaining calls (summed over threads), %.1f us per call, %.2f calls per pass\n",
 	                                                 (unsigned long long)st.tasks, (unsigned long long)st.anchors, (unsigned long long)st.segments, (unsigned long long)st.passes, (unsigned long long)st.launches,
-	                                                 st.host_call_ns * 1e-9, st.tasks ? st.host_call_ns * 1e-3 / st.tasks : 0.0); }
+	                                                 st.host_call_ns * 1e-9, st.tasks ? st.host_call_ns * 1e-3 / st.tasks : 0.0, st.passes ? (double)st.tasks / st.passes : 0.0); }
 	{
 		int s, nd = mm2c_device_count();
 		fprintf(stderr, "[mm2_gpuhost] per device slot:");
