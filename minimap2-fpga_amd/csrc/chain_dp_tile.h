@@ -1088,7 +1088,8 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	X.mdq1_v = P.max_dq - 1; X.bw_v = P.bw;
 	int sent_v = SENT, mdqbw_v = P.max_dq - 1 - P.bw;        // the score of a dead lane; the bound of the one-compare filter
 	int selq_v = 0x0c040302;                                 // q24 ring: the byte selector that puts {slot.b2, slot.b3, byte ring, 0} together (v_perm_b32)
-	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v), "+v"(selq_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
+	asm volatile("" : "+v"(X.mdq1_v), "+v"(X.bw_v), "+v"(sent_v), "+v"(mdqbw_v));   // per-lane copies: VALU operands from VGPRs issue at the full rate
+	if (C16 == 2) asm volatile("" : "+v"(selq_v));           // (a register of its own only in the instantiation that uses it)
 	TileMem M;
 	M.lds = lds; M.a = a; M.f = f; M.p = p; M.t = t; M.pbase = pbase;
 
@@ -1187,7 +1188,7 @@ chain_dp_tile(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				} else if (C16) {
 					// the compact forms take packed words where the 32-bit ones take x and q: the tile's own {x, q} halves and the anchors' {x - 1, q - 1} halves
 #define MM2C_CALLC(FN, LO0) FN<NX, NF>(i0, __builtin_amdgcn_readfirstlane(k), cnt, P.max_skip, avg, f, p, pbase, a, t, own_xq, own_xq1, own_xq, own_xq1, span_l, lo_c, \
-                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v, 0, selq_v MM2C_LC_ARG)
+                                 LO0, tw_l, own_f, own_p, addr0, addr0b, lomc_v, ownst, rl, mdqbw_v, X.bw_v, sent_v, 0, 0 MM2C_LC_ARG)
 					if (FAR && tile_far) k = TAB ? MM2C_CALLC(scan_tile_asm_tab_far_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_far_c, lo_l);
 					else k = TAB ? MM2C_CALLC(scan_tile_asm_tab_c, lo_l) : MM2C_CALLC(scan_tile_asm_cmp_c, lo_l);
 #undef MM2C_CALLC

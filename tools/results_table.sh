@@ -20,6 +20,8 @@ row "asm20" "mixed" --preset asm20 --profile mixed --anchors-per-read 7500
 row "asm20" "colinear" --preset asm20 --profile colinear --anchors-per-read 7500
 row "ava-ont" "mixed" --preset ava-ont --profile mixed --reads 16384 --anchors-per-read 20000
 row "ava-ont" "colinear" --preset ava-ont --profile colinear --reads 16384 --anchors-per-read 20000
+row "map-ont" "dense, ragged" --profile dense --ragged
+row "asm20" "mixed, ragged" --preset asm20 --profile mixed --ragged
 row "map-ont, general variant" "mixed" --profile mixed --general
 row "map-ont, gap_scale 0.8" "mixed" --profile mixed --gap-scale 0.8
 cat $OUT
