@@ -391,7 +391,7 @@ int grow_pinned(char **p, size_t *cap, size_t need, bool gpu_addressed)
 	ScopedNs timed(SS.alloc_ns); ++SS.n_alloc;
 	// gpu_addressed: kernels read / write the buffer themselves (host_stage.hip) and the host reads results behind a flag word, not behind a stream wait: mapped
 	// into the device's address space and coherent (fine-grained) by request rather than by the runtime's default
-	HIP_TRY(hipHostMalloc((void **)p, want, gpu_addressed ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void **)p, want, gpu_addressed ? (hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
 	*cap = want;
 	return 0;
 }

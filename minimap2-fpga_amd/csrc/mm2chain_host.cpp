@@ -2,6 +2,7 @@
 // read from many threads, chain_hardware.cpp:27-197) and the batched ones; passes over staged / pipelined copies, the combiner of small
 // concurrent calls, the whole-function batch entry.
 #include "api_internal.h"
+#include <sched.h>
 
 using namespace mm2c_api;
 
@@ -117,7 +118,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	const bool direct = staged && G.direct_pass.load() != 0 && (size_t)total <= G.direct_max_anchors;
 	unsigned *d_done = (unsigned *)(c->d_scratch + align16((size_t)total * 8));
 	if (direct && !c->h_flag) {
-		HIP_TRY(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocCoherent));
+		HIP_TRY(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
 		*c->h_flag = 0; c->seq = 0;
 	}
 	if (staged) {
@@ -240,6 +241,9 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			for (uint64_t spins = 0; ; ++spins) {
 				if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == c->seq) { seen = true; break; }
 				__builtin_ia32_pause();
+				// a host that runs more threads than it has cores (a path-B host may: a thread inside the call only waits) must not lose a core to this loop: after about the
+				// length of a short pass the thread offers its core between looks (returns at once when nobody else is runnable)
+				if (spins > 1024 && (spins & 31) == 31) sched_yield();
 				if ((spins & 1023) == 1023 && pt_now() - pt2 > 50000000ull) break;
 			}
 			if (!seen) {

@@ -227,3 +227,51 @@ def test_busy_protocol_of_the_reference_symbol():
         assert_same(f, p, f1, p1, None, "protocol off")
     finally:
         mm2chain.tune("decline_when_busy", 1)
+
+
+@pytest.mark.parametrize("direct", [1, 0])
+def test_small_host_passes_staged_by_kernels_or_by_copy_commands(direct):
+    """Round 5: a staged pass of the host-buffer entries reads its upload arena with a kernel straight from the page-locked staging buffer and writes f / p back the same way, the caller
+    polling a flag word (csrc/host_stage.hip; mm2c_tune("direct_pass", 1), the default) -- or, with the knob off, uses copy commands and a stream wait as before.  Both forms, sizes around
+    the 16-byte pieces the staging kernels move (odd anchor counts: f / p end on an 8-byte boundary), one anchor, the largest pass that still takes the kernels (2^18 anchors) and the first
+    that does not, many passes in a row on one context (the flag's sequence numbers), and concurrent callers."""
+    import threading
+    import mm2chain
+    from mm2chain import params, synth
+    P = params.map_ont()
+    mm2chain.tune("direct_pass", direct)
+    try:
+        for n_reads, n_per, seed in [(1, 1, 1), (1, 7, 2), (3, (1, 9), 3), (5, (200, 3000), 4), (40, (50, 700), 5)]:
+            off, a = _stream("mixed", n_reads, n_per, seed=700 + seed)
+            f_ref, p_ref = oracle_batch(P, off, a)
+            for _ in range(3):
+                f, p = mm2chain.chain_batch_host(P, off, a)
+                assert_same(f, p, f_ref, p_ref, off, f"direct_pass={direct}, {n_reads} reads")
+        for total in ((1 << 18), (1 << 18) + 1, (1 << 18) - 1):
+            off, a = _stream("mixed", 64, total // 64 + 1, seed=99)
+            a = a[:total]; off = np.minimum(off, total)
+            f_ref, p_ref = oracle_batch(P, off, a)
+            f, p = mm2chain.chain_batch_host(P, off, a)
+            assert_same(f, p, f_ref, p_ref, off, f"direct_pass={direct}, {total} anchors")
+        off, a = _stream("mixed", 48, (100, 2500), seed=808)
+        f_ref, p_ref = oracle_batch(P, off, a)
+        errs = []
+
+        def worker(tid):
+            try:
+                for rep in range(20):
+                    for k in range(tid, 48, 8):
+                        t = a[off[k]:off[k + 1]]
+                        f, p = mm2chain.chain_task(P, t, ob.avg_qspan(t), tid=tid)
+                        assert_same(f, p, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"read {k} thread {tid} rep {rep}")
+            except Exception as e:                                  # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:3]
+    finally:
+        mm2chain.tune("direct_pass", 1)

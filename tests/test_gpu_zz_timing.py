@@ -10,6 +10,16 @@ import oracle_binding as ob
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    import torch
+    import mm2chain
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    mm2chain.init()
+    yield
+    mm2chain.shutdown()
+
+
 def _timed(fn):
     t0 = time.perf_counter(); fn(); return (time.perf_counter() - t0) * 1e3
 
