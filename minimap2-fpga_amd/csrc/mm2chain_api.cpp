@@ -339,11 +339,17 @@ int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
 {
 	if (tl_slot >= 0) return get_thread_ctx(out);                   // this IS the slot's worker thread
 	int k = 0;
-	for (; k < N_BATCH_CTX; ++k) {
-		hold = std::unique_lock<std::mutex>(g_batch_mu[k], std::try_to_lock);
-		if (hold.owns_lock()) break;
+	for (;;) {
+		for (k = 0; k < N_BATCH_CTX; ++k) {
+			hold = std::unique_lock<std::mutex>(g_batch_mu[k], std::try_to_lock);
+			if (hold.owns_lock()) break;
+		}
+		if (k < N_BATCH_CTX) break;
+		// both busy: a third caller takes whichever set is given back first (it used to queue on the first one even when the second came free earlier); batch calls last
+		// milliseconds, so looking every 100 us costs nothing.  (Each set keeps its own grow-only arenas: once two pipeline threads have overlapped, the resident
+		// footprint of big mini-batches is doubled; mm2c_tune("trim", 0) gives the device cache back, the arenas go with mm2c_shutdown.)
+		std::this_thread::sleep_for(std::chrono::microseconds(100));
 	}
-	if (k == N_BATCH_CTX) { k = 0; hold = std::unique_lock<std::mutex>(g_batch_mu[0]); }   // both busy: wait for the first
 	async_init_join();
 	std::lock_guard<std::mutex> lk(G.mu);
 	if (!lib_ready()) return fail_not_ready();
