@@ -106,8 +106,8 @@ int  mm2c_device_identity(int *ordinal, char *pci_bus_id, size_t bus_len, char *
  * host batches of at least twice that size (default 20 Mi anchors); "multi_min_anchors" = smallest host batch that is split across the
  * devices of mm2c_init_devices (default 2^20); "trim" = give the cached device memory back to the runtime.  Results never depend on a knob.  "coop_waves" > 1 (default 16, the only width built: any value above 1 means 16) = a host-buffer pass of at most "coop_max_tasks" (1024) pieces gives every piece a workgroup of
  * 16 waves that share its LDS rings (csrc/chain_dp_coop.h: candidates counted and the older tiles reduced in parallel, the exact scan only where the early exit of chain.c:231 can fire;
- * env MM2C_COOP_WAVES), 0 = one wave per piece always; "coop_plans" 1 = plans of few tasks take that kernel too (tests); "combiner_lanes" 1..4 = passes the call combiner of the per-read
- * entries may have in flight at once (default 3; env MM2C_COMBINER_LANES), "combine_max_anchors" = a call of more anchors than this runs alone (env MM2C_COMBINE_MAX). */
+ * env MM2C_COOP_WAVES), 0 = one wave per piece always; "coop_plans" 1 = plans of few tasks take that kernel too (tests); "combiner_lanes" 1..16 = passes the call combiner of the per-read
+ * entries may have in flight at once on each device (default 4; env MM2C_COMBINER_LANES), "combine_max_anchors" = a call of more anchors than this runs alone (env MM2C_COMBINE_MAX). */
 int  mm2c_tune(const char *key, int value);
 
 /* HW/SW split model of the reference for this hardware (chain.c:80-81,101; constants in the form of chain_hardware.h:19-30 live in

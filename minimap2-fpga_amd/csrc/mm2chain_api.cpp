@@ -557,7 +557,7 @@ int mm2c_init(int device_ordinal)
 	const char *cm = getenv("MM2C_COMBINE_MAX");         // experiments: 0 = no call combiner
 	if (cm) G.combine_max_anchors = (size_t)std::max(0, atoi(cm));
 	const char *cl = getenv("MM2C_COMBINER_LANES");      // experiments: passes of the call combiner in flight
-	if (cl) G.combiner_lanes = std::max(1, std::min(4, atoi(cl)));
+	if (cl) G.combiner_lanes = std::max(1, std::min(16, atoi(cl)));
 	const char *dp = getenv("MM2C_DIRECT_PASS");         // 0: small per-read passes use copy commands and a stream wait instead of the staging kernels and the polled flag (experiments)
 	if (dp) G.direct_pass = atoi(dp) != 0;
 	const char *cw = getenv("MM2C_COOP_WAVES");          // 0: the host-buffer entries never use several waves per task (experiments; the tests use mm2c_tune)
@@ -839,7 +839,7 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	if (strcmp(key, "combiner_lanes") == 0) {
-		if (value < 1 || value > 4) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 4");
+		if (value < 1 || value > 16) return fail(MM2C_E_ARG, "combiner_lanes must be 1 .. 16");
 		G.combiner_lanes = value;
 		return 0;
 	}

@@ -299,7 +299,7 @@ void note_host_variant(const mm2c::LaunchInfo &I)
 // ONE COMBINER PER DEVICE SLOT (round 5): the reference keeps a queue, a lock, a buffer set and an expected end time per kernel and picks one per call
 // (chain_hardware.cpp:9-23,54-72); here every device of mm2c_init_devices / MM2C_DEVICES has its own combiner -- lanes, streams, arenas on that device -- and a
 // per-read call goes to the slot with the least work outstanding (anchors of the calls inside it), the scan starting at tid % n so that idle devices are taken in turn.
-constexpr int N_LANES = 4;
+constexpr int N_LANES = 16;
 constexpr int MAX_SLOTS = 64;
 struct Combiner {
 	std::mutex mu;
@@ -308,7 +308,8 @@ struct Combiner {
 	int leaders = 0;                    // passes being put together or in flight
 	bool busy[N_LANES] = {};
 	ThreadCtx ctx[N_LANES];             // stream + arenas of a pass in flight (exclusive to its leader)
-	uint64_t epoch[N_LANES] = { ~0ull, ~0ull, ~0ull, ~0ull };
+	uint64_t epoch[N_LANES];
+	Combiner() { for (uint64_t &e : epoch) e = ~0ull; }
 	std::atomic<int64_t> outstanding{0};            // anchors of the calls that have entered this slot and not yet left it (what the routing balances)
 	std::atomic<uint64_t> passes{0}, calls{0}, anchors{0};   // served since mm2c_init (mm2c_get_slot_stats)
 	std::atomic<double> pred_ms{0.0};               // path A: predicted device time (hw_time_pred) of the calls inside the slot (run_chaining_on_hw's decline, chain_hardware.cpp:54-75)
