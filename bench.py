@@ -92,6 +92,9 @@ def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0, device_li
     import tempfile
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     exes = {"cpu_chaining": "mm2_refhost", "batched_gpu": "mm2_batchhost", "per_read_gpu": "mm2_gpuhost"}
+    if os.path.exists(os.path.join(ref_dir, "mm2_splithost")):
+        # the caller's side of path A restated (oracle/ref_host/chain_shim_split.c): chain.c's HW/SW decision with the MI355X constants + the busy protocol, device branch = the product
+        exes["split_gpu_cpu"] = "mm2_splithost"
     for e in exes.values():
         if not os.path.exists(os.path.join(ref_dir, e)):
             return {"skipped": f"oracle/_ref/{e} is not there: the hosts are built from the reference's own objects by __graft_entry__.build() where /root/reference exists"}
@@ -134,6 +137,9 @@ def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0, device_li
             m = re.search(r"GPU chaining: (.*)", err)
             if m:
                 rec["per_read_calls"] = m.group(1).strip()
+            m = re.search(r"\[mm2_splithost\] (split model .*)", err)
+            if m:
+                rec["split"] = m.group(1).strip()
             m = re.search(r"per device slot: (.*)", err)
             if m:
                 rec["per_device_slot"] = m.group(1).strip()
@@ -144,7 +150,7 @@ def e2e_map_ont(threads, reads, genome_mb, mini_batch, budget_s=120.0, device_li
         done = [v for v in md5s.values() if v]
         out["paf_identical"] = bool(len(done) == len(exes) and len(set(done)) == 1)
         cpu = out["hosts"].get("cpu_chaining", {}).get("wall_s")
-        for k in ("batched_gpu", "per_read_gpu"):
+        for k in ("batched_gpu", "per_read_gpu", "split_gpu_cpu"):
             wk = out["hosts"].get(k, {}).get("wall_s")
             if cpu and wk and out["hosts"][k].get("rc") == 0:
                 out[k + "_vs_cpu_chaining"] = round(wk / cpu, 3)          # < 1: faster than the CPU-chaining host

@@ -64,3 +64,31 @@ def test_batched_host_prints_the_reference_paf():
     want = open(os.path.join(ROOT, "tests", "golden", "ref_host_paf_observed.txt")).read().split("# t-inv.fa q-inv.fa\n")[1].split("#")[0]
     assert lines == want
     assert _run_batch("t2.fa", "q2.fa") == ""
+
+
+# ---- the caller's side of path A restated (oracle/ref_host/chain_shim_split.c): chain.c's prediction pass, HW/SW decision and busy protocol (chain.c:53-164) over the product's
+# mm2c_chain_task_host_pred for the device branch and the oracle's loop for the software branch; both compute the V1 recurrence, so the PAF is the reference's either way
+SPLIT_EXE = os.path.join(ROOT, "oracle", "_ref", "mm2_splithost")
+
+
+@pytest.mark.parametrize("all_hw", [False, True])
+def test_host_that_keeps_the_references_hw_sw_split(all_hw):
+    if not os.path.exists(SPLIT_EXE):
+        pytest.skip("oracle/_ref/mm2_splithost not built (needs /root/reference at build time: __graft_entry__.build())")
+    env = dict(os.environ)
+    env.pop("MM2_SPLIT_ALL_HW", None)
+    if all_hw:
+        env["MM2_SPLIT_ALL_HW"] = "1"                                  # C_HW = -1e30: the model sends every read to the device
+    outs = {}
+    for ref, qry in (("MT-human.fa", "MT-orang.fa"), ("t-inv.fa", "q-inv.fa"), ("t2.fa", "q2.fa")):
+        r = subprocess.run([SPLIT_EXE, "-t", "3", os.path.join(DATA, ref), os.path.join(DATA, qry)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[qry] = r.stdout
+        if qry == "MT-orang.fa":
+            m = [l for l in r.stderr.splitlines() if l.startswith("[mm2_splithost] split model")]
+            assert m, r.stderr
+            on_device = int(m[0].split(": ")[1].split(" reads on the device")[0])
+            assert (on_device > 0) == all_hw, m[0]                     # a 346-anchor read: the MI355X model keeps it on the CPU thread; with C_HW = -1e30 it goes to the device
+    assert hashlib.md5(outs["MT-orang.fa"].encode()).hexdigest() == MT_MD5
+    want = open(os.path.join(ROOT, "tests", "golden", "ref_host_paf_observed.txt")).read().split("# t-inv.fa q-inv.fa\n")[1].split("#")[0]
+    assert outs["q-inv.fa"] == want and outs["q2.fa"] == ""

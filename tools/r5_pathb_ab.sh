@@ -14,5 +14,9 @@ for CFG in "$@"; do
     echo "path B [$CFG] run $RUN: wall $(python3 -c "print(round($T1-$T0,2))") s md5 $(md5sum < $W/b.paf | cut -c1-8)"; grep -E "staged passes|requests per|per call|per device slot|ERROR|rror" $W/b.err | cut -c1-400
   done
 done
+for RUN in 1 2; do
+  T0=$(date +%s.%N); timeout -k 10 300 $REPO/oracle/_ref/mm2_splithost -t 16 $W/syn.ref.fa $W/syn.reads.fa > $W/s.paf 2> $W/s.err; T1=$(date +%s.%N)
+  echo "split host (path A restated) run $RUN: wall $(python3 -c "print(round($T1-$T0,2))") s md5 $(md5sum < $W/s.paf | cut -c1-8)"; grep -E "split model|per call" $W/s.err | cut -c1-400
+done
 T0=$(date +%s.%N); timeout -k 10 300 $REPO/oracle/_ref/mm2_refhost -t 16 $W/syn.ref.fa $W/syn.reads.fa > $W/a.paf 2> $W/a.err; T1=$(date +%s.%N)
 echo "cpu host again: wall $(python3 -c "print(round($T1-$T0,2))") s"
