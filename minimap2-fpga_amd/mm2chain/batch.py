@@ -7,6 +7,7 @@ mm_chain_dp : the whole reference function (mmpriv.h:65), DP on the GPU, epilogu
 torch is plumbing only: device memory, streams.
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -21,7 +22,8 @@ def init(device=None):
     global _inited
     lib = N.load()
     if device is None:
-        device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        # (MM2C_DEVICES in the environment names the devices when the caller names none: mm2c_init(-1), as for a host whose init hook carries no ordinals)
+        device = torch.cuda.current_device() if torch.cuda.is_available() and not os.environ.get("MM2C_DEVICES") else -1
     N.check(lib.mm2c_init(int(device)), "mm2c_init")
     _inited = True
 

@@ -1200,7 +1200,8 @@ def test_big_host_batch_is_pipelined_in_chunks():
     finally:
         mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
     assert_same(f, p, f_ref, p_ref, off, "big pageable batch, pipelined")
-    assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()   # the chunks have the prepass classes
+    if mm2chain.device_count() == 1:                         # (with MM2C_DEVICES naming several slots the batch is split first and its parts are too small for the pipeline)
+        assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()   # the chunks have the prepass classes
     f, p = mm2chain.chain_batch_host(P, off, a)
     assert_same(f, p, f_ref, p_ref, off, "big pageable batch")
     pa = mm2chain.PinnedArray(a.shape, np.uint64); pf = mm2chain.PinnedArray(f.shape, np.int32); pp = mm2chain.PinnedArray(p.shape, np.int32)
