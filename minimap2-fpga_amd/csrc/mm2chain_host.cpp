@@ -686,6 +686,7 @@ int mm2c_chain_task_host_pred(const mm2c_params_t *par, int64_t n, const mm2c_an
                               int32_t *f, int32_t *p, int tid, float hw_time_pred, float sw_time_pred)
 {
 	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
+	if (!lib_ready()) return fail_not_ready();          // (before the protocol: "declined" must never be the answer of a library that has no device -- that would be a silent CPU route)
 	if (!G.decline_when_busy.load() || !(hw_time_pred > 0.f && sw_time_pred > 0.f)) return mm2c_chain_task_host(par, n, a, avg_qspan_scaled, f, p, tid);
 	const int slot = book_pred(tid, hw_time_pred, sw_time_pred);
 	if (slot < 0) { ++g_declined; return 1; }                                                                // chain_hardware.cpp:75

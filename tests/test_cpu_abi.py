@@ -83,6 +83,8 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
         mm2chain.chain_task(params.map_ont(), a, 0.15)
     with pytest.raises(mm2chain.Mm2cError):
         mm2chain.chain_task_pred(params.map_ont(), a, 0.15, 0, 0.1, 5.0)
+    with pytest.raises(mm2chain.Mm2cError):
+        mm2chain.chain_task_pred(params.map_ont(), a, 0.15, 0, 10.0, 5.0)      # predictions that WOULD decline on a busy device: no device is an error, not "declined"
     assert lib.mm2c_device_count() == 0
 
 
