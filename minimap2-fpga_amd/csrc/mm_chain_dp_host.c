@@ -81,11 +81,31 @@ static void msd128(mm2c_anchor_t *lo, mm2c_anchor_t *hi, int shift)
 
 static void sort128x(mm2c_anchor_t *a, size_t n) { if (n <= 64) ins128(a, a + n); else msd128(a, a + n, 56); }
 
-/* keys of u[] are distinct (low word = anchor index), so any correct ascending sort equals radix_sort_64 */
-static int cmp_u64(const void *x, const void *y)
+/* keys of u[] are distinct (low word = anchor index), so any correct ascending sort equals radix_sort_64 (chain.c:368).  A read has a few hundred chain ends: runs of
+ * 8 by insertion, then bottom-up merges through `buf` (room for n keys) -- a quarter of what qsort() with its compare callback took on the per-read path (round 5). */
+static void sort_u64(uint64_t *u, int64_t n, uint64_t *buf)
 {
-	uint64_t a = *(const uint64_t *)x, b = *(const uint64_t *)y;
-	return a < b ? -1 : a > b;
+	int64_t i, j, w;
+	uint64_t *src = u, *dst = buf;
+	for (i = 0; i < n; i += 8) {
+		const int64_t e = i + 8 < n ? i + 8 : n;
+		for (j = i + 1; j < e; ++j) {
+			const uint64_t key = u[j];
+			int64_t k = j;
+			while (k > i && u[k - 1] > key) { u[k] = u[k - 1]; --k; }
+			u[k] = key;
+		}
+	}
+	for (w = 8; w < n; w <<= 1) {
+		for (i = 0; i < n; i += 2 * w) {
+			int64_t a = i, am = i + w < n ? i + w : n, b = am, bm = i + 2 * w < n ? i + 2 * w : n, o = i;
+			while (a < am && b < bm) dst[o++] = src[b] < src[a] ? src[b++] : src[a++];
+			while (a < am) dst[o++] = src[a++];
+			while (b < bm) dst[o++] = src[b++];
+		}
+		{ uint64_t *t = src; src = dst; dst = t; }
+	}
+	if (src != u) memcpy(u, src, (size_t)n * 8);
 }
 
 /*
@@ -101,11 +121,13 @@ static int32_t chain_epilogue(int min_cnt, int min_sc, int64_t n, const mm2c_anc
 	int64_t i, j;
 	uint64_t *u = u_out;
 	*n_b_out = 0;
-	for (i = 0; i < n; ++i)                                                  /* chain.c:106-111 */
-		v[i] = (p[i] >= 0 && v[p[i]] > f[i]) ? v[p[i]] : f[i];
-	/* chain ends (chain.c:349-367) */
 	memset(t, 0, (size_t)n * 4);
-	for (i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
+	for (i = 0; i < n; ++i) {                                                /* chain.c:106-111, and in the same sweep the child marks of chain.c:350 */
+		const int32_t pi = p[i];
+		if (pi >= 0) { const int32_t vp = v[pi]; v[i] = vp > f[i] ? vp : f[i]; t[pi] = 1; }
+		else v[i] = f[i];
+	}
+	/* chain ends (chain.c:349-367) */
 	for (i = 0, n_u = 0; i < n; ++i) {
 		if (t[i] != 0 || v[i] < min_sc) continue;
 		for (j = i; j >= 0 && f[j] < v[j]; ) j = p[j];
@@ -113,7 +135,7 @@ static int32_t chain_epilogue(int min_cnt, int min_sc, int64_t n, const mm2c_anc
 		u[n_u++] = (uint64_t)f[j] << 32 | (uint64_t)j;
 	}
 	if (n_u == 0) return 0;
-	qsort(u, (size_t)n_u, 8, cmp_u64);                                       /* chain.c:368 */
+	sort_u64(u, n_u, (uint64_t *)tmp);                                       /* chain.c:368 (tmp: 2 n anchors of scratch, free until the emission below) */
 	for (i = 0; i < n_u >> 1; ++i) { uint64_t s = u[i]; u[i] = u[n_u - i - 1]; u[n_u - i - 1] = s; }
 	/* backtrack (chain.c:375-390); v[] is reused as the list of chained anchors */
 	memset(t, 0, (size_t)n * 4);
@@ -129,21 +151,19 @@ static int32_t chain_epilogue(int min_cnt, int min_sc, int64_t n, const mm2c_anc
 	}
 	n_u = k;
 	if (n_u == 0) return 0;
-	/* emit (chain.c:397-402) into tmp, then order chains by first x (chain.c:406-420) into b_out */
-	for (i = 0, k = 0; i < n_u; ++i) {
-		const int32_t k0 = k, ni = (int32_t)u[i];
-		for (j = 0; j < ni; ++j) tmp[k++] = a[v[k0 + (ni - j - 1)]];
-	}
+	/* order the chains by the x of their first anchor (chain.c:406-420), then emit each straight into its final place (chain.c:397-402): v[] holds the chained anchors of
+	 * chain i in backtrack order (last anchor first), so its first anchor is the last entry of its stretch.  (Round 5: one copy of the chained anchors instead of two.) */
 	{
 		mm2c_anchor_t *w = tmp + n;                                          /* second half of tmp: one sort record per chain */
-		uint64_t *u2 = (uint64_t *)vt;                                       /* v[] and t[] are dead from here on */
+		uint64_t *u2 = (uint64_t *)tmp;                                      /* first half: the chains' (score, count) in their final order */
 		int64_t n_b = 0;
-		for (i = 0, k = 0; i < n_u; ++i) { w[i].x = tmp[k].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
+		for (i = 0, k = 0; i < n_u; ++i) { const int32_t ni = (int32_t)u[i]; w[i].x = a[v[k + ni - 1]].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += ni; }
 		sort128x(w, (size_t)n_u);
 		for (i = 0; i < n_u; ++i) {
 			const int32_t src = (int32_t)w[i].y, cnt = (int32_t)u[src];
+			const int32_t *vi = v + (w[i].y >> 32) + cnt - 1;
 			u2[i] = u[src];
-			memcpy(&b_out[n_b], &tmp[w[i].y >> 32], (size_t)cnt * sizeof(mm2c_anchor_t));
+			for (j = 0; j < cnt; ++j) b_out[n_b + j] = a[vi[-j]];
 			n_b += cnt;
 		}
 		memcpy(u, u2, (size_t)n_u * 8);
