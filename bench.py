@@ -411,15 +411,22 @@ def main():
     per_rank_ns = sharding.gather_elapsed_ns(int(elapsed * 1e9))
     wall = max_ns / 1e9
 
-    # ---- correctness of what was just timed: a sample of tasks against the oracle (outside the timed region)
+    # ---- correctness of what was just timed (outside the timed region): f / p of EVERY distinct read of this rank's batch against the oracle -- the replicas behind
+    # them are copies of the same reads, compared with the first replica on the device.  The oracle pass doubles as the first pass of the cpu_baseline leg.
     import oracle_binding as ob
-    n_check = min(64, distinct_chk)
+    n_check = distinct_chk
     end = int(off1[n_check])
-    f_ref, p_ref, _ = ob.chain_batch(P, off1[: n_check + 1].numpy(), a1[:end].cpu().numpy().view(np.uint64), min(8, os.cpu_count() or 1))
+    chk_threads = max(1, host_cores() // max(world, 1))
+    a1_np = a1[:end].cpu().numpy().view(np.uint64)
+    f_ref, p_ref, chk_s = ob.chain_batch(P, off1[: n_check + 1].numpy(), a1_np, chk_threads)
     verified = bool(np.array_equal(d_f[:end].cpu().numpy(), f_ref) and np.array_equal(d_p[:end].cpu().numpy(), p_ref))
+    del f_ref, p_ref
     if not args.strong:
         last = total - int(off1[-1])                            # the last replica must equal the first one
-        verified = verified and bool(torch.equal(d_f[last:], d_f[: int(off1[-1])]))
+        verified = verified and bool(torch.equal(d_f[last:], d_f[: int(off1[-1])])) and bool(torch.equal(d_p[last:], d_p[: int(off1[-1])]))
+        if times > 2:                                            # ... and one in the middle
+            mid = (times // 2) * int(off1[-1])
+            verified = verified and bool(torch.equal(d_f[mid: mid + int(off1[-1])], d_f[: int(off1[-1])])) and bool(torch.equal(d_p[mid: mid + int(off1[-1])], d_p[: int(off1[-1])]))
     if world > 1:                                               # every rank's check counts
         vt = torch.tensor([1 if verified else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(vt, op=dist.ReduceOp.MIN)
@@ -443,7 +450,8 @@ def main():
                    "reads_per_gpu_per_step": n_tasks, "reads_whole_batch": (global_total and (args.reads if args.strong else n_tasks * world)), "distinct_reads": distinct, "anchors_per_read": args.anchors_per_read,
                    "profile": args.profile, "preset": args.preset, "ragged": bool(args.ragged),
                    "parallelism": f"read-sharded x{world}" + (" (one batch, tasks dealt longest-first)" if args.strong else "")},
-        "verified_vs_oracle": verified,
+        "verified_vs_oracle": verified, "verified_reads": n_check,
+        "verified_what": "f[] and p[] of the step just timed, every distinct read of the batch element-wise against the CPU oracle; the first, middle and last replica equal on the device",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.profile, total, args.preset), "kernel": "chain_dp_tile", "kernel_ms_avg": k_avg_ms,
                      "prepass_kernel_ms_avg": float(np.mean(prepass_ms)),
@@ -567,6 +575,14 @@ def main():
         cores = host_cores()
         off_np = off1.numpy()
         a_np = a1.cpu().numpy().view(np.uint64)
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.lower().startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         probe = min(distinct, 4 * cores)
         _, _, s = ob.chain_batch(P, off_np[: probe + 1], a_np[: int(off_np[probe])], cores)
         rate = int(off_np[probe]) / max(s, 1e-6)
@@ -578,7 +594,8 @@ def main():
             s_all += ob.chain_batch(P, off_np[: n_s + 1], a_np[: int(off_np[n_s])], cores)[2]
         n1 = int(max(1, min(n_s, 2_000_000 // args.anchors_per_read)))
         _, _, s_one = ob.chain_batch(P, off_np[: n1 + 1], a_np[: int(off_np[n1])], 1)
-        out["cpu_baseline"] = {"value": reps * int(off_np[n_s]) / s_all, "unit": "anchors/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": reps * int(off_np[n_s]) / s_all, "unit": "anchors/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+                               "verification_pass": {"reads": n_check, "anchors": end, "threads": chk_threads, "seconds": round(chk_s, 3)},
                                "sample": f"first {n_s} reads of the same batch x {reps} passes ({reps * int(off_np[n_s])} anchors), "
                                          f"{cores} threads, tasks round-robin, {s_all:.1f} s wall",
                                "value_1thread": int(off_np[n1]) / s_one}

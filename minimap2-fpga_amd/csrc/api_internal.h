@@ -31,7 +31,7 @@ struct ThreadCtx;
 
 struct Global {
 	std::mutex mu;
-	bool ready = false;
+	std::atomic<bool> ready{false};         // written under `mu`; read without it by lib_ready()
 	int device = -1;                        // primary device (= devices[0])
 	std::vector<int> devices;               // every device the library drives (mm2c_init_devices); entries may repeat
 	std::atomic<int64_t> multi_min_anchors{1 << 20};   // host batches of at least this many anchors are split across the devices
@@ -56,7 +56,10 @@ struct Global {
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: 16 waves per task (chain_dp_coop; 0 or 1: never; the width is fixed, the value only switches)
 	std::atomic<int64_t> coop_max_tasks{1024};
 	std::atomic<int> pin_workers{1};                    // the worker thread of a device slot is pinned to the CPUs of the device's NUMA node (sysfs; 0: left to the scheduler)
-	std::atomic<int> decline_when_busy{1};              // mm2c_chain_task_host_pred / run_chaining_on_hw: the reference's busy protocol (chain_hardware.cpp:54-75); 0: always accept
+	std::atomic<int> decline_when_busy{0};              // mm2c_chain_task_host_pred / run_chaining_on_hw: the reference's busy protocol (chain_hardware.cpp:54-75).  0 (default since round 6):
+	                                                    // always accept -- a chain.o built without PROCESS_ON_SW_IF_HW_BUSY ignores the answer 1 (chain.c:105,163-169) and would chain from
+	                                                    // uninitialised f / p, and no decline rule beat "never" on the measured run (profiles/r6_per_read.md); 1: decline by the measured
+	                                                    // service time of the slot; 2: round 5's rule (booked predictions).  MM2C_DECLINE_WHEN_BUSY / mm2c_tune opt in.
 	std::atomic<int> direct_pass{1};                    // small staged passes: the two copies are kernels and the host polls a flag word (host_stage.hip; 0: copy commands + stream wait)
 	std::atomic<size_t> direct_max_anchors{1u << 18};   // ... passes of up to this many anchors
 	std::atomic<int> pipe_coop_chunks{1};               // pipelined host batches: this many of the LAST chunks run with several waves per piece when they have few enough pieces

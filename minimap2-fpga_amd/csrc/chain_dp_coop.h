@@ -44,7 +44,16 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // LDS behind the rings: per anchor of the tile (= per lane) the best of the older tiles' candidates as one 64-bit key (score << 32 | index: the waves merge their
 // partial results with an LDS atomic maximum, equal scores -> the nearer index) and the candidate count (atomic add), then the own tile's table of pair scores
 // without f (64 x 64 ints, row = candidate, column = lane of the anchor)
-template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, BYTES = PAIRS + 2 * 64 * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
+// Round 6: the candidate rings.  A candidate's x, q, f used to reach the 64 lanes of a pair row through v_readlane into SGPRs (eight candidates fetched by lanes 0 .. 7
+// per unit): three scalar-side instructions per row plus the wait states behind them, in a kernel that the counters show to be bound by scalar-side issue (437 instructions
+// per anchor on the long ava-ont reads, 60 % of them scalar-side: v_readlane, compares into SGPR pairs, exec juggling, branches).  Now every anchor of the last COOP_NC tiles has
+// {x, q} (8 bytes) and f (4 bytes) in two rings of their own, written by wave 0 when the anchor's tile is final; a row reads them with ONE LDS address for all lanes (a
+// broadcast read: no bank conflict, no scalar side), f only when some lane passed the filters.  32 tiles cover everything phase A deals (NX - 1 + COOP_FAR_TILES = 19 tiles back), so
+// no candidate of phase A comes from memory any more.
+constexpr int COOP_NC = 32;
+template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, CXQ = PAIRS + 2 * 64 * 64 * 4,
+                                                       CF = CXQ + COOP_NC * 64 * 8, BYTES = CF + COOP_NC * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
+static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold every tile phase A deals");
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -205,40 +214,47 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// candidates j1 - 1 down to j0 of older tiles against the 64 anchors of the tile that starts at anchor t0 (per lane: x - 1, q - 1, span - 1, window start), in units
 		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (A predecessor with equal x, dr == 0, is rejected by pair_ok: dr - 1 is
 		// 0xffffffff and the unsigned |dr - dq| huge.)
-		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1, int ring_lo) {
+		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1, int lo_max) {
 			int best_l = SENT, jb_l = -1, cnt_l = 0;
 			unsigned long long m_l = 0;                          // d1: which anchors of the tile before t0 are candidates (bit c: anchor t0 - 1 - c)
-			const int n_units = (j1 - j0 + 7) >> 3;
+			const char *const cxq = lds + LY::BYTES + CL::CXQ, *const cf = lds + LY::BYTES + CL::CF;
+			constexpr int CM = 64 * COOP_NC - 1;
+			// one row: candidate j (x, q: one broadcast read) against the 64 anchors of the tile.  EDGE rows lie before the window start of some anchor of the tile
+			// (j < lo_max = the window start of its last anchor: st[] is monotone) and carry the per-lane window test; the others are inside every window.
+			auto row = [&](int j, int2 xq, bool edge) {
+				const int dr1 = tx1v - xq.x, dq1 = tq1v - xq.y;
+				const int dd = absdiff(dr1, dq1);
+				bool ok = pair_ok(dr1, dq1, dd);
+				if (edge) ok = ok && j >= lov;
+				if (BALLOT(ok) != 0) {                           // (most candidates are candidates of none of the 64 anchors: the score waits for one that is)
+					const int fj = *(const int *)(cf + ((j & CM) << 2));
+					int s0 = pair_score0(dr1, dq1, dd, sp1v);
+					asm volatile("" : "+v"(s0));                 // for every lane, whatever its filter said: nine instructions are cheaper than the exec mask around them
+					const int sc = ok ? s0 + fj : SENT;
+					cnt_l += ok ? 1 : 0;
+					if (d1) m_l |= ok ? 1ull << (t0 - 1 - j) : 0ull;
+					const bool take = sc > best_l;               // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
+					best_l = max(sc, best_l); jb_l = take ? j : jb_l;
+				}
+			};
+			// rows jhi - 1 - me, jhi - 1 - me - nw, ... down to jlo: the candidates of [jlo, jhi) dealt to the nw waves one by one, four reads in flight
+			auto rows = [&](int jhi, int jlo, bool edge) {
+				int j = jhi - 1 - me;
 #if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
-			if (0)
+				if (0)
 #endif
-			for (int u = me; u < n_units; u += nw) {
-				const int jl = j1 - 1 - 8 * u - (lane & 7);          // lanes 0 .. 7 fetch the unit's candidates
-				int xv = 0, qv = 0, fv = 0;
-				if (lane < 8 && jl >= j0) {
-					if (!FAR || jl >= ring_lo) { const int2 xq = *(const int2 *)(lds + LY::XQ + (jl & (SN - 1)) * 8); xv = xq.x; qv = xq.y; }
-					else { const uint4 aj = a[jl]; xv = (int)aj.x; qv = (int)aj.z; }   // a candidate of a tile that has left the ring: from memory (the anchors are read-only)
-					if ((t0 >> 6) - (jl >> 6) <= NF) fv = ((const int2 *)(lds + LY::FP + ((jl << 3) & LY::FMASK)))->x + FBIAS;
-					else fv = __hip_atomic_load(&f[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-				const int n_here = min(8, j1 - j0 - 8 * u);
-#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					if (t < n_here) {
-						const int j = j1 - 1 - 8 * u - t;
-						const int dr1 = tx1v - rdlane(xv, t), dq1 = tq1v - rdlane(qv, t);
-						const int dd = absdiff(dr1, dq1);
-						const bool ok = pair_ok(dr1, dq1, dd) && j >= lov;
-						if (BALLOT(ok) != 0) {                       // (most candidates are candidates of none of the 64 anchors: the score waits for one that is)
-							const int sc = ok ? pair_score0(dr1, dq1, dd, sp1v) + rdlane(fv, t) : SENT;
-							cnt_l += ok ? 1 : 0;
-							if (d1) m_l |= ok ? 1ull << (t0 - 1 - j) : 0ull;
-							const bool take = sc > best_l;         // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
-							best_l = take ? sc : best_l; jb_l = take ? j : jb_l;
-						}
+				{
+					for (; j - 3 * nw >= jlo; j -= 4 * nw) {
+						const int2 c0 = *(const int2 *)(cxq + ((j & CM) << 3)), c1 = *(const int2 *)(cxq + (((j - nw) & CM) << 3)),
+						           c2 = *(const int2 *)(cxq + (((j - 2 * nw) & CM) << 3)), c3 = *(const int2 *)(cxq + (((j - 3 * nw) & CM) << 3));
+						row(j, c0, edge); row(j - nw, c1, edge); row(j - 2 * nw, c2, edge); row(j - 3 * nw, c3, edge);
 					}
+					for (; j >= jlo; j -= nw) row(j, *(const int2 *)(cxq + ((j & CM) << 3)), edge);
 				}
-			}
+			};
+			const int jm = min(max(lo_max, j0), j1);
+			rows(j1, jm, false);
+			rows(jm, j0, true);
 			const int sb = ((t0 >> 6) & 1) * 64;
 			if (BALLOT(cnt_l != 0) != 0) {
 				if (best_l != SENT) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -273,7 +289,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// ---- the tile before this one (the part of it inside the first anchor's window and the ring); the first tile's table (the later ones are made a tile ahead, below)
 			const int lo_first = rdlane(lo_l, 63);
 			const int jmin = max(max(lo_first, stamp_lo), 0);
-			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l, true, stamp_lo);
+			if (i0 > 0) older_pairs(i0, max(jmin, i0 - 64), i0, wv, W, tx1_l, tq1_l, span1_l, lo_l, true, rdlane(lo_l, 64 - cnt));   // (lo_max: the window start of the tile's last anchor)
 			else own_table(0, cnt, wv, W, own_x, own_q, span1_l, lo_l);
 		}
 		int *const s_pair = s_pair2 + ((i0 >> 6) & 1) * (64 * 64);          // this tile's table
@@ -441,6 +457,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
 			const int o = (idx << 3) & LY::FMASK;
 			*(int2 *)(lds + LY::FP + o) = make_int2(own_f - FBIAS, own_p);
+			// ... and the candidate rings of phase A (the slots of the tile COOP_NC back: the last rows that read them were dealt a tile ago, for this very tile)
+			*(int2 *)(lds + LY::BYTES + CL::CXQ + ((idx & (64 * COOP_NC - 1)) << 3)) = make_int2(own_x, own_q);
+			*(int *)(lds + LY::BYTES + CL::CF + ((idx & (64 * COOP_NC - 1)) << 2)) = own_f;
 		} else if (i0 + 64 < n) {
 			// ---------------------------------------------------------------- phase A1 for the NEXT tile, beside wave 0's walk of this one: its anchors (already in `nxt`) against
 			// the candidates of the tiles before this one -- final f, and ring slots nobody writes during the walk (wave 0 puts this tile's f / p into the slot of the tile
@@ -452,7 +471,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// than the ring -- the 1 024 anchors of a V2 scan are up to 17 tiles -- keeps the short cut)
 			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1 + (FAR ? COOP_FAR_TILES : 0))), 0);
 			const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
-			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false, t0 - 64 * (NX - 1));   // (the slot of the tile NX back from the next one is the next tile's: wave 0 fills it when it gets there)
+			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false, rdlane(lo_n, 64 - min(64, n - t0)));   // (candidates from the candidate rings: their slots are final a tile before the walker reuses them)
 			own_table(t0, min(64, n - t0), wv - 1, W - 1, (int)nxt.x, (int)nxt.z, sp_n, lo_n);   // x and q only: nothing of it waits for this tile's walk
 		}
 #if MM2C_COOP_PROBE == 9

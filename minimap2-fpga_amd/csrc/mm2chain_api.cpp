@@ -36,12 +36,17 @@ static std::atomic<bool> g_async_pending{false};
 static char g_async_err[512] = "";
 static thread_local bool tl_is_init_thread = false;   // set on the initialisation thread itself: its own calls into the library must not wait for it
 
+static void async_join_locked()                    // g_async_mu held
+{
+	if (g_async_th && g_async_th->joinable()) g_async_th->join();
+	g_async_pending.store(false, std::memory_order_release);
+}
+
 void async_init_join()
 {
 	if (tl_is_init_thread || !g_async_pending.load(std::memory_order_acquire)) return;
 	std::lock_guard<std::mutex> lk(g_async_mu);
-	if (g_async_th && g_async_th->joinable()) g_async_th->join();
-	g_async_pending.store(false, std::memory_order_release);
+	async_join_locked();
 }
 
 int fail_not_ready()
@@ -189,7 +194,10 @@ struct SlotWorker {
 	bool quit = false, started = false;
 	int pinned_node = -1;                    // NUMA node the thread was pinned to, -1: not pinned
 };
-static SlotWorker g_workers[64];
+// Never destroyed (advisor, round 5): a host that leaves through exit() -- the drop-in's own exit(EXIT_FAILURE), minimap2's exit(1), a Python interpreter that ends
+// without mm2c_shutdown -- would otherwise run ~thread() on a joinable thread (std::terminate -> SIGABRT instead of its exit code) and destroy a mutex and a
+// condition variable that a worker still waits on.  g_async_th above is kept the same way.
+static SlotWorker *const g_workers = new SlotWorker[64];
 
 static bool parse_cpulist(const char *txt, cpu_set_t *out)
 {
@@ -253,7 +261,8 @@ static void slot_worker_main(int s)
 // ends the workers (mm2c_shutdown, before it takes the library's lock: a worker's job may need it)
 static void stop_slot_workers()
 {
-	for (SlotWorker &w : g_workers) {
+	for (int s = 0; s < 64; ++s) {
+		SlotWorker &w = g_workers[s];
 		{
 			std::lock_guard<std::mutex> lk(w.mu);
 			if (!w.started) continue;
@@ -302,7 +311,7 @@ int get_thread_ctx(ThreadCtx **out)
 {
 	async_init_join();
 	std::lock_guard<std::mutex> lk(G.mu);
-	if (!lib_ready()) return fail_not_ready();
+	if (!G.ready) return fail_not_ready();           // (the join is above, outside the lock: joining under G.mu would deadlock with an initialisation thread that wants it)
 	if (tl_slot >= 0) {
 		// the worker of a split batch: the persistent context of its device slot (the slot's one worker thread)
 		ThreadCtx *c = &g_slot_ctx[tl_slot];
@@ -352,7 +361,7 @@ int get_batch_ctx(ThreadCtx **out, std::unique_lock<std::mutex> &hold)
 	}
 	async_init_join();
 	std::lock_guard<std::mutex> lk(G.mu);
-	if (!lib_ready()) return fail_not_ready();
+	if (!G.ready) return fail_not_ready();
 	if (!g_batch_ctx[k].st || g_batch_epoch[k] != G.epoch) {
 		g_batch_ctx[k] = ThreadCtx();
 		DeviceScope on(G.device);
@@ -568,6 +577,8 @@ int mm2c_init(int device_ordinal)
 	if (q4) G.q24_ring = atoi(q4) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
+	const char *dwb = getenv("MM2C_DECLINE_WHEN_BUSY");  // a path-A host (no mm2c_tune call site) opts into the busy protocol here: 1 / 2 = the rules of mm2chain_host.cpp, book_pred
+	if (dwb) G.decline_when_busy = std::max(0, std::min(2, atoi(dwb)));
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
 	if (ft) G.far_thr10 = std::max(0, atoi(ft));
 	G.ready = true;
@@ -606,13 +617,14 @@ int mm2c_slot_worker_node(int slot)
 
 int mm2c_init_async(int device_ordinal)
 {
-	async_init_join();                               // one at a time
-	std::lock_guard<std::mutex> lk(g_async_mu);
+	if (tl_is_init_thread) return 0;
+	std::lock_guard<std::mutex> lk(g_async_mu);      // held across the join of the previous start AND the creation of the next: two concurrent callers take turns,
+	async_join_locked();                             // and the second one finds the first one's thread either finished (joined here) or the library ready
 	if (G.ready) return 0;
 	g_async_err[0] = 0;
 	try {
 		g_async_pending.store(true, std::memory_order_release);
-		delete g_async_th; g_async_th = nullptr;
+		delete g_async_th; g_async_th = nullptr;     // (joined above: never a joinable thread)
 		g_async_th = new std::thread([device_ordinal]() {
 			tl_is_init_thread = true;
 			int rc = mm2c_init(device_ordinal);
@@ -857,7 +869,8 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	if (strcmp(key, "decline_when_busy") == 0) {
-		G.decline_when_busy = value != 0;
+		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "decline_when_busy must be 0 (never decline), 1 (by the slot's measured service time) or 2 (round 5's rule: booked predictions)");
+		G.decline_when_busy = value;
 		return 0;
 	}
 	if (strcmp(key, "direct_pass") == 0) {

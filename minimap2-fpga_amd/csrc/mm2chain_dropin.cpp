@@ -14,12 +14,20 @@
 
 typedef struct { uint64_t x, y; } mm128_t;   // minimap.h:53
 
+// hardware_init's first argument: the host's BUFFER_N (main.c:367 passes chain_hardware.h:64's 5 187 500).  The reference sizes its device buffers by it and refuses a
+// longer call (chain_hardware.cpp:34-37); this library's buffers grow on demand, but a host that states a size keeps the reference's contract for it.  0: no size stated.
+static long g_buffer_n = 0;
+
 int run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_span, float avg_qspan,
                        mm128_t *a, int *f, int *p, unsigned char *num_subparts, long total_subparts, int tid,
                        float hw_time_pred, float sw_time_pred)
 {
 	(void)num_subparts; (void)total_subparts;   // FPGA pipeline bookkeeping (chain.c:62-78), not needed on a GPU
 	if (n == 0) return 0;                       // chain_hardware.cpp:30-32
+	if (g_buffer_n > 0 && n > g_buffer_n) {     // chain_hardware.cpp:34-37: same message, same exit code
+		fprintf(stderr, "Error: The size of the call (n = %ld) exceeds buffer size (%ld). Process this read on SW?\n", n, g_buffer_n);
+		exit(1);
+	}
 	mm2c_params_t par;
 	mm2c_params_fpga_v2(&par, max_dist_x, max_dist_y, bw, q_span);
 	// the busy protocol of chain_hardware.cpp:54-75 (PROCESS_ON_SW_IF_HW_BUSY): 1 = declined, the caller's own loop runs (chain.c:106,112-164).  The caller of THIS
@@ -35,7 +43,8 @@ int run_chaining_on_hw(long n, int max_dist_x, int max_dist_y, int bw, int q_spa
 
 bool hardware_init(long buf_size, char *binary_name)
 {
-	(void)buf_size; (void)binary_name;          // BUFFER_N / xclbin path (main.c:367): buffers grow on demand, no bitstream
+	(void)binary_name;                          // xclbin path (main.c:367): no bitstream
+	g_buffer_n = buf_size > 0 ? buf_size : 0;   // BUFFER_N: the longest call run_chaining_on_hw accepts (the buffers themselves grow on demand)
 	// MM2C_ASYNC_INIT=1: the runtime start-up (0.2 s) runs on a thread of its own while main.c:371-399 reads the index; a device that then turns out to be missing
 	// ends the process at the first chaining call (message + exit, as chain_hardware.cpp:208-235) instead of making this function return false
 	const char *as = getenv("MM2C_ASYNC_INIT");

@@ -22,6 +22,16 @@ struct HostReq {
 static std::atomic<uint64_t> g_pt_build{0}, g_pt_submit{0}, g_pt_wait{0}, g_pt_out{0}, g_pt_n{0};
 static std::atomic<uint64_t> g_pt_cls_ns[8], g_pt_cls_calls[8], g_pt_cls_reqs{0};   // ... and the callers' wall time by size of the call (< 256, < 512, ... anchors)
 static const bool g_pt_on = getenv("MM2C_PASS_TIMING") != nullptr;
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#elif defined(__aarch64__)
+	asm volatile("yield" ::: "memory");
+#else
+	asm volatile("" ::: "memory");
+#endif
+}
 static inline uint64_t pt_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Runs one GPU pass over the union of the requests (all with the same scalars).
@@ -240,7 +250,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			bool seen = false;
 			for (uint64_t spins = 0; ; ++spins) {
 				if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == c->seq) { seen = true; break; }
-				__builtin_ia32_pause();
+				cpu_relax();
 				// a host that runs more threads than it has cores (a path-B host may: a thread inside the call only waits) must not lose a core to this loop: after about the
 				// length of a short pass the thread offers its core between looks (returns at once when nobody else is runnable)
 				if (spins > 1024 && (spins & 31) == 31) sched_yield();
@@ -312,7 +322,9 @@ struct Combiner {
 	Combiner() { for (uint64_t &e : epoch) e = ~0ull; }
 	std::atomic<int64_t> outstanding{0};            // anchors of the calls that have entered this slot and not yet left it (what the routing balances)
 	std::atomic<uint64_t> passes{0}, calls{0}, anchors{0};   // served since mm2c_init (mm2c_get_slot_stats)
-	std::atomic<double> pred_ms{0.0};               // path A: predicted device time (hw_time_pred) of the calls inside the slot (run_chaining_on_hw's decline, chain_hardware.cpp:54-75)
+	std::atomic<double> pred_ms{0.0};               // path A, rule 2: predicted device time (hw_time_pred) of the calls inside the slot (run_chaining_on_hw's decline, chain_hardware.cpp:54-75)
+	std::atomic<int> inside{0};                     // path A, rule 1: calls that have entered the slot and not yet left it ...
+	std::atomic<float> svc_ms{0.f};                 // ... and what a pass of this slot has taken lately (EWMA of the wall time of run_requests, ms; 0: nothing measured yet)
 };
 static Combiner CB[MAX_SLOTS];
 std::atomic<uint64_t> g_declined{0};
@@ -333,26 +345,28 @@ void release_combiner()
 			if (CB[s].ctx[k].st && CB[s].ctx[k].device >= 0) (void)hipSetDevice(CB[s].ctx[k].device);
 			CB[s].ctx[k].release(); CB[s].epoch[k] = ~0ull;
 		}
-		CB[s].passes = 0; CB[s].calls = 0; CB[s].anchors = 0; CB[s].outstanding = 0; CB[s].pred_ms = 0.0;
+		CB[s].passes = 0; CB[s].calls = 0; CB[s].anchors = 0; CB[s].outstanding = 0; CB[s].pred_ms = 0.0; CB[s].inside = 0; CB[s].svc_ms = 0.f;
 	}
 	g_declined = 0;
 }
 
 // The slot a per-read call goes to: the one with the least anchors outstanding, idle slots in turn from tid % n (negative tid: as 0).  Adds the call's anchors to the
 // slot; the caller hands them back with leave_slot().
-int enter_slot(int tid, int64_t n_anchors)
+int enter_slot(int tid, int64_t n_anchors, int forced)
 {
 	const int nd = std::max(1, std::min(n_devices(), MAX_SLOTS));
 	int best = 0;
-	if (nd > 1) {
+	if (forced >= 0 && forced < nd) best = forced;             // path A: the slot that accepted the call under the busy protocol runs it (chain_hardware.cpp:58-72: the kernel that accepts is the kernel that runs)
+	else if (nd > 1) {
 		int64_t out[MAX_SLOTS];
 		for (int s = 0; s < nd; ++s) out[s] = CB[s].outstanding.load(std::memory_order_relaxed);
 		best = mm2c_route_slot(nd, out, tid);
 	}
 	CB[best].outstanding.fetch_add(n_anchors, std::memory_order_relaxed);
+	CB[best].inside.fetch_add(1, std::memory_order_relaxed);
 	return best;
 }
-void leave_slot(int slot, int64_t n_anchors) { CB[slot].outstanding.fetch_sub(n_anchors, std::memory_order_relaxed); }
+void leave_slot(int slot, int64_t n_anchors) { CB[slot].outstanding.fetch_sub(n_anchors, std::memory_order_relaxed); CB[slot].inside.fetch_sub(1, std::memory_order_relaxed); }
 
 int get_slot_stats(int slot, uint64_t *passes, uint64_t *calls, uint64_t *anchors)
 {
@@ -365,11 +379,24 @@ int get_slot_stats(int slot, uint64_t *passes, uint64_t *calls, uint64_t *anchor
 // otherwise tries the next kernel, returning 1 when none will do.  Here a device serves several calls at once (combined passes, `combiner_lanes` of them in
 // flight), so "the time until it is free" is the predicted device time of the calls inside the slot divided by the lanes.  Returns the slot that took the call (its
 // hw_time_pred is then booked until release_pred) or -1 = declined.  Predictions that are not positive (a caller that has no model) never decline.
+// Round 6, rule 1 ("decline_when_busy" 1): the measured thing instead of a sum of predictions -- per slot the number of calls inside it and an EWMA of what a pass of
+// that slot has taken lately; a call is turned away only when (calls ahead / lanes + 1) x that service time exceeds sw_time_pred, i.e. when waiting its turn and being
+// served is expected to last longer than the caller's own loop.  Rule 2 ("decline_when_busy" 2) is round 5's: booked hw_time_pred / lanes + hw_time_pred < sw_time_pred.
+// Returns the slot that took the call (under rule 2 its hw_time_pred is booked until release_pred) or -1 = declined.
 int book_pred(int tid, float hw_ms, float sw_ms)
 {
 	const int nd = std::max(1, std::min(n_devices(), MAX_SLOTS));
 	const int first = (int)((unsigned)(tid < 0 ? 0 : tid) % (unsigned)nd);
 	const double lanes = (double)std::max(1, std::min<int>(N_LANES, G.combiner_lanes));
+	if (G.decline_when_busy.load() == 1) {
+		for (int k = 0; k < nd; ++k) {
+			const int s = (first + k) % nd;
+			const double svc = (double)CB[s].svc_ms.load(std::memory_order_relaxed);
+			const double ahead = (double)std::max(0, CB[s].inside.load(std::memory_order_relaxed));
+			if (!(hw_ms > 0.f && sw_ms > 0.f) || svc <= 0.0 || (ahead / lanes + 1.0) * svc <= (double)sw_ms) return s;
+		}
+		return -1;
+	}
 	for (int k = 0; k < nd; ++k) {
 		const int s = (first + k) % nd;
 		double cur = CB[s].pred_ms.load(std::memory_order_relaxed);
@@ -386,6 +413,7 @@ int book_pred(int tid, float hw_ms, float sw_ms)
 }
 void release_pred(int slot, float hw_ms)
 {
+	if (G.decline_when_busy.load() != 2) return;              // (only rule 2 books predictions)
 	double cur = CB[slot].pred_ms.load(std::memory_order_relaxed);
 	while (!CB[slot].pred_ms.compare_exchange_weak(cur, std::max(0.0, cur - (double)hw_ms), std::memory_order_relaxed)) {}
 }
@@ -433,7 +461,7 @@ int submit_combined(HostReq *me, int slot)
 		async_init_join();
 		{
 			std::lock_guard<std::mutex> gl(G.mu);
-			if (!lib_ready()) rc = fail_not_ready();
+			if (!G.ready) rc = fail_not_ready();                      // (joined above, outside the lock)
 			else if (slot >= (int)G.devices.size()) rc = fail(MM2C_E_ARG, "device slot %d of %d", slot, (int)G.devices.size());
 			else if (cb.epoch[lane_k] != G.epoch) {                   // first pass after (re)initialisation: fresh stream and arenas ON THE SLOT'S DEVICE
 				cb.ctx[lane_k] = ThreadCtx();
@@ -444,7 +472,14 @@ int submit_combined(HostReq *me, int slot)
 				else cb.epoch[lane_k] = G.epoch;
 			}
 		}
-		if (rc == 0) rc = run_requests(&cb.ctx[lane_k], batch.data(), (int)batch.size());
+		if (rc == 0) {
+			const uint64_t t_pass = pt_now();
+			rc = run_requests(&cb.ctx[lane_k], batch.data(), (int)batch.size());
+			if (rc == 0) {                                            // what a pass of this slot takes, for the busy protocol (racy read-modify-write: an estimate)
+				const float ms = (float)((pt_now() - t_pass) * 1e-6), old = cb.svc_ms.load(std::memory_order_relaxed);
+				cb.svc_ms.store(old > 0.f ? 0.875f * old + 0.125f * ms : ms, std::memory_order_relaxed);
+			}
+		}
 	} catch (...) {
 		rc = fail(MM2C_E_ARG, "out of host memory in a combined chaining pass");
 	}
@@ -468,7 +503,7 @@ int submit_combined(HostReq *me, int slot)
 extern "C" {
 
 static int chain_batch_host_tid(const mm2c_params_t *par, int64_t n_tasks, const int64_t *h_offsets, const mm2c_anchor_t *h_anchors,
-                                const float *h_avg_qspan, int32_t *h_f, int32_t *h_p, int tid)
+                                const float *h_avg_qspan, int32_t *h_f, int32_t *h_p, int tid, int forced_slot = -1)
 {
 	int rc;
 	const auto t_begin = std::chrono::steady_clock::now();
@@ -489,7 +524,7 @@ static int chain_batch_host_tid(const mm2c_params_t *par, int64_t n_tasks, const
 	// context of its own device slot, however small its range is
 	if (!in_split_worker() && (size_t)total <= G.combine_max_anchors) {
 		// the device slot with the least work inside it takes the call (one combiner per device)
-		const int slot = enter_slot(tid, total);
+		const int slot = enter_slot(tid, total, forced_slot);
 		rc = submit_combined(&req, slot);
 		leave_slot(slot, total);
 		if (rc != 0 && req.err[0]) fail(rc, "%s", req.err);
@@ -687,10 +722,12 @@ int mm2c_chain_task_host_pred(const mm2c_params_t *par, int64_t n, const mm2c_an
 {
 	if (n == 0) return 0;                                                                                   // chain_hardware.cpp:30-32
 	if (!lib_ready()) return fail_not_ready();          // (before the protocol: "declined" must never be the answer of a library that has no device -- that would be a silent CPU route)
+	if (n < 0) return fail(MM2C_E_ARG, "n < 0");
 	if (!G.decline_when_busy.load() || !(hw_time_pred > 0.f && sw_time_pred > 0.f)) return mm2c_chain_task_host(par, n, a, avg_qspan_scaled, f, p, tid);
 	const int slot = book_pred(tid, hw_time_pred, sw_time_pred);
 	if (slot < 0) { ++g_declined; return 1; }                                                                // chain_hardware.cpp:75
-	const int rc = mm2c_chain_task_host(par, n, a, avg_qspan_scaled, f, p, tid);
+	const int64_t off[2] = { 0, n };
+	const int rc = chain_batch_host_tid(par, 1, off, a, &avg_qspan_scaled, f, p, tid, slot);                // the slot that accepted the call is the slot that runs it
 	release_pred(slot, hw_time_pred);
 	return rc;
 }

@@ -68,7 +68,9 @@ def make_stream(profile, n_reads, n_per_read=5000, seed=1, q_span=15, device="cp
         span_ref = {"mixed": 100000, "dense": 45000, "colinear": 100000}[profile] if locus is None else locus
         strand = _uniform(rd, seed, 1, 0, 2)[task]
         rid = _uniform(rd, seed, 2, 0, 24)[task]
-        start = _uniform(rd, seed, 3, 1 << 20, (1 << 31) - (1 << 22))[task]
+        # (a locus longer than ~4 Mb -- the long-read streams of tools/long_reads.py -- must still end below 2^31: the bound moves down for those only)
+        start_hi = (1 << 31) - (1 << 22) if span_ref + 40000 < (1 << 22) else (1 << 31) - span_ref - (1 << 20)
+        start = _uniform(rd, seed, 3, 1 << 20, start_hi)[task]
         kind = _uniform(g, seed, 5, 0, 100)
         if profile == "mixed":
             is_chain, is_rep = kind < 35, (kind >= 35) & (kind < 50)

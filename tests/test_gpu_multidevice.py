@@ -197,9 +197,12 @@ def test_per_read_calls_are_served_by_every_device_context(n_ctx):
 
 
 def test_busy_protocol_of_the_reference_symbol():
-    """chain_hardware.cpp:54-75 (PROCESS_ON_SW_IF_HW_BUSY): run_chaining_on_hw returns 1 = declined when waiting for the device plus hw_time_pred would take longer
-    than sw_time_pred; the caller's own loop (chain.c:106,112-164) then runs.  Here: a prediction pair the idle device cannot meet is declined with f / p untouched,
-    one it can meet is computed (== the oracle), predictions that are not positive never decline, and the knob turns the protocol off."""
+    """chain_hardware.cpp:54-75 (PROCESS_ON_SW_IF_HW_BUSY): run_chaining_on_hw returns 1 = declined when waiting for the device would take longer than sw_time_pred; the
+    caller's own loop (chain.c:106,112-164) then runs.  Round 6: OFF by default (a chain.o built without that flag ignores the 1 and would chain from uninitialised f / p,
+    chain.c:105,163-169) -- a host opts in with MM2C_DECLINE_WHEN_BUSY / mm2c_tune("decline_when_busy", 1 | 2).  Rule 2 (round 5's: booked predictions): a prediction pair
+    the idle device cannot meet is declined with f / p untouched, one it can meet is computed (== the oracle), predictions that are not positive never decline.  Rule 1
+    (measured: calls inside the slot and the service time of its passes): a caller whose own loop would take a microsecond is turned away, one whose loop takes seconds
+    is served."""
     import mm2chain
     from mm2chain import params
     off, a = _stream("mixed", 2, 1500, seed=12)
@@ -207,26 +210,40 @@ def test_busy_protocol_of_the_reference_symbol():
     avg = ob.avg_qspan(t)
     Pv2 = params.make_params(max_skip=2**31 - 1, max_iter=1024)
     f_ref, p_ref, _ = ob.chain_fpv(Pv2, t, avg)
+    P = params.map_ont()
+    f1, p1, _ = ob.chain_fpv(P, t, avg)
+    # default: never declined, whatever the predictions say
     d0 = mm2chain.slot_stats(0)["declined"]
     ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=2.0, sw_time_pred=0.5)
-    assert ret == 1 and mm2chain.slot_stats(0)["declined"] == d0 + 1
-    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.4, sw_time_pred=0.5)
-    assert ret == 0
-    assert_same(f, p, f_ref, p_ref, None, "accepted call")
-    ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.0, sw_time_pred=-1.0)
-    assert ret == 0
-    assert_same(f, p, f_ref, p_ref, None, "no model: never declined")
-    P = params.map_ont()
-    rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 9.0, 1.0)
-    assert rc == 1 and np.all(f == -77) and np.all(p == -77)          # declined: nothing written
+    assert ret == 0 and mm2chain.slot_stats(0)["declined"] == d0
+    assert_same(f, p, f_ref, p_ref, None, "default: the protocol is off")
     try:
-        mm2chain.tune("decline_when_busy", 0)
+        mm2chain.tune("decline_when_busy", 2)
+        ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=2.0, sw_time_pred=0.5)
+        assert ret == 1 and mm2chain.slot_stats(0)["declined"] == d0 + 1
+        ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.4, sw_time_pred=0.5)
+        assert ret == 0
+        assert_same(f, p, f_ref, p_ref, None, "accepted call")
+        ret, f, p = mm2chain.run_chaining_on_hw(t.shape[0], 5000, 5000, 500, 15, avg, t, None, 0, tid=3, hw_time_pred=0.0, sw_time_pred=-1.0)
+        assert ret == 0
+        assert_same(f, p, f_ref, p_ref, None, "no model: never declined")
         rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 9.0, 1.0)
-        f1, p1, _ = ob.chain_fpv(P, t, avg)
-        assert rc == 0
-        assert_same(f, p, f1, p1, None, "protocol off")
-    finally:
+        assert rc == 1 and np.all(f == -77) and np.all(p == -77)          # declined: nothing written
+        # rule 1: the slot has served passes by now, so it knows what one takes (tens of microseconds to a millisecond)
         mm2chain.tune("decline_when_busy", 1)
+        rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 0.05, 1e-6)     # the caller's loop: a nanosecond -- waiting for a pass cannot beat it
+        assert rc == 1 and np.all(f == -77) and np.all(p == -77)
+        rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 0.05, 5000.0)   # the caller's loop: seconds
+        assert rc == 0
+        assert_same(f, p, f1, p1, None, "rule 1: served")
+        rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 0.0, 0.0)       # no model
+        assert rc == 0
+        assert_same(f, p, f1, p1, None, "rule 1, no model: never declined")
+    finally:
+        mm2chain.tune("decline_when_busy", 0)
+    rc, f, p = mm2chain.chain_task_pred(P, t, avg, 0, 9.0, 1.0)
+    assert rc == 0
+    assert_same(f, p, f1, p1, None, "protocol off")
 
 
 @pytest.mark.parametrize("direct", [1, 0])
