@@ -55,6 +55,93 @@ template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 *
                                                        CF = CXQ + COOP_NC * 64 * 8, BYTES = CF + COOP_NC * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
 static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold every tile phase A deals");
 
+// ---- the rows of phase A that lie inside every anchor's window, by hand (round 6).  `n_rows` candidates, the first at LDS addresses lds_xq ({x, q}, 8 bytes) / lds_f
+// (f, 4 bytes), the following ones at descending addresses (a segment of the candidate rings that does not wrap), candidate indices j_first, j_first - 1, ...;
+// per lane: the anchor's x - 1, q - 1, span - 1, the bound's addend, and its running (best, index of best, candidates counted).  Per row:
+//   the filters of chain.c:202-205 as in the hand-written loop of chain_dp_tile (two subtractions, saturating subtraction, v_sad, v_max, one compare)      7 instructions, then,
+//   when some lane passed: count it, and test whether any such lane can still beat its best (f + span > best, see older_pairs)                            + 5,
+//   when one can: the score of chain.c:207-209,218 with gap_scale 1 for every lane, SENT where the filter failed, strict maximum (nearest first)         + 15.
+// The compiler's code for the same C++ (the `row` lambda of older_pairs, which still serves the rows with the window test, the tile before, and the gap-cost table)
+// is 10 / + 7 / + 19 with two or three s_nop and a boolean round trip per row, and its own address arithmetic on the scalar unit -- in a kernel bound by
+// scalar-side issue.  Four rows' reads are in flight; reads and waits are all inside the block (nothing in flight when it ends).  Temporaries: v100 .. v116.
+#define MM2C_CROW(X, Q, F, JOFF, WAITF, LBL) \
+	"v_sub_u32 v112, %[tx1], " X "\n\t" \
+	"v_sub_u32 v113, %[tq1], " Q "\n\t" \
+	"v_sub_u32_e64 v114, v113, %[mdqbw] clamp\n\t" \
+	"v_sad_u32 v115, v112, v113, 0\n\t" \
+	"v_max_u32 v114, v114, v115\n\t" \
+	"v_cmp_ge_u32 vcc, %[bw], v114\n\t" \
+	"s_cbranch_vccz " LBL "\n\t" \
+	WAITF \
+	"v_add_u32 v114, " F ", %[spb]\n\t" \
+	"v_cmp_ge_i32 %[st], v114, %[best]\n\t" \
+	"v_addc_co_u32 %[cnt], %[sc2], 0, %[cnt], vcc\n\t"       /* (two instructions behind the branch: the wait states between a VALU write of VCC and a VALU that reads it) */ \
+	"s_and_b64 %[st], %[st], vcc\n\t" \
+	"s_cbranch_scc0 " LBL "\n\t" \
+	"v_cvt_f32_i32 v116, v115\n\t" \
+	"v_or_b32 v115, 1, v115\n\t" \
+	"v_ffbh_u32 v115, v115\n\t" \
+	"v_min3_i32 v112, v113, v112, %[sp1]\n\t" \
+	"v_mul_f32 v116, %[avg], v116\n\t" \
+	"v_cvt_i32_f32 v116, v116\n\t" \
+	"v_lshrrev_b32 v115, 1, v115\n\t" \
+	"v_add3_u32 v112, v112, v115, " F "\n\t" \
+	"v_sub_u32 v112, v112, v116\n\t" \
+	"v_add_u32 v112, -14, v112\n\t" \
+	"v_cndmask_b32 v112, %[sent], v112, vcc\n\t" \
+	"s_sub_i32 %[sj2], %[sj], " JOFF "\n\t" \
+	"v_cmp_gt_i32 vcc, v112, %[best]\n\t" \
+	"v_max_i32 %[best], v112, %[best]\n\t" \
+	"v_mov_b32 v113, %[sj2]\n\t" \
+	"v_cndmask_b32 %[jb], %[jb], v113, vcc\n" \
+	LBL ":\n\t"
+
+__device__ __forceinline__ void coop_rows_inner(int lds_xq, int lds_f, int n_rows, int j_first, int tx1, int tq1, int sp1, int spb, int mdqbw, int bw, int sent,
+                                                float avg, int &best, int &jb, int &cnt)
+{
+	int pxl = lds_xq - 24, pfl = lds_f - 12;                   // the lowest address of a group of four rows
+	int sn = __builtin_amdgcn_readfirstlane(n_rows), sj = __builtin_amdgcn_readfirstlane(j_first), sj2;
+	unsigned long long st, sc2;
+	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
+	asm volatile(
+		"Lcr_grp_%=:\n\t"
+		"s_cmp_lt_i32 %[sn], 4\n\t"
+		"s_cbranch_scc1 Lcr_tail_%=\n\t"
+		"ds_read2_b64 v[100:103], %[pxl] offset0:3 offset1:2\n\t"
+		"ds_read2_b32 v[108:109], %[pfl] offset0:3 offset1:2\n\t"
+		"ds_read2_b64 v[104:107], %[pxl] offset0:1 offset1:0\n\t"
+		"ds_read2_b32 v[110:111], %[pfl] offset0:1 offset1:0\n\t"
+		"v_subrev_u32 %[pxl], 32, %[pxl]\n\t"
+		"v_subrev_u32 %[pfl], 16, %[pfl]\n\t"
+		"s_waitcnt lgkmcnt(3)\n\t"
+		MM2C_CROW("v100", "v101", "v108", "0", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_a_%=")
+		MM2C_CROW("v102", "v103", "v109", "1", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_b_%=")
+		"s_waitcnt lgkmcnt(1)\n\t"
+		MM2C_CROW("v104", "v105", "v110", "2", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_c_%=")
+		MM2C_CROW("v106", "v107", "v111", "3", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_d_%=")
+		"s_sub_i32 %[sj], %[sj], 4\n\t"
+		"s_sub_i32 %[sn], %[sn], 4\n\t"
+		"s_branch Lcr_grp_%=\n"
+		"Lcr_tail_%=:\n\t"
+		"s_cmp_lt_i32 %[sn], 1\n\t"
+		"s_cbranch_scc1 Lcr_end_%=\n\t"
+		"ds_read_b64 v[100:101], %[pxl] offset:24\n\t"
+		"ds_read_b32 v108, %[pfl] offset:12\n\t"
+		"v_subrev_u32 %[pxl], 8, %[pxl]\n\t"
+		"v_subrev_u32 %[pfl], 4, %[pfl]\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		MM2C_CROW("v100", "v101", "v108", "0", "", "Lcr_e_%=")
+		"s_sub_i32 %[sj], %[sj], 1\n\t"
+		"s_sub_i32 %[sn], %[sn], 1\n\t"
+		"s_branch Lcr_tail_%=\n"
+		"Lcr_end_%=:\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		: [best] "+v"(best), [jb] "+v"(jb), [cnt] "+v"(cnt), [pxl] "+v"(pxl), [pfl] "+v"(pfl), [sn] "+s"(sn), [sj] "+s"(sj), [sj2] "=&s"(sj2), [st] "=&s"(st), [sc2] "=&s"(sc2)
+		: [tx1] "v"(tx1), [tq1] "v"(tq1), [sp1] "v"(sp1), [spb] "v"(spb), [mdqbw] "v"(mdqbw), [bw] "v"(bw), [sent] "v"(sent), [avg] "s"(avg)
+		: "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116");
+}
+#undef MM2C_CROW
+
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
@@ -106,6 +193,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 	}
 
+#ifdef MM2C_COOP_PRIO
+	if (wv == 0) __builtin_amdgcn_s_setprio(MM2C_COOP_PRIO);   // the walker is the wave every tile waits for: its instructions go first on its SIMD
+#endif
 	const int rl = 63 - lane;
 	AnchorCtx X;
 	X.avg = avg; X.rl = rl; X.seg_i = 0; X.far_mode = 0;
@@ -215,41 +305,72 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// of 8 dealt to `nw` waves of which this is number `me`; results into that tile's set of summaries.  (A predecessor with equal x, dr == 0, is rejected by pair_ok: dr - 1 is
 		// 0xffffffff and the unsigned |dr - dq| huge.)
 		auto older_pairs = [&](int t0, int j0, int j1, int me, int nw, int tx1v, int tq1v, int sp1v, int lov, bool d1, int lo_max) {
-			int best_l = SENT, jb_l = -1, cnt_l = 0;
+			// best so far starts at the anchor's own span (chain.c:188): a candidate only matters to the maximum when it beats that, and whether a candidate counts
+			// (cnt_l, the masks of the rank test) does not depend on its score
+			const int spv = sp1v + 1;
+			int best_l = spv, jb_l = -1, cnt_l = 0;
 			unsigned long long m_l = 0;                          // d1: which anchors of the tile before t0 are candidates (bit c: anchor t0 - 1 - c)
 			const char *const cxq = lds + LY::BYTES + CL::CXQ, *const cf = lds + LY::BYTES + CL::CF;
 			constexpr int CM = 64 * COOP_NC - 1;
-			// one row: candidate j (x, q: one broadcast read) against the 64 anchors of the tile.  EDGE rows lie before the window start of some anchor of the tile
-			// (j < lo_max = the window start of its last anchor: st[] is monotone) and carry the per-lane window test; the others are inside every window.
-			auto row = [&](int j, int2 xq, bool edge) {
+			// A pair scores at most f[j] + span (chain.c:207-220: min(dq, dr, span) minus a gap cost that is never negative while gap_scale >= 0), so a row in which
+			// no lane that passed the filters can BEAT its best so far (strictly: the wave meets its candidates nearest first and chain.c:226 keeps the first of equal
+			// scores) is only counted.  On a chain the nearest candidate of a wave's block has the highest f; the ones behind it are counted, not scored.
+			const int spb = P.gap_scale >= 0.f ? sp1v : 0x3fffffff;   // (a negative gap_scale turns the gap cost into a gain: no bound -- every counted row is scored)
+			// one row: candidate j (x, q, f: broadcast reads, one LDS address for all lanes) against the 64 anchors of the tile.  EDGE rows lie before the window start of
+			// some anchor of the tile (j < lo_max = the window start of its last anchor: st[] is monotone) and carry the per-lane window test; the others are inside every window.
+			auto row = [&](int j, int2 xq, int fj, bool edge) {
 				const int dr1 = tx1v - xq.x, dq1 = tq1v - xq.y;
 				const int dd = absdiff(dr1, dq1);
 				bool ok = pair_ok(dr1, dq1, dd);
-				if (edge) ok = ok && j >= lov;
-				if (BALLOT(ok) != 0) {                           // (most candidates are candidates of none of the 64 anchors: the score waits for one that is)
-					const int fj = *(const int *)(cf + ((j & CM) << 2));
-					int s0 = pair_score0(dr1, dq1, dd, sp1v);
-					asm volatile("" : "+v"(s0));                 // for every lane, whatever its filter said: nine instructions are cheaper than the exec mask around them
-					const int sc = ok ? s0 + fj : SENT;
+				if (edge) ok = ok & (j >= lov);                  // (`&`, and masks below: around `&&` of divergent values the compiler builds exec regions)
+				const mask_t okm = BALLOT(ok);
+				if (okm != 0) {                                  // (most candidates are candidates of none of the 64 anchors)
 					cnt_l += ok ? 1 : 0;
 					if (d1) m_l |= ok ? 1ull << (t0 - 1 - j) : 0ull;
-					const bool take = sc > best_l;               // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
-					best_l = max(sc, best_l); jb_l = take ? j : jb_l;
+					if ((okm & BALLOT(fj + spb >= best_l)) != 0) {   // f + span > best, as f + (span - 1) >= best
+						int s0 = pair_score0(dr1, dq1, dd, sp1v);
+						asm volatile("" : "+v"(s0));             // for every lane, whatever its filter said: nine instructions are cheaper than the exec mask around them
+						const int sc = ok ? s0 + fj : SENT;
+						const bool take = sc > best_l;           // a wave meets its candidates nearest first: strict, as chain.c:226 (the waves' results are merged by (score, index))
+						best_l = max(sc, best_l); jb_l = take ? j : jb_l;
+					}
 				}
 			};
-			// rows jhi - 1 - me, jhi - 1 - me - nw, ... down to jlo: the candidates of [jlo, jhi) dealt to the nw waves one by one, four reads in flight
+			// `cnt` rows jt, jt - 1, ..., contiguous in the rings: one base address, the rows at constant offsets from it, eight rows' reads in flight
+			auto seg = [&](int jt, int cnt_rows, bool edge) {
+#ifndef MM2C_COOP_ROWS_CXX
+				if constexpr (!TAB)
+					if (!edge && !d1) {                          // the bulk: rows inside every window, dealt a tile ahead -- the hand-written block
+						coop_rows_inner(LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), cnt_rows, jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
+						                sent_v, avg, best_l, jb_l, cnt_l);
+						return;
+					}
+#endif
+				const int2 *const px = (const int2 *)(cxq + ((jt & CM) << 3));
+				const int *const pf = (const int *)(cf + ((jt & CM) << 2));
+				int k = 0;
+				for (; k + 8 <= cnt_rows; k += 8) {
+					int2 c[8]; int fv[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u) { c[u] = px[-(k + u)]; fv[u] = pf[-(k + u)]; }
+#pragma unroll
+					for (int u = 0; u < 8; ++u) row(jt - k - u, c[u], fv[u], edge);
+				}
+				for (; k < cnt_rows; ++k) row(jt - k, px[-k], pf[-k], edge);
+			};
+			// the candidates of [jlo, jhi) in nw contiguous blocks, the nearest block to wave 0; a block that crosses the rings' wrap-around is two segments
 			auto rows = [&](int jhi, int jlo, bool edge) {
-				int j = jhi - 1 - me;
+				const int n_rows = jhi - jlo;
+				if (n_rows <= 0) return;
+				const int per = (n_rows + nw - 1) / nw;
+				const int ja = jhi - me * per, jz = max(ja - per, jlo);         // my block: [jz, ja)
 #if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
 				if (0)
 #endif
-				{
-					for (; j - 3 * nw >= jlo; j -= 4 * nw) {
-						const int2 c0 = *(const int2 *)(cxq + ((j & CM) << 3)), c1 = *(const int2 *)(cxq + (((j - nw) & CM) << 3)),
-						           c2 = *(const int2 *)(cxq + (((j - 2 * nw) & CM) << 3)), c3 = *(const int2 *)(cxq + (((j - 3 * nw) & CM) << 3));
-						row(j, c0, edge); row(j - nw, c1, edge); row(j - 2 * nw, c2, edge); row(j - 3 * nw, c3, edge);
-					}
-					for (; j >= jlo; j -= nw) row(j, *(const int2 *)(cxq + ((j & CM) << 3)), edge);
+				if (ja > jz) {
+					const int jw = (ja - 1) & ~CM;                              // first anchor of the ring revolution that holds ja - 1
+					if (jw > jz) { seg(ja - 1, ja - jw, edge); seg(jw - 1, jw - jz, edge); }
+					else seg(ja - 1, ja - jz, edge);
 				}
 			};
 			const int jm = min(max(lo_max, j0), j1);
@@ -257,7 +378,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			rows(jm, j0, true);
 			const int sb = ((t0 >> 6) & 1) * 64;
 			if (BALLOT(cnt_l != 0) != 0) {
-				if (best_l != SENT) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (best_l > spv) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				if (cnt_l != 0) __hip_atomic_fetch_add(&s_cnt2[sb + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				if (d1 && m_l != 0) __hip_atomic_fetch_or(&s_d12[sb + lane], m_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
