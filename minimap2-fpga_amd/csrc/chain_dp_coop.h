@@ -52,7 +52,7 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // no candidate of phase A comes from memory any more.
 constexpr int COOP_NC = 32;
 template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, CXQ = PAIRS + 2 * 64 * 64 * 4,
-                                                       CF = CXQ + COOP_NC * 64 * 8, BYTES = CF + COOP_NC * 64 * 4; };   // (two sets of summaries and two tables: see the schedule)
+                                                       CF = CXQ + COOP_NC * 64 * 8, QCNT = CF + COOP_NC * 64 * 4, BYTES = QCNT + 16; };   // (two sets of summaries and two tables: see the schedule; QCNT: the group counters of phase A1, by tile parity)
 static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold every tile phase A deals");
 
 // ---- the rows of phase A that lie inside every anchor's window, by hand (round 6).  `n_rows` candidates, the first at LDS addresses lds_xq ({x, q}, 8 bytes) / lds_f
@@ -64,18 +64,19 @@ static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold eve
 // The compiler's code for the same C++ (the `row` lambda of older_pairs, which still serves the rows with the window test, the tile before, and the gap-cost table)
 // is 10 / + 7 / + 19 with two or three s_nop and a boolean round trip per row, and its own address arithmetic on the scalar unit -- in a kernel bound by
 // scalar-side issue.  Four rows' reads are in flight; reads and waits are all inside the block (nothing in flight when it ends).  Temporaries: v100 .. v116.
-#define MM2C_CROW(X, Q, F, JOFF, WAITF, LBL) \
+#define MM2C_CROW(X, Q, F, JOFF, WAITF, LBL, FILT, D1) \
 	"v_sub_u32 v112, %[tx1], " X "\n\t" \
 	"v_sub_u32 v113, %[tq1], " Q "\n\t" \
 	"v_sub_u32_e64 v114, v113, %[mdqbw] clamp\n\t" \
 	"v_sad_u32 v115, v112, v113, 0\n\t" \
-	"v_max_u32 v114, v114, v115\n\t" \
+	FILT \
 	"v_cmp_ge_u32 vcc, %[bw], v114\n\t" \
 	"s_cbranch_vccz " LBL "\n\t" \
 	WAITF \
 	"v_add_u32 v114, " F ", %[spb]\n\t" \
 	"v_cmp_ge_i32 %[st], v114, %[best]\n\t" \
 	"v_addc_co_u32 %[cnt], %[sc2], 0, %[cnt], vcc\n\t"       /* (two instructions behind the branch: the wait states between a VALU write of VCC and a VALU that reads it) */ \
+	D1 \
 	"s_and_b64 %[st], %[st], vcc\n\t" \
 	"s_cbranch_scc0 " LBL "\n\t" \
 	"v_cvt_f32_i32 v116, v115\n\t" \
@@ -95,6 +96,46 @@ static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold eve
 	"v_mov_b32 v113, %[sj2]\n\t" \
 	"v_cndmask_b32 %[jb], %[jb], v113, vcc\n" \
 	LBL ":\n\t"
+// the filter's last step.  Inside every window: the maximum of the two violations.  EDGE rows (before the window start of some anchor of the tile) add a third: how far the
+// candidate lies before the lane's window start, (lov + r) - (j of the group's first row) saturated at 0, shifted beyond any bw the block is used with (bw < 2^20)
+#define MM2C_CFILT_INNER "v_max_u32 v114, v114, v115\n\t"
+#define MM2C_CFILT_EDGE(LOV) "v_sub_u32_e64 v117, " LOV ", %[sj] clamp\n\t" "v_lshlrev_b32 v117, 20, v117\n\t" "v_max3_u32 v114, v114, v115, v117\n\t"
+// the tile before (phase A2, a group of exactly four rows per call): which of its anchors are a lane's candidates, as bit r of a word for row r of the group
+#define MM2C_CD1(R) "v_cndmask_b32_e64 v116, 0, 1, vcc\n\t" "v_lshl_or_b32 %[ml], v116, " R ", %[ml]\n\t"
+#define MM2C_CROWS_BODY(F0, F1, F2, F3, D0, D1, D2, D3) \
+		"Lcr_grp_%=:\n\t" \
+		"s_cmp_lt_i32 %[sn], 4\n\t" \
+		"s_cbranch_scc1 Lcr_tail_%=\n\t" \
+		"ds_read2_b64 v[100:103], %[pxl] offset0:3 offset1:2\n\t" \
+		"ds_read2_b32 v[108:109], %[pfl] offset0:3 offset1:2\n\t" \
+		"ds_read2_b64 v[104:107], %[pxl] offset0:1 offset1:0\n\t" \
+		"ds_read2_b32 v[110:111], %[pfl] offset0:1 offset1:0\n\t" \
+		"v_subrev_u32 %[pxl], 32, %[pxl]\n\t" \
+		"v_subrev_u32 %[pfl], 16, %[pfl]\n\t" \
+		"s_waitcnt lgkmcnt(3)\n\t" \
+		MM2C_CROW("v100", "v101", "v108", "0", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_a_%=", F0, D0) \
+		MM2C_CROW("v102", "v103", "v109", "1", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_b_%=", F1, D1) \
+		"s_waitcnt lgkmcnt(1)\n\t" \
+		MM2C_CROW("v104", "v105", "v110", "2", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_c_%=", F2, D2) \
+		MM2C_CROW("v106", "v107", "v111", "3", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_d_%=", F3, D3) \
+		"s_sub_i32 %[sj], %[sj], 4\n\t" \
+		"s_sub_i32 %[sn], %[sn], 4\n\t" \
+		"s_branch Lcr_grp_%=\n" \
+		"Lcr_tail_%=:\n\t" \
+		"s_cmp_lt_i32 %[sn], 1\n\t" \
+		"s_cbranch_scc1 Lcr_end_%=\n\t" \
+		"ds_read_b64 v[100:101], %[pxl] offset:24\n\t" \
+		"ds_read_b32 v108, %[pfl] offset:12\n\t" \
+		"v_subrev_u32 %[pxl], 8, %[pxl]\n\t" \
+		"v_subrev_u32 %[pfl], 4, %[pfl]\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t" \
+		MM2C_CROW("v100", "v101", "v108", "0", "", "Lcr_e_%=", F0, D0) \
+		"s_sub_i32 %[sj], %[sj], 1\n\t" \
+		"s_sub_i32 %[sn], %[sn], 1\n\t" \
+		"s_branch Lcr_tail_%=\n" \
+		"Lcr_end_%=:\n\t" \
+		"s_waitcnt lgkmcnt(0)\n\t"
+#define MM2C_CROWS_CLOBBERS "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117"
 
 __device__ __forceinline__ void coop_rows_inner(int lds_xq, int lds_f, int n_rows, int j_first, int tx1, int tq1, int sp1, int spb, int mdqbw, int bw, int sent,
                                                 float avg, int &best, int &jb, int &cnt)
@@ -103,44 +144,51 @@ __device__ __forceinline__ void coop_rows_inner(int lds_xq, int lds_f, int n_row
 	int sn = __builtin_amdgcn_readfirstlane(n_rows), sj = __builtin_amdgcn_readfirstlane(j_first), sj2;
 	unsigned long long st, sc2;
 	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
-	asm volatile(
-		"Lcr_grp_%=:\n\t"
-		"s_cmp_lt_i32 %[sn], 4\n\t"
-		"s_cbranch_scc1 Lcr_tail_%=\n\t"
-		"ds_read2_b64 v[100:103], %[pxl] offset0:3 offset1:2\n\t"
-		"ds_read2_b32 v[108:109], %[pfl] offset0:3 offset1:2\n\t"
-		"ds_read2_b64 v[104:107], %[pxl] offset0:1 offset1:0\n\t"
-		"ds_read2_b32 v[110:111], %[pfl] offset0:1 offset1:0\n\t"
-		"v_subrev_u32 %[pxl], 32, %[pxl]\n\t"
-		"v_subrev_u32 %[pfl], 16, %[pfl]\n\t"
-		"s_waitcnt lgkmcnt(3)\n\t"
-		MM2C_CROW("v100", "v101", "v108", "0", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_a_%=")
-		MM2C_CROW("v102", "v103", "v109", "1", "s_waitcnt lgkmcnt(2)\n\t", "Lcr_b_%=")
-		"s_waitcnt lgkmcnt(1)\n\t"
-		MM2C_CROW("v104", "v105", "v110", "2", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_c_%=")
-		MM2C_CROW("v106", "v107", "v111", "3", "s_waitcnt lgkmcnt(0)\n\t", "Lcr_d_%=")
-		"s_sub_i32 %[sj], %[sj], 4\n\t"
-		"s_sub_i32 %[sn], %[sn], 4\n\t"
-		"s_branch Lcr_grp_%=\n"
-		"Lcr_tail_%=:\n\t"
-		"s_cmp_lt_i32 %[sn], 1\n\t"
-		"s_cbranch_scc1 Lcr_end_%=\n\t"
-		"ds_read_b64 v[100:101], %[pxl] offset:24\n\t"
-		"ds_read_b32 v108, %[pfl] offset:12\n\t"
-		"v_subrev_u32 %[pxl], 8, %[pxl]\n\t"
-		"v_subrev_u32 %[pfl], 4, %[pfl]\n\t"
-		"s_waitcnt lgkmcnt(0)\n\t"
-		MM2C_CROW("v100", "v101", "v108", "0", "", "Lcr_e_%=")
-		"s_sub_i32 %[sj], %[sj], 1\n\t"
-		"s_sub_i32 %[sn], %[sn], 1\n\t"
-		"s_branch Lcr_tail_%=\n"
-		"Lcr_end_%=:\n\t"
-		"s_waitcnt lgkmcnt(0)\n\t"
+	asm volatile(MM2C_CROWS_BODY(MM2C_CFILT_INNER, MM2C_CFILT_INNER, MM2C_CFILT_INNER, MM2C_CFILT_INNER, "", "", "", "")
 		: [best] "+v"(best), [jb] "+v"(jb), [cnt] "+v"(cnt), [pxl] "+v"(pxl), [pfl] "+v"(pfl), [sn] "+s"(sn), [sj] "+s"(sj), [sj2] "=&s"(sj2), [st] "=&s"(st), [sc2] "=&s"(sc2)
 		: [tx1] "v"(tx1), [tq1] "v"(tq1), [sp1] "v"(sp1), [spb] "v"(spb), [mdqbw] "v"(mdqbw), [bw] "v"(bw), [sent] "v"(sent), [avg] "s"(avg)
-		: "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116");
+		: MM2C_CROWS_CLOBBERS);
+}
+// the same for the rows that need the window test (lov: the lane's window start; needs bw < 2^20 and windows of fewer than 2^11 anchors before the tile, which the
+// tiles phase A deals guarantee)
+__device__ __forceinline__ void coop_rows_edge(int lds_xq, int lds_f, int n_rows, int j_first, int tx1, int tq1, int sp1, int spb, int mdqbw, int bw, int sent,
+                                               float avg, int lov, int &best, int &jb, int &cnt)
+{
+	int pxl = lds_xq - 24, pfl = lds_f - 12;
+	int sn = __builtin_amdgcn_readfirstlane(n_rows), sj = __builtin_amdgcn_readfirstlane(j_first), sj2;
+	unsigned long long st, sc2;
+	const int lov1 = lov + 1, lov2 = lov + 2, lov3 = lov + 3;
+	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
+	asm volatile(MM2C_CROWS_BODY(MM2C_CFILT_EDGE("%[lov0]"), MM2C_CFILT_EDGE("%[lov1]"), MM2C_CFILT_EDGE("%[lov2]"), MM2C_CFILT_EDGE("%[lov3]"), "", "", "", "")
+		: [best] "+v"(best), [jb] "+v"(jb), [cnt] "+v"(cnt), [pxl] "+v"(pxl), [pfl] "+v"(pfl), [sn] "+s"(sn), [sj] "+s"(sj), [sj2] "=&s"(sj2), [st] "=&s"(st), [sc2] "=&s"(sc2)
+		: [tx1] "v"(tx1), [tq1] "v"(tq1), [sp1] "v"(sp1), [spb] "v"(spb), [mdqbw] "v"(mdqbw), [bw] "v"(bw), [sent] "v"(sent), [avg] "s"(avg),
+		  [lov0] "v"(lov), [lov1] "v"(lov1), [lov2] "v"(lov2), [lov3] "v"(lov3)
+		: MM2C_CROWS_CLOBBERS);
+}
+// a group of exactly four rows of the tile before (n_rows == 4: the single-row loop behind the group, which has no row number, must not run); ml: bit r = row r counted
+__device__ __forceinline__ void coop_rows4_d1(bool edge, int lds_xq, int lds_f, int j_first, int tx1, int tq1, int sp1, int spb, int mdqbw, int bw, int sent,
+                                              float avg, int lov, int &best, int &jb, int &cnt, int &ml)
+{
+	int pxl = lds_xq - 24, pfl = lds_f - 12;
+	int sn = 4, sj = __builtin_amdgcn_readfirstlane(j_first), sj2;
+	unsigned long long st, sc2;
+	const int lov1 = lov + 1, lov2 = lov + 2, lov3 = lov + 3;
+	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
+	asm volatile("" : "+s"(sn));
+	if (!edge)
+		asm volatile(MM2C_CROWS_BODY(MM2C_CFILT_INNER, MM2C_CFILT_INNER, MM2C_CFILT_INNER, MM2C_CFILT_INNER, MM2C_CD1("0"), MM2C_CD1("1"), MM2C_CD1("2"), MM2C_CD1("3"))
+			: [best] "+v"(best), [jb] "+v"(jb), [cnt] "+v"(cnt), [ml] "+v"(ml), [pxl] "+v"(pxl), [pfl] "+v"(pfl), [sn] "+s"(sn), [sj] "+s"(sj), [sj2] "=&s"(sj2), [st] "=&s"(st), [sc2] "=&s"(sc2)
+			: [tx1] "v"(tx1), [tq1] "v"(tq1), [sp1] "v"(sp1), [spb] "v"(spb), [mdqbw] "v"(mdqbw), [bw] "v"(bw), [sent] "v"(sent), [avg] "s"(avg)
+			: MM2C_CROWS_CLOBBERS);
+	else
+		asm volatile(MM2C_CROWS_BODY(MM2C_CFILT_EDGE("%[lov0]"), MM2C_CFILT_EDGE("%[lov1]"), MM2C_CFILT_EDGE("%[lov2]"), MM2C_CFILT_EDGE("%[lov3]"), MM2C_CD1("0"), MM2C_CD1("1"), MM2C_CD1("2"), MM2C_CD1("3"))
+			: [best] "+v"(best), [jb] "+v"(jb), [cnt] "+v"(cnt), [ml] "+v"(ml), [pxl] "+v"(pxl), [pfl] "+v"(pfl), [sn] "+s"(sn), [sj] "+s"(sj), [sj2] "=&s"(sj2), [st] "=&s"(st), [sc2] "=&s"(sc2)
+			: [tx1] "v"(tx1), [tq1] "v"(tq1), [sp1] "v"(sp1), [spb] "v"(spb), [mdqbw] "v"(mdqbw), [bw] "v"(bw), [sent] "v"(sent), [avg] "s"(avg),
+			  [lov0] "v"(lov), [lov1] "v"(lov1), [lov2] "v"(lov2), [lov3] "v"(lov3)
+			: MM2C_CROWS_CLOBBERS);
 }
 #undef MM2C_CROW
+#undef MM2C_CROWS_BODY
 
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
@@ -209,6 +257,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	unsigned long long *const s_own2 = (unsigned long long *)(lds + LY::BYTES + CL::MASKS);   // [tile parity][lane] bit k: candidate k of the anchor's own tile is one of its candidates
 	unsigned long long *const s_d12 = s_own2 + 2 * 64;                                          // [tile parity][lane] bit c: anchor (tile start - 1 - c), in the tile before, is one of its candidates
 	int *const s_pair2 = (int *)(lds + LY::BYTES + CL::PAIRS);            // [tile parity][candidate k of that tile][lane]
+	int *const s_q2 = (int *)(lds + LY::BYTES + CL::QCNT);                // [tile parity] next group of candidates of phase A1
 
 	int own_x = 0, own_q = 0, own_g = 0, own_f = 0, own_p = -1;
 	int seg0 = 0;
@@ -217,6 +266,10 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 
 #if MM2C_COOP_PROBE == 9
 	long long tp[6] = {0, 0, 0, 0, 0, 0}, tq = wall_clock64();   // wave 0: 100 MHz ticks spent up to barrier 1 / in phase A2 / summary + flags / in the pushes / rest of phase B / tile end
+	long long th[6] = {0, 0, 0, 0, 0, 0}, hq = wall_clock64();   // a helper wave: tile prologue / waiting at barrier 1 / its share of phase A2 / waiting at barrier 2 / phase A1 / the next tile's table
+#define MM2C_HTICK(K) do { const long long tn_ = wall_clock64(); th[K] += tn_ - hq; hq = tn_; } while (0)
+#else
+#define MM2C_HTICK(K) do {} while (0)
 #endif
 	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
 	int cur_st = (rl < n) ? st[rl] : 0;
@@ -237,6 +290,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			{	// the summaries of the NEXT tile start empty (its older-tile pairs are dealt while this tile is walked); tile 0 has no older tiles, its set is emptied here too
 				const int nb = ((i0 >> 6) + 1) & 1;
 				s_key2[nb * 64 + lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[nb * 64 + lane] = 0; s_own2[nb * 64 + lane] = 0; s_d12[nb * 64 + lane] = 0;
+				if (lane == 0) s_q2[nb] = 0;
 				if (i0 == 0) { s_key2[lane] = (long long)((unsigned long long)(unsigned)SENT << 32); s_cnt2[lane] = 0; s_own2[lane] = 0; s_d12[lane] = 0; }
 			}
 			for (int s = lane; s < SN / 4; s += 64) ((int *)(lds + LY::ST))[s] = 0;
@@ -253,30 +307,34 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		const int span_l = P.span_override >= 0 ? P.span_override : (int)(cur.w & 0xff);
 		mask_t eq_prev = 0;
-		{
-			asm volatile("" : "+v"(prev_last));
-			const int px = __builtin_amdgcn_update_dpp(prev_last, own_x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-			eq_prev = BALLOT(px == own_x);
-			if (i0 == 0) eq_prev &= ~(1ull << 63);
-		}
 		X.stamp_lo = stamp_lo;
 		const int addr0 = ((idx - 64) & (SN - 1)) * LY::XS;
 		const int addr0b = ((idx - 128) & (SN - 1)) * LY::XS;
 		int lomc_v = stamp_lo - 1;
 		asm volatile("" : "+v"(lomc_v));
 		const int lo_l = no_pairs ? idx : min(cur_st, idx);
-		const mask_t above = ~(eq_prev >> lane);
-		const int e_l = above ? (int)__builtin_ctzll(above) : 64;
-		const int w_l = min(rl, idx - lo_l);
-		const int lo_c = max(lo_l, stamp_lo), bef_l = max(i0 - lo_c, 0);
-		int tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);
-		if (lo_l >= idx) tw_l |= (int)0xa0000000;
-		if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
-		if (e_l > rl) tw_l |= (int)0x80000000;
+		const int lo_c = max(lo_l, stamp_lo);
+		int tw_l = 0;
+		if (wv == 0) {                                               // what only the walker's exact scans read (the other waves deal pairs: x, q, span, window start)
+			asm volatile("" : "+v"(prev_last));
+			const int px = __builtin_amdgcn_update_dpp(prev_last, own_x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+			eq_prev = BALLOT(px == own_x);
+			if (i0 == 0) eq_prev &= ~(1ull << 63);
+			const mask_t above = ~(eq_prev >> lane);
+			const int e_l = above ? (int)__builtin_ctzll(above) : 64;
+			const int w_l = min(rl, idx - lo_l);
+			const int bef_l = max(i0 - lo_c, 0);
+			tw_l = max(w_l - e_l, 0) | (min(lane + 1 + e_l, 64) << 8) | (bef_l << 15);
+			if (lo_l >= idx) tw_l |= (int)0xa0000000;
+			if (FAR && lo_l < stamp_lo) tw_l |= 1 << 30;
+			if (e_l > rl) tw_l |= (int)0x80000000;
+		}
 		const int ownst = idx & (SN - 1);
 		const int tx1_l = own_x - 1, tq1_l = own_q - 1;
 
+		MM2C_HTICK(0);
 		__syncthreads();      // the rings hold x / q of this tile and f / p of the tiles before it (wave 0 wrote them); the summaries of the tile before have been read
+		MM2C_HTICK(1);
 #if MM2C_COOP_PROBE == 9
 		if (wv == 0) { const long long tn = wall_clock64(); tp[1] += tn - tq; tq = tn; }
 #endif
@@ -316,6 +374,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// no lane that passed the filters can BEAT its best so far (strictly: the wave meets its candidates nearest first and chain.c:226 keeps the first of equal
 			// scores) is only counted.  On a chain the nearest candidate of a wave's block has the highest f; the ones behind it are counted, not scored.
 			const int spb = P.gap_scale >= 0.f ? sp1v : 0x3fffffff;   // (a negative gap_scale turns the gap cost into a gain: no bound -- every counted row is scored)
+			const bool asm_rows = P.bw < (1 << 20);              // the hand-written rows (the edge form shifts its window violation beyond bw)
 			// one row: candidate j (x, q, f: broadcast reads, one LDS address for all lanes) against the 64 anchors of the tile.  EDGE rows lie before the window start of
 			// some anchor of the tile (j < lo_max = the window start of its last anchor: st[] is monotone) and carry the per-lane window test; the others are inside every window.
 			auto row = [&](int j, int2 xq, int fj, bool edge) {
@@ -340,9 +399,17 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			auto seg = [&](int jt, int cnt_rows, bool edge) {
 #ifndef MM2C_COOP_ROWS_CXX
 				if constexpr (!TAB)
-					if (!edge && !d1) {                          // the bulk: rows inside every window, dealt a tile ahead -- the hand-written block
-						coop_rows_inner(LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), cnt_rows, jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
-						                sent_v, avg, best_l, jb_l, cnt_l);
+					if (!d1 && asm_rows) {                       // the rows dealt a tile ahead: the hand-written blocks
+						if (!edge) coop_rows_inner(LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), cnt_rows, jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
+						                           sent_v, avg, best_l, jb_l, cnt_l);
+						else coop_rows_edge(LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), cnt_rows, jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
+						                    sent_v, avg, lov, best_l, jb_l, cnt_l);
+						return;
+					} else if (d1 && asm_rows && cnt_rows == 4) {   // the tile before: a whole group, with the candidate masks of the rank test
+						int ml = 0;
+						coop_rows4_d1(edge, LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
+						              sent_v, avg, lov, best_l, jb_l, cnt_l, ml);
+						m_l |= (unsigned long long)(unsigned)ml << (t0 - 1 - jt);   // row r of the group is anchor jt - r: bit t0 - 1 - jt + r
 						return;
 					}
 #endif
@@ -358,24 +425,54 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				}
 				for (; k < cnt_rows; ++k) row(jt - k, px[-k], pf[-k], edge);
 			};
-			// the candidates of [jlo, jhi) in nw contiguous blocks, the nearest block to wave 0; a block that crosses the rings' wrap-around is two segments
-			auto rows = [&](int jhi, int jlo, bool edge) {
-				const int n_rows = jhi - jlo;
-				if (n_rows <= 0) return;
-				const int per = (n_rows + nw - 1) / nw;
-				const int ja = jhi - me * per, jz = max(ja - per, jlo);         // my block: [jz, ja)
-#if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
-				if (0)
-#endif
-				if (ja > jz) {
-					const int jw = (ja - 1) & ~CM;                              // first anchor of the ring revolution that holds ja - 1
-					if (jw > jz) { seg(ja - 1, ja - jw, edge); seg(jw - 1, jw - jz, edge); }
-					else seg(ja - 1, ja - jz, edge);
-				}
+			// rows [jz, ja) of one kind; a range that crosses the rings' wrap-around is two segments
+			auto rows = [&](int ja, int jz, bool edge) {
+				if (ja <= jz) return;
+				const int jw = (ja - 1) & ~CM;                                  // first anchor of the ring revolution that holds ja - 1
+				if (jw > jz) { seg(ja - 1, ja - jw, edge); seg(jw - 1, jw - jz, edge); }
+				else seg(ja - 1, ja - jz, edge);
 			};
+			// the candidates of [j0, j1) in groups of four consecutive ones, dealt to the nw waves in turn, nearest group first (every wave meets near and far candidates,
+			// chain and noise alike: contiguous blocks per wave left the waves with the far blocks 25 % behind); the part of a group at or behind jm needs no window test
 			const int jm = min(max(lo_max, j0), j1);
-			rows(j1, jm, false);
-			rows(jm, j0, true);
+#if MM2C_COOP_PROBE == 1 || MM2C_COOP_PROBE == 4
+			if (0)
+#endif
+			if (d1) {
+				// the tile before (every wave, between two barriers): one group of four each
+				const int n_grp = (j1 - j0 + 3) >> 2;
+				for (int g = me; g < n_grp; g += nw) {
+					const int ja = j1 - 4 * g, jz = max(ja - 4, j0);
+					rows(ja, max(jz, jm), false);
+					rows(min(ja, jm), jz, true);
+				}
+			} else {
+				// the tiles before that, dealt a tile ahead beside the walk.  Equal shares do not end together: the CU serves its waves oldest first, and with equal contiguous
+				// blocks the youngest wave finished a quarter behind the oldest (measured per wave, round 6); taking every group of candidates from a counter costs a
+				// third more than it balances (per group: the atomic, two window-start splits, a call of the hand-written block).  So: three quarters of the candidates in
+				// equal contiguous blocks, the nearest to wave 0 -- and the farthest quarter in groups of eight TAKEN FROM A COUNTER in LDS by whoever is done with its
+				// block (every wave still meets its candidates nearest first).
+				const int n_all = j1 - j0;
+				const int per = ((n_all * 3 / 4) / nw) & ~3;                       // rows of a static block (whole groups of four)
+				const int jq = j1 - per * nw;                                       // [j0, jq): the queue's part
+				int *const q = s_q2 + ((t0 >> 6) & 1);
+				int gv = 0;
+				if (lane == 0) gv = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (requested before the block is worked on)
+				if (per > 0) {
+					const int ja = j1 - me * per, jz = ja - per;
+					rows(ja, max(jz, jm), false);
+					rows(min(ja, jm), jz, true);
+				}
+				const int n_grp = (jq - j0 + 7) >> 3;
+				int g = __builtin_amdgcn_readfirstlane(gv);
+				while (g < n_grp) {
+					if (lane == 0) gv = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					const int ja = jq - 8 * g, jz = max(ja - 8, j0);
+					rows(ja, max(jz, jm), false);
+					rows(min(ja, jm), jz, true);
+					g = __builtin_amdgcn_readfirstlane(gv);
+				}
+			}
 			const int sb = ((t0 >> 6) & 1) * 64;
 			if (BALLOT(cnt_l != 0) != 0) {
 				if (best_l > spv) __hip_atomic_fetch_max(&s_key2[sb + lane], (long long)(((unsigned long long)(unsigned)best_l << 32) | (unsigned)jb_l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -396,10 +493,16 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 				const int Lk = 63 - k;
 				const int dr1 = xv - 1 - rdlane(xv, Lk), dq1 = qv - 1 - rdlane(qv, Lk);
 				const int dd = absdiff(dr1, dq1);
-				const bool ok = pair_ok(dr1, dq1, dd) && dr1 != -1 && t0 + k >= lov && lane < Lk;
-				cnt_l += ok ? 1 : 0;
-				m_l |= ok ? 1ull << k : 0ull;
-				tab[k * 64 + lane] = ok ? pair_score0(dr1, dq1, dd, sp1v) : SENT;
+				const bool ok = pair_ok(dr1, dq1, dd) & (dr1 != -1) & (t0 + k >= lov) & (lane < Lk);
+				int s0 = SENT;
+				if (BALLOT(ok) != 0) {                           // (a noise candidate is nobody's: its row is SENT throughout)
+					cnt_l += ok ? 1 : 0;
+					m_l |= ok ? 1ull << k : 0ull;
+					int sc = pair_score0(dr1, dq1, dd, sp1v);
+					asm volatile("" : "+v"(sc));
+					s0 = ok ? sc : SENT;
+				}
+				tab[k * 64 + lane] = s0;
 			}
 			if (cnt_l != 0) {
 				__hip_atomic_fetch_add(&s_cnt2[((t0 >> 6) & 1) * 64 + lane], cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -414,7 +517,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			else own_table(0, cnt, wv, W, own_x, own_q, span1_l, lo_l);
 		}
 		int *const s_pair = s_pair2 + ((i0 >> 6) & 1) * (64 * 64);          // this tile's table
+		MM2C_HTICK(2);
 		__syncthreads();
+		MM2C_HTICK(3);
 #if MM2C_COOP_PROBE == 9
 		if (wv == 0) { const long long tn = wall_clock64(); tp[2] += tn - tq; tq = tn; }
 #endif
@@ -593,7 +698,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			const int jmin_n = max(max(lo_first_n, t0 - 64 * (NX - 1 + (FAR ? COOP_FAR_TILES : 0))), 0);
 			const int sp_n = (P.span_override >= 0 ? P.span_override : (int)(nxt.w & 0xff)) - 1;
 			if (jmin_n < i0) older_pairs(t0, jmin_n, i0, wv - 1, W - 1, (int)nxt.x - 1, (int)nxt.z - 1, sp_n, lo_n, false, rdlane(lo_n, 64 - min(64, n - t0)));   // (candidates from the candidate rings: their slots are final a tile before the walker reuses them)
+			MM2C_HTICK(4);
 			own_table(t0, min(64, n - t0), wv - 1, W - 1, (int)nxt.x, (int)nxt.z, sp_n, lo_n);   // x and q only: nothing of it waits for this tile's walk
+			MM2C_HTICK(5);
 		}
 #if MM2C_COOP_PROBE == 9
 		if (wv == 0) { const long long tn = wall_clock64(); tp[5] += tn - tq; tq = tn; }
@@ -601,6 +708,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		cur = nxt; cur_st = nxt_st;
 	}
 #if MM2C_COOP_PROBE == 9
+	if (lane == 0 && (wv == 1 || wv == 8 || wv == 15) && task == 0) printf("coop helper wave %d ticks: prologue %lld, at barrier 1 %lld, A2 %lld, at barrier 2 %lld, A1 %lld, table %lld\n", wv, th[0], th[1], th[2], th[3], th[4], th[5]);
 	if (threadIdx.x == 0 && task == 0) printf("coop ticks (100 MHz) n=%d: to barrier1 %lld, A2 %lld, summary %lld, pushes %lld, rest of B %lld, tile end %lld\n", n, tp[1], tp[2], tp[3], tp[4], tp[5], tp[0]);
 #endif
 }

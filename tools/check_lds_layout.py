@@ -85,7 +85,7 @@ def check(path, verbose=False):
             if mc:
                 # chain_dp_coop<W, GS1, FAR, TAB> (csrc/chain_dp_coop.h): the same hand-written loop over Lds<COOP_NX = 16, COOP_NF = 8, false, TAB, false>, with the
                 # per-anchor summaries (two sets of a 64-bit key and a count per lane) and two tiles' pair tables (64 x 64 ints each) behind the rings INSIDE the one LDS object
-                want = lds_bytes(16, 8, 0, int(mc.group(4)), 0) + 2 * 64 * 8 + 2 * 64 * 4 + 2 * 2 * 64 * 8 + 2 * 64 * 64 * 4 + 32 * 64 * 12   # ... and (round 6) the candidate rings: x / q and f of 32 tiles
+                want = lds_bytes(16, 8, 0, int(mc.group(4)), 0) + 2 * 64 * 8 + 2 * 64 * 4 + 2 * 2 * 64 * 8 + 2 * 64 * 64 * 4 + 32 * 64 * 12 + 16   # ... and (round 6) the candidate rings: x / q and f of 32 tiles, and the group counters of phase A1
                 seen += 1
                 if verbose:
                     print(f"{triple} chain_dp_coop<{','.join(mc.groups())}>: group segment {lds} B, rings + summaries {want} B")
