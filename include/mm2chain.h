@@ -159,6 +159,11 @@ int mm2c_plan_run_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_a
  * recent mm2c_plan_run_device; synchronises on the end event.  _prepass_ms: the same for the window-start kernel
  * (chain_window_start) that runs just before it. */
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
+/* Round 6: which of the two DP kernels took the pieces of the most recent run.  A batch of few long pieces -- fewer pieces than the GPU has wave slots, BASELINE config 5's
+ * long reads -- runs with sixteen waves per piece (chain_dp_coop, the analogue of the reference's one deep pipeline per task, device/minimap2_opencl.cl:49,71), anything
+ * else with one wave per piece; with long tasks cut into pieces on the device the choice is made there (chain_route), so this call waits for the run and reads it back.
+ * pieces = the tasks, or the pieces they were cut into; one_wave_pieces + coop_pieces = pieces.  mm2c_tune("coop_plans", 0 | 1 | 2): never / every small plan / per run. */
+int mm2c_plan_last_route(mm2c_plan_t *plan, int64_t *pieces, int64_t *one_wave_pieces, int64_t *coop_pieces);
 /* Which kernel instantiation the most recent mm2c_plan_run_device launched for the tasks' first pass, as text, e.g.
  * "chain_dp_tile<NX=8,NF=2,SKIP=1,GEN=0,GS1=1,FAR=1,TAB=0> loop=asm classes=1 cut=0" (loop=asm: the hand-written per-tile loop, loop=c++: its
  * C++ restatement; chain_dp_wave<...>: the first-generation kernel).  For tests and logs: results never depend on the instantiation. */

@@ -64,7 +64,7 @@ struct Global {
 	std::atomic<size_t> direct_max_anchors{1u << 18};   // ... passes of up to this many anchors
 	std::atomic<int> pipe_coop_chunks{1};               // pipelined host batches: this many of the LAST chunks run with several waves per piece when they have few enough pieces
 	std::atomic<int> combiner_lanes{4};                 // passes of the call combiner in flight at once (1 .. 16; round 5, with direct passes: 4.60 / 4.55 / 4.65 / 4.67 / 4.78 / 4.83 s for 3 / 4 / 6 / 8 / 12 / 16 on the 120 000-read run)
-	std::atomic<int> coop_plans{0};                     // plans take the cooperative kernel too when they have few tasks (tests; default: the host-buffer entries only)
+	std::atomic<int> coop_plans{2};                     // plans and the cooperative kernel: 2 (default) per run, by coop_pays (few long pieces); 1: every plan of few tasks (tests); 0: never
 	std::atomic<int> plan_cut{1};                       // plans: cut long tasks into pieces on the device (chain_cut) before the DP
 	std::atomic<int> plan_cut_min{8192};                // ... tasks of at least this many anchors (the ones that make the tail of a batch)
 	hipStream_t stream = nullptr;           // library stream for plan runs with stream == NULL

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64 * W)
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
 {
 	constexpr int NX = COOP_NX, NF = COOP_NF;
 	constexpr bool SKIP = true, GEN = false;
@@ -210,9 +210,10 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int64_t task = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int64_t)blockIdx.x;
 	// every exit below is taken by all waves of the workgroup or by none: the conditions are the same values in every wave
 	if (task >= n_tasks) return;
+	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut) that chain_route gave to this kernel: the grid is sized for the most it may give
 	if (only_flagged && status[task] == 0) return;
 	const int64_t base0 = offsets[task];
-	const int n = __builtin_amdgcn_readfirstlane((int)(offsets[task + 1] - base0));
+	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base0));
 	// the one-word keys of the straight-line pushes (score << 7 | origin) need |score| < 2^23: at most 255 gained per link and a gap cost that cannot overflow
 	// the word either (<= gap_scale * (2.55 * bw + 17) before the shift)
 	const bool key32_ok = n < (1 << 15) && P.span_override <= 255 && P.gap_scale >= 0.f && P.gap_scale <= 4.f && P.bw <= (1 << 17);
@@ -223,6 +224,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if ((uint32_t)(uintptr_t)(void *)lds != 0) { if (threadIdx.x == 0) status[task] = 3; return; }   // cannot happen: one LDS object per kernel
 
 	const int pbase = pbase_in ? pbase_in[task] : 0;
+	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative), as in chain_dp_tile
 	float avg = avg_in ? avg_in[task] : -1.0f;
 	if (avg < 0.f) {
 		uint64_t sum = 0;
@@ -272,12 +274,12 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #define MM2C_HTICK(K) do {} while (0)
 #endif
 	uint4 cur = (rl < n) ? a[rl] : make_uint4(0, 0, 0, 0);
-	int cur_st = (rl < n) ? st[rl] : 0;
+	int cur_st = (rl < n) ? st[rl] - st_sub : 0;
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int idx = i0 + rl;
 		const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - i0));
 		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
-		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64]; }
+		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64] - st_sub; }
 		int prev_last = rdlane(own_x, 0);
 		own_x = (int)cur.x; own_q = (int)cur.z;
 		own_g = (cur.w >> 16) & 0xff;

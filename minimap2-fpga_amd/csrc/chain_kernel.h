@@ -27,7 +27,8 @@ struct CutArgs {
 	int32_t seg_min = 256;
 	int32_t min_anchors = 8192;     // only tasks at least this long are cut: the others do not make the tail
 	int64_t *d_start = nullptr, *d_end = nullptr;
-	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;
+	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;   // d_count: three words -- [0] pieces cut, [1] / [2] the pieces chain_route gives to the one-wave / the cooperative kernel
+	int32_t *d_live = nullptr;      // the count the one-wave kernels go by (nullptr: d_count; under the device-side route: d_count + 1)
 	int32_t *d_has_cut = nullptr;   // per task (n_tasks entries), zero on entry: set by the prepass where a window is empty
 	float *d_avg = nullptr;
 	uint8_t *d_cls = nullptr;       // per piece: ring-size class of its task (nullptr: no classes)
@@ -60,6 +61,7 @@ struct LaunchArgs {
 	int32_t *d_status;          // per task, must be zero on entry
 	int64_t max_task_anchors = 0;   // length of the longest task when the caller knows it (0: unknown): lets a small pass size a grid of one block per 256 anchors (chain_window_start_wide)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
+	                            // < 0 (with a device-side cut): decided on the device once the pieces are known (chain_route): few long pieces -> the cooperative kernel
 	int force_tab = 0;          // 1: the gap-cost table of the tile kernel also for gap_scale == 1 (mm2c_tune("force_tab"); slower, kept for the parity tests)
 	int ring_class;             // 3: tile kernel (general variant: first-generation kernel); 4: tile kernel for every variant; 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
 	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
@@ -77,7 +79,14 @@ struct LaunchInfo {
 	int q24;         // class-1 tasks (long ring) run the instantiation with the q24 ring (chain_dp_tile.h, Lds<> RING 2) instead of 32-bit slots
 	int cut;         // tasks are cut into pieces on the device first
 	int coop;        // waves per task of the cooperative kernel (chain_dp_coop), 0: one wave per task
+	int route_auto;  // 1: which of the two ran is decided on the device after the cut (chain_route; CutArgs::d_count[1], [2] say which)
 };
+constexpr int COOP_ROUTE_MAX_PIECES = 2048;   // the cooperative kernel is only considered for batches of at most this many pieces
+// few long pieces -> several waves per piece.  One wave per piece is bound by its longest piece (about 0.7 us per anchor); the cooperative kernel by the anchors a CU
+// is dealt (about 0.1 us per anchor: total / 256 + the longest piece at worst): 7 Lmax > 1.05 (total / 256 + Lmax)  <=>  1450 Lmax > total (measured on long ava-ont
+// reads, round 6: 2 048 x 100 000 anchors 80 ms / 94 ms, 1 020 x 300 000 210 / 127, 255 x 10^6 618 / 102 for one wave / sixteen)
+__host__ __device__ inline bool coop_pays(long long n_pieces, long long longest, long long total) { return n_pieces > 0 && n_pieces <= COOP_ROUTE_MAX_PIECES && 1450ll * longest > total; }
+
 
 int chain_ring_anchors(int ring_class);
 // label counters of the hand-written loop (builds with -DMM2C_LABEL_COUNT only; hipErrorNotSupported otherwise): 8 rows (compact << 2 | table << 1 | far) x 32 labels

@@ -44,6 +44,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
 #include <stdint.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -366,16 +367,25 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 // The same window starts for a pass of few tasks (a lone call: one block above would walk the task's tiles one after the other, 25 us for 5 000 anchors, while the
 // GPU is empty): one block per 256 anchors of a task, blockIdx.y = the tile, every lane a binary search over the task's sorted x in memory -- the tiles do not wait for
 // one another, the answers are the same by construction (the same bounds [max(i - max_iter, 0), i], the same condition).  Only st[]: no classes, no avg, no cut flags.
+// span_sum (optional, one zeroed word per task): the block adds the spans of its anchors (chain.c:48: a[i].y >> 32 & 0xff) -- chain_avg_finish turns the sums into
+// avg_qspan_scaled in place.  (A task of up to 2^22 anchors: the sum fits 32 bits.)
 __global__ void __launch_bounds__(256)
-chain_window_start_wide(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all)
+chain_window_start_wide(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all,
+                        unsigned *__restrict__ span_sum)
 {
 	const int64_t task = (int64_t)blockIdx.x;
 	if (task >= n_tasks) return;
 	const int64_t base = offsets[task];
 	const int n = (int)(offsets[task + 1] - base);
+	if ((int)blockIdx.y * 256 >= n) return;
 	const int i = (int)blockIdx.y * 256 + (int)threadIdx.x;
-	if (i >= n) return;
 	const ulonglong2 *a = a_all + base;
+	if (span_sum) {
+		unsigned v = i < n ? (unsigned)(a[i].y >> 32) & 0xffu : 0u;
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&span_sum[task], v);
+	}
+	if (i >= n) return;
 	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
 	const uint64_t xi = a[i].x;
 	int hi = i, lo = max(i - P.max_iter, 0);                          // answer in [lo, hi]; x_i <= x_i + D always holds
@@ -384,6 +394,38 @@ chain_window_start_wide(KParams P, int64_t n_tasks, const int64_t *__restrict__ 
 		if (xi > a[mid].x + D) lo = mid + 1; else hi = mid;           // chain.c:192 condition for "++st"
 	}
 	st_all[base + i] = lo;
+}
+
+// Which kernel takes the pieces of a batch, decided where the pieces are known: chain_cut has just counted them.  Few long pieces (coop_pays, chain_kernel.h) go to the
+// cooperative kernel, anything else to one wave per piece; both kernels are launched, each goes by its own count word and the one that was not chosen finds 0 there.
+__global__ void __launch_bounds__(256)
+chain_route(CutArgs C)
+{
+	__shared__ unsigned long long s_tot;
+	__shared__ int s_max;
+	const int n = *C.d_count;
+	if (n > COOP_ROUTE_MAX_PIECES) { if (threadIdx.x == 0) { C.d_count[1] = n; C.d_count[2] = 0; } return; }
+	if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
+	__syncthreads();
+	unsigned long long tot = 0; int mx = 0;
+	for (int p = (int)threadIdx.x; p < n; p += 256) { const int len = (int)(C.d_end[p] - C.d_start[p]); tot += (unsigned long long)len; mx = max(mx, len); }
+	atomicAdd(&s_tot, tot); atomicMax(&s_max, mx);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const bool coop = coop_pays(n, s_max, (long long)s_tot);
+		C.d_count[1] = coop ? 0 : n; C.d_count[2] = coop ? n : 0;
+	}
+}
+
+// avg_qspan_scaled (chain.c:48-49: .01 * (float)sum / n, the product and the quotient in double, rounded to float) from the span sums of chain_window_start_wide, in place
+__global__ void __launch_bounds__(256)
+chain_avg_finish(int64_t n_tasks, const int64_t *__restrict__ offsets, unsigned *__restrict__ sum_avg)
+{
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= n_tasks) return;
+	const int64_t n = offsets[t + 1] - offsets[t];
+	const unsigned sum = sum_avg[t];
+	((float *)sum_avg)[t] = n > 0 ? (float)(__dmul_rn(.01, (double)(float)sum) / (double)n) : 0.f;
 }
 
 // ---------------------------------------------------------------- ring-size classes: one class for a batch that is nearly of one kind
@@ -664,7 +706,7 @@ static hipError_t launch_tile_nx(const LaunchArgs &L, const float *d_avg, hipStr
 	if (L.cut.max_pieces > 0) {
 		hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>), dim3((unsigned)L.cut.max_pieces), dim3(64), 0, st,
 		                   L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, (const uint4 *)L.d_anchors, L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p,
-		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_count, with_cls ? (const uint8_t *)L.cut.d_cls : (const uint8_t *)nullptr, my_cls, cls_mask);
+		                   L.d_t, L.cut.d_status, only_flagged, L.cut.d_end, L.cut.d_live ? L.cut.d_live : L.cut.d_count, with_cls ? (const uint8_t *)L.cut.d_cls : (const uint8_t *)nullptr, my_cls, cls_mask);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL((chain_dp_tile<NX, NF, SKIP, GEN, GS1, FAR, TAB, C16>), dim3((unsigned)L.n_tasks), dim3(64), 0, st,
@@ -735,9 +777,21 @@ constexpr int COOP_W = 16;
 static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged)
 {
 	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);
-	const dim3 grid((unsigned)L.n_tasks), block(64 * COOP_W);
+	const dim3 block(64 * COOP_W);
+	if (L.cut.max_pieces > 0) {
+		// the pieces chain_route gave to this kernel (d_count[2] of them: at most COOP_ROUTE_MAX_PIECES, or none)
+		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
+#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
+	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
+	                                            (const int64_t *)L.cut.d_end, (const int32_t *)(L.cut.d_count + 2))
+		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
+		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
+#undef MM2C_COOP
+		return hipGetLastError();
+	}
+	const dim3 grid((unsigned)L.n_tasks);
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
-	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged)
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -828,8 +882,13 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	const bool force_tab = force_tab_env || L.force_tab != 0;
 	const bool tab = tile && (!gs1 || force_tab) && P.bw >= 0 && P.bw <= 511 && P.gap_scale > -20.f && P.gap_scale < 20.f;
 	// several waves per task: asked for by the caller for a pass of few tasks; the variants with the hand-written loop, tasks not cut on the device
-	const bool coop = L.coop_waves > 1 && tile && !want_gen && skip && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw && L.cut.max_pieces == 0;
+	const bool coop_cfg = tile && !want_gen && skip && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;
+	const bool coop = L.coop_waves > 1 && coop_cfg && L.cut.max_pieces == 0;
+	// ... or left to the device: with a cut, how many pieces there are and how long is only known there (chain_route, after chain_cut)
+	const bool coop_auto = L.coop_waves < 0 && coop_cfg && L.cut.max_pieces > 0 && L.cut.d_count != nullptr;
+	if (coop_auto) L.cut.d_live = L.cut.d_count + 1;
 	if (info) {
+		info->route_auto = coop_auto ? 1 : 0;
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
 		info->coop = coop ? COOP_W : 0;
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
@@ -846,11 +905,17 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
 	const unsigned c16_bound = tile && (!want_gen || tile_gen) ? compact_q_span(L, skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw) : 0u;
 	// a pass of few tasks that wants nothing but st[] from the prepass (the cooperative kernel: no classes; avg handed in; no cut on the device): one block per tile
-	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && L.d_avg != nullptr && L.cut.max_pieces == 0;
-	if (wide_prepass)
+	// (avg not handed in: the blocks add up the spans into the avg workspace and a small kernel finishes them -- a plan of few long tasks: 256 reads of 10^6 anchors
+	// 3.9 -> about 1 ms, one block per task walks its tiles one after the other)
+	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && (L.d_avg != nullptr || L.d_avg_ws != nullptr) && L.cut.max_pieces == 0
+	                          && (L.max_task_anchors + 255) / 256 <= 65535;
+	if (wide_prepass) {
+		unsigned *sums = L.d_avg ? nullptr : (unsigned *)L.d_avg_ws;
+		if (sums && hipMemsetAsync(sums, 0, (size_t)L.n_tasks * 4, st) != hipSuccess) return hipGetLastError();
 		hipLaunchKernelGGL(chain_window_start_wide, dim3((unsigned)L.n_tasks, (unsigned)((L.max_task_anchors + 255) / 256)), dim3(256), 0, st, P, L.n_tasks, L.d_offsets,
-		                   (const ulonglong2 *)L.d_anchors, L.d_st);
-	else
+		                   (const ulonglong2 *)L.d_anchors, L.d_st, sums);
+		if (sums) hipLaunchKernelGGL(chain_avg_finish, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_offsets, sums);
+	} else
 	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
 	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
 	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr,
@@ -870,6 +935,11 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		e = hipGetLastError();
 		if (n_launches) ++*n_launches;
 	}
+	if (e == hipSuccess && coop_auto) {
+		hipLaunchKernelGGL(chain_route, dim3(1), dim3(256), 0, st, L.cut);
+		e = hipGetLastError();
+		if (n_launches) ++*n_launches;
+	}
 	if (e == hipSuccess && ev_dp_begin) e = hipEventRecord(ev_dp_begin, st);
 	LaunchArgs L1 = L; L1.d_avg = d_avg;
 	for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
@@ -878,7 +948,9 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		const bool gen = want_gen || pass == 1;
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
+		if (pass == 1) { L.cut.d_live = nullptr; L1.cut.d_live = nullptr; }   // the pieces flagged for the general variant come from either kernel: every piece is looked at
 		if (coop && !gen) { e = launch_coop(L, d_avg, st, tab, flagged); if (n_launches) ++*n_launches; continue; }
+		if (coop_auto && !gen) { e = launch_coop(L, d_avg, st, tab, flagged); if (n_launches) ++*n_launches; }   // (and the one-wave kernels below: each goes by its own count)
 		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged, n_launches); if (n_launches) ++*n_launches; continue; }
 		if (tile) { e = launch_r<256>(L1, st, skip, gen, gs1, far_old, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {

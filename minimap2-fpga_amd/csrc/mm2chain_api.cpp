@@ -878,7 +878,8 @@ int mm2c_tune(const char *key, int value)
 		return 0;
 	}
 	if (strcmp(key, "coop_plans") == 0) {
-		G.coop_plans = value != 0;
+		if (value < 0 || value > 2) return fail(MM2C_E_ARG, "coop_plans must be 0 (never), 1 (every plan of at most coop_max_tasks tasks) or 2 (per run: few long pieces)");
+		G.coop_plans = value;
 		return 0;
 	}
 	if (strcmp(key, "coop_max_tasks") == 0) {
@@ -1050,8 +1051,17 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	HIP_TRY(hipMemsetAsync(L.d_cls_stat, 0, 32 * mm2c::CLS_STAT_SLOTS, st));
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.wide_pct = G.wide_pct; L.noskip_loop = G.noskip_loop;
 	HIP_TRY(hipMemsetAsync(pl->d_status, 0, (size_t)pl->n_tasks * 4, st));
-	// a plan of few tasks: several waves per task instead of pieces cut on the device (chain_dp_coop.h; launch_chain_dp takes it for the variants of the hand-written loop)
-	L.coop_waves = (G.coop_plans && pl->n_tasks <= G.coop_max_tasks) ? G.coop_waves.load() : 0;   // (plans: only when asked for, mm2c_tune("coop_plans", 1))
+	// Few long pieces: several waves per piece (chain_dp_coop.h; launch_chain_dp takes it for the variants of the hand-written loop).  "coop_plans" 2 (default, round 6):
+	// decided per run by coop_pays (chain_kernel.h) -- here when the tasks run as they are, on the device (chain_route) when long tasks are cut into pieces first;
+	// 1: every plan of at most coop_max_tasks tasks, uncut (the parity tests' way to the kernel); 0: never.
+	const int coop_mode = G.coop_waves.load() > 1 ? G.coop_plans.load() : 0;
+	const int64_t longest = pl->sizes_desc.empty() ? 0 : (int64_t)pl->sizes_desc[0];
+	const bool will_cut = G.plan_cut && G.seg_min > 0 && longest >= G.plan_cut_min;
+	L.coop_waves = 0;
+	if (coop_mode == 1 && pl->n_tasks <= G.coop_max_tasks) L.coop_waves = G.coop_waves.load();
+	else if (coop_mode == 2 && !will_cut && !pl->d_off_user && mm2c::coop_pays(pl->n_tasks, longest, pl->total)) L.coop_waves = G.coop_waves.load();
+	else if (coop_mode == 2 && will_cut) L.coop_waves = -1;
+	if (L.coop_waves > 1) L.max_task_anchors = longest;
 	if (L.coop_waves <= 1 && G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
 		// plan_cut_min anchors or more (they make the tail of the batch); a batch without any runs exactly as before.
@@ -1138,6 +1148,33 @@ int mm2c_plan_last_variant(mm2c_plan_t *pl, char *buf, size_t len)
 	if (!pl || !buf || len == 0) return fail(MM2C_E_ARG, "NULL argument");
 	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
 	format_variant(pl->info, buf, len);
+	return 0;
+}
+
+int mm2c_plan_last_route(mm2c_plan_t *pl, int64_t *pieces, int64_t *one_wave_pieces, int64_t *coop_pieces)
+{
+	if (!pl || !pieces || !one_wave_pieces || !coop_pieces) return fail(MM2C_E_ARG, "NULL argument");
+	if (!pl->ran) return fail(MM2C_E_ARG, "plan has not been run");
+	if (pl->info.route_auto && pl->d_cut) {
+		// decided on the device (chain_route): the three count words of the cut arena
+		DeviceScope on(pl->device);
+		HIP_TRY(on.err);
+		HIP_TRY(hipEventSynchronize(pl->ev1));
+		int32_t w[3] = {0, 0, 0};
+		HIP_TRY(hipMemcpy(w, pl->d_cut, sizeof(w), hipMemcpyDeviceToHost));
+		*pieces = w[0]; *one_wave_pieces = w[1]; *coop_pieces = w[2];
+		return 0;
+	}
+	*pieces = pl->n_tasks;
+	*one_wave_pieces = pl->info.coop ? 0 : pl->n_tasks; *coop_pieces = pl->info.coop ? pl->n_tasks : 0;
+	if (pl->info.cut && pl->d_cut) {
+		DeviceScope on(pl->device);
+		HIP_TRY(on.err);
+		HIP_TRY(hipEventSynchronize(pl->ev1));
+		int32_t w = 0;
+		HIP_TRY(hipMemcpy(&w, pl->d_cut, sizeof(w), hipMemcpyDeviceToHost));
+		*pieces = w; *one_wave_pieces = w;
+	}
 	return 0;
 }
 

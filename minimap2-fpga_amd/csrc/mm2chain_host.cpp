@@ -192,9 +192,14 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			}
 			// the LAST chunks of the pipeline: nothing follows them that could hide the length of their longest task (one wave per task: 3.5 ms for 5 000 anchors on an
 			// otherwise empty GPU, the tail of the whole batch) -- chunks of few enough pieces take several waves per piece instead ("pipe_coop_chunks": how many, 0 = none)
-			if (k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) {
-				L.coop_waves = G.coop_waves.load();
-				for (int64_t q2 = s0; q2 < s1; ++q2) L.max_task_anchors = std::max<int64_t>(L.max_task_anchors, seg_off[(size_t)q2 + 1] - seg_off[(size_t)q2]);
+			// Round 6: ANY chunk of few long pieces does (coop_pays: a chunk of long reads has fewer pieces than the GPU has wave slots).
+			{
+				int64_t longest = 0;
+				for (int64_t q2 = s0; q2 < s1; ++q2) longest = std::max<int64_t>(longest, seg_off[(size_t)q2 + 1] - seg_off[(size_t)q2]);
+				if ((k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) || (G.coop_plans.load() == 2 && mm2c::coop_pays(s1 - s0, longest, a1 - a0))) {
+					L.coop_waves = G.coop_waves.load();
+					L.max_task_anchors = longest;
+				}
 			}
 			HIP_TRY(mm2c::launch_chain_dp(L, st, &nl, nullptr, k == 0 ? &c->last_info : nullptr));
 			if (k == 0) note_host_variant(c->last_info);
@@ -231,8 +236,13 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_cls = (uint8_t *)(c->d_in + o_cls); L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat);
 	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
 	// a pass of few pieces (a lone call, a handful of combined calls) cannot fill the GPU with one wave per piece: several waves per piece (chain_dp_coop.h)
-	L.coop_waves = n_seg <= G.coop_max_tasks ? G.coop_waves.load() : 0;
-	if (L.coop_waves > 1) for (int64_t k = 0; k < n_seg; ++k) L.max_task_anchors = std::max<int64_t>(L.max_task_anchors, seg_off[(size_t)k + 1] - seg_off[(size_t)k]);
+	// (round 6: and a bigger pass of few LONG pieces, coop_pays)
+	{
+		int64_t longest = 0;
+		for (int64_t k = 0; k < n_seg; ++k) longest = std::max<int64_t>(longest, seg_off[(size_t)k + 1] - seg_off[(size_t)k]);
+		L.coop_waves = (n_seg <= G.coop_max_tasks || (G.coop_plans.load() == 2 && mm2c::coop_pays(n_seg, longest, total))) ? G.coop_waves.load() : 0;
+		if (L.coop_waves > 1) L.max_task_anchors = longest;
+	}
 	if (one_seg_each && par->n_segs <= 1 && !par->is_cdna) L.P.flags |= mm2c::KF_IGNORE_SEG;
 	int nl = 0;
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
@@ -661,6 +671,11 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 			L.cut.d_start = (int64_t *)(b + o_cstart); L.cut.d_end = (int64_t *)(b + o_cend); L.cut.d_pbase = (int32_t *)(b + o_cpb); L.cut.d_avg = (float *)(b + o_cavg);
 			L.cut.d_cls = (uint8_t *)(b + o_ccls);
 			HIP_TRY(hipMemsetAsync(b + o_cut, 0, o_cstart - o_cut, w.st));          // count, status, has_cut
+			if (G.coop_plans.load() == 2 && G.coop_waves.load() > 1) L.coop_waves = -1;   // few long pieces -> several waves per piece, decided on the device (chain_route)
+		} else if (G.coop_plans.load() == 2 && G.coop_waves.load() > 1) {
+			int64_t longest = 0;
+			for (size_t k = 0; k < nt; ++k) longest = std::max<int64_t>(longest, m_off[k + 1] - m_off[k]);
+			if (mm2c::coop_pays((int64_t)nt, longest, (int64_t)tot)) { L.coop_waves = G.coop_waves.load(); L.max_task_anchors = longest; }
 		}
 		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr, &c->last_info));
 		note_host_variant(c->last_info);

@@ -168,6 +168,12 @@ class ChainPlan:
         N.check(self.lib.mm2c_plan_last_kernel_ms(self.handle, C.byref(ms)), "mm2c_plan_last_kernel_ms")
         return ms.value
 
+    def last_route(self):
+        """(pieces, pieces run with one wave each, pieces run with sixteen waves each) of the last run -- mm2c_plan_last_route"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        N.check(self.lib.mm2c_plan_last_route(self.handle, C.byref(a), C.byref(b), C.byref(c)), "mm2c_plan_last_route")
+        return int(a.value), int(b.value), int(c.value)
+
     def last_variant(self):
         """text naming the kernel instantiation the last run launched (mm2c_plan_last_variant)"""
         buf = C.create_string_buffer(192)

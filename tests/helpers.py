@@ -24,23 +24,53 @@ def oracle_batch(par, offsets, anchors):
     return f, p
 
 
+# Which DP kernel a plan runs is decided per run since round 6 ("coop_plans" 2: few long pieces -> sixteen waves per piece, chain_dp_coop; anything else -> one wave per
+# piece, chain_dp_tile / chain_dp_wave).  The parity inputs were written against the instantiations of the one-wave kernels, and many tests assert which of them ran --
+# and nearly all of them are small batches, which the default now sends to the cooperative kernel.  So gpu_batch runs every input TWICE unless a test has pinned the
+# route itself (the `knobs` fixture notes it here): with one wave per piece (what is returned, and what `variant` names) and with the library's default route, and
+# the two results must be equal element for element.  ROUTE_LOG collects what the default chose (pieces, one-wave pieces, cooperative pieces).
+PINNED_ROUTE = None
+ROUTE_LOG = []
+
+
+def _run_plan(par, offsets, d_a, d_avg, variant):
+    import mm2chain
+    total = d_a.shape[0]
+    d_f = torch.full((total,), -77, dtype=torch.int32, device="cuda")
+    d_p = torch.full((total,), -77, dtype=torch.int32, device="cuda")
+    plan = mm2chain.ChainPlan(par, offsets)
+    plan.run(d_a, d_f, d_p, d_avg)
+    torch.cuda.synchronize()
+    if variant is not None:
+        variant.append(plan.last_variant())
+    route = plan.last_route()
+    plan.close()
+    return d_f.cpu().numpy(), d_p.cpu().numpy(), route
+
+
 def gpu_batch(par, offsets, anchors, avg=None, variant=None):
     """run the HIP path through the C ABI (plan, device-resident) and return f, p as numpy; `variant`: a list that receives the text of
     mm2c_plan_last_variant (which kernel instantiation ran)"""
     import mm2chain
     a_np = np.ascontiguousarray(anchors).view(np.int64).reshape(-1, 2)
     d_a = torch.from_numpy(a_np).cuda()
-    total = a_np.shape[0]
-    d_f = torch.full((total,), -77, dtype=torch.int32, device="cuda")
-    d_p = torch.full((total,), -77, dtype=torch.int32, device="cuda")
     d_avg = torch.from_numpy(np.asarray(avg, dtype=np.float32)).cuda() if avg is not None else None
-    plan = mm2chain.ChainPlan(par, offsets)
-    plan.run(d_a, d_f, d_p, d_avg)
-    torch.cuda.synchronize()
-    if variant is not None:
-        variant.append(plan.last_variant())
-    plan.close()
-    return d_f.cpu().numpy(), d_p.cpu().numpy()
+    if PINNED_ROUTE is not None:
+        f, p, _ = _run_plan(par, offsets, d_a, d_avg, variant)
+        return f, p
+    try:
+        mm2chain.tune("coop_plans", 0)
+        f, p, _ = _run_plan(par, offsets, d_a, d_avg, variant)
+    finally:
+        mm2chain.tune("coop_plans", 2)
+    f2, p2, route = _run_plan(par, offsets, d_a, d_avg, None)
+    ROUTE_LOG.append(route)
+    bad = np.nonzero((f != f2) | (p != p2))[0]
+    if bad.size:
+        i = int(bad[0])
+        raise AssertionError(f"the library's default route (pieces {route[0]}: {route[1]} with one wave, {route[2]} with sixteen) differs from one wave per piece at "
+                             f"{bad.size} of {f.size} anchors; first at {i}: f {f2[i]} vs {f[i]}, p {p2[i]} vs {p[i]}")
+    return f, p
 
 
 def assert_same(f, p, f_ref, p_ref, offsets=None, what=""):

@@ -962,9 +962,16 @@ def test_hip_equals_the_references_own_device_kernel(knobs):
 def knobs():
     """tuning knobs a test changes, put back afterwards (results never depend on them; the instantiation that runs does)"""
     import mm2chain
-    yield mm2chain.tune
+    import helpers
+
+    def tune(key, val):
+        if key == "coop_plans":
+            helpers.PINNED_ROUTE = val                        # (gpu_batch then runs the input once, as pinned, instead of on both routes)
+        return mm2chain.tune(key, val)
+    yield tune
+    helpers.PINNED_ROUTE = None
     for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
-                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 0), ("coop_waves", 8), ("coop_max_tasks", 1024), ("q24_ring", 1)):
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 2), ("coop_waves", 16), ("coop_max_tasks", 1024), ("q24_ring", 1)):
         mm2chain.tune(key, val)
 
 
@@ -1196,9 +1203,13 @@ def test_big_host_batch_is_pipelined_in_chunks():
     f_ref, p_ref = oracle_batch(P, off, a)
     mm2chain.tune("pipeline_chunk_anchors", 300000)          # force the chunked two-stream path at this size
     try:
+        f, p = mm2chain.chain_batch_host(P, off, a)          # (chunks of about 85 pieces: the default route gives each piece sixteen waves)
+        assert_same(f, p, f_ref, p_ref, off, "big pageable batch, pipelined, default route")
+        assert "chain_dp_coop" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+        mm2chain.tune("coop_plans", 0); mm2chain.tune("pipe_coop_chunks", 0)
         f, p = mm2chain.chain_batch_host(P, off, a)
     finally:
-        mm2chain.tune("pipeline_chunk_anchors", 20 << 20)
+        mm2chain.tune("pipeline_chunk_anchors", 20 << 20); mm2chain.tune("coop_plans", 2); mm2chain.tune("pipe_coop_chunks", 1)
     assert_same(f, p, f_ref, p_ref, off, "big pageable batch, pipelined")
     if mm2chain.device_count() == 1:                         # (with MM2C_DEVICES naming several slots the batch is split first and its parts are too small for the pipeline)
         assert "compact=1" in mm2chain.last_host_variant() and "loop=asm" in mm2chain.last_host_variant(), mm2chain.last_host_variant()   # the chunks have the prepass classes
