@@ -252,6 +252,7 @@ def main():
                          "sharding.shard_tasks (longest first, on anchors per task) and gathered into a rank-local CSR batch; "
                          "value = anchors of the whole batch / max-over-ranks time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (extra launches); used when profiling")
+    ap.add_argument("--no-long", action="store_true", help="skip the long-read leg (BASELINE config 5's regime: 1e5 .. 1e6 anchors per read, about half a minute)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end map-ont leg (three host processes over a synthetic genome, about half a minute)")
     ap.add_argument("--e2e-reads", type=int, default=120000)
     ap.add_argument("--e2e-genome-mb", type=float, default=50.0)
@@ -565,6 +566,20 @@ def main():
                                        "sample": "same call with anchors and outputs in page-locked host memory (mm2c_pinned_alloc): chunks uploaded back to back on one stream, "
                                                  "their kernels and downloads on three compute streams in turn",
                                        "matches_resident": bool(np.array_equal(pf.array, fh) and np.array_equal(pp.array, ph))}
+        # ---- long reads (round 6; BASELINE config 5's regime, SURVEY 8 a1: 1e5 .. 1e6 anchors per task): batches with fewer tasks than the GPU has wave slots, at the
+        # anchor density of the ava-ont stream, -x ava-ont scalars.  DP through a plan on the library's default route (which kernel took the pieces is reported) and the
+        # seed-hit path; f / p and the sorted anchors of the first reads against the oracle.  tools/long_reads.py is the same measurement with every route.
+        if not args.no_long and args.preset == "map-ont":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import long_reads
+            lr = {"what": "DP (prepass + kernel, HIP events) and seed hits -> sorted anchors on synthetic long reads: mixed profile at 50 anchors per kb (locus = 20 x anchors per read), "
+                          "-x ava-ont scalars (max_dist 10000, bw 2000), HBM-resident, best of 3; a few distinct reads replicated into separate memory", "sizes": []}
+            for reads_l, per_l in ((2048, 100000), (1024, 300000), (256, 1000000)):
+                r_l = long_reads.measure(reads_l, per_l, routes=("auto",), reps=3, check=1)
+                lr["sizes"].append({"reads": r_l["reads"], "anchors_per_read": per_l, "dp": r_l["dp"]["auto"], "seed_hits": r_l["seed_hits"]})
+            lr["dp_min_value"] = min(s_["dp"]["value"] for s_ in lr["sizes"]); lr["seed_hits_min_value"] = min(s_["seed_hits"]["value"] for s_ in lr["sizes"])
+            lr["verified_vs_oracle"] = bool(all(s_["dp"]["identical_to_oracle"] and s_["seed_hits"]["identical_to_oracle"] for s_ in lr["sizes"]))
+            out["long_reads"] = lr
     except StopIteration:
         pass
     except Exception as e:                                                   # never let a secondary figure break the line

@@ -101,12 +101,19 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	pl->total = n_reads ? h_anchor_off[n_reads] - h_anchor_off[0] : 0;
 	pl->n_matches = n_reads ? h_match_off[n_reads] - h_match_off[0] : 0;
 	const size_t nr = (size_t)std::max<int64_t>(n_reads, 1), tot = (size_t)std::max<int64_t>(pl->total, 1);
-	const bool big = biggest > mm2c::seed_tie_lds_max();
+	// The tie replay of a read of 12 289 .. 131 072 anchors runs on eight waves with its digits in LDS -- one read per CU (up to 141 KB) --, which is the way for the few
+	// long reads of a mapping batch; a batch that is MADE of such reads (an all-vs-all chunk: thousands of them) is better off with one wave per read and the digits in
+	// memory, eight and more reads in flight per CU: 2 048 reads of 10^5 anchors 97 -> 44 ms (round 6, profiles/r6_long_reads.md).
+	int64_t n_mid = 0;
+	for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; n_mid += cap > mm2c::seed_tie_mid_lower() && cap <= mm2c::seed_tie_lds_max(); }
+	int64_t tie_global_above = mm2c::seed_tie_lds_max();
+	{ const char *tg = getenv("MM2C_TIE_GLOBAL_ABOVE"); if (tg) tie_global_above = std::max(64, atoi(tg)); else if (n_mid > 512) tie_global_above = mm2c::seed_tie_mid_lower(); }
+	const bool big = biggest > tie_global_above;
 	size_t at = 0;
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_moff = take((nr + 1) * 8), o_aoff = take((nr + 1) * 8), o_ord = take(nr * 4), o_stat = take(nr * 4), o_ties = take(nr * 4),
 	             o_stack = take(4 * (tot / 64 + 2 * nr + 2) * 4), o_un = take(tot * 16), o_scr = take(tot * 16), o_tc = take(tot * 4), o_xd = take(nr * 8),
-	             o_bid = take(tot * 4), o_bdg = take(big ? tot + nr : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
+	             o_bid = take(tot * 4), o_bdg = take(big ? tot + nr + 64 : 1), o_cnt = take(nr * 4), o_oo = take((nr + 1) * 8);
 	pl->device = cur_device();
 	DeviceScope on(pl->device);
 	hipError_t e = on.err;
@@ -138,8 +145,10 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 	{
 		const int64_t *lower = mm2c::seed_tie_class_lower();                     // a read keeps at most its capacity: these bound the grids of the classes
 		const int64_t sort_cap = mm2c::seed_sort_lds_cap0(), sort_cap2 = mm2c::seed_sort_lds_cap();
-		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 6; ++k) S.n_above[k] += cap > lower[k]; S.n_sort_big += cap > sort_cap; S.n_sort_huge += cap > sort_cap2; }
+		S.tie_global_above = tie_global_above;
+		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 5; ++k) S.n_above[k] += cap > lower[k]; S.n_above[5] += cap > tie_global_above; S.n_sort_big += cap > sort_cap; S.n_sort_huge += cap > sort_cap2; }
 		{ const char *ls = getenv("MM2C_LDS_SORT"); if (ls) S.lds_sort = atoi(ls) != 0; }
+		{ const char *ms = getenv("MM2C_MW_SORT"); if (ms) S.mw_sort = atoi(ms) != 0; }
 	}
 	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);
 	return pl;

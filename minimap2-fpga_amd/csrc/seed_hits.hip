@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64) void seed_sort(SeedArgs A)
 	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
 	const int kb = b0 + b1 + bs, idb = na > 1 ? 32 - __clz(na - 1) : 1;
 	if (A.lds_sort && A.d_anchor_off[read + 1] - a0 <= SORT_LDS_CAP && kb <= 32) return;   // seed_sort_lds has sorted this read (it goes by the read's capacity: the launch order does)
+	if (A.mw_sort && A.d_anchor_off[read + 1] - a0 > SORT_LDS_CAP && kb + idb <= 64) return;   // seed_sort_mw takes it (long reads: sixteen waves)
 	int run = 0;
 	if (kb + idb <= 64) {
 		uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;                        // the two halves of the 16-byte-per-anchor scratch
@@ -496,6 +497,61 @@ __device__ uint64_t *block_sort_keys(uint64_t *a, uint64_t *b, int n, int bit_lo
 	return from;
 }
 
+// ---- kernel 2b (round 6): seed_sort for LONG reads (capacity beyond SORT_LDS_CAP) on the sixteen waves of a workgroup --------------------------------------
+// One wave sorting a read of 10^5 .. 10^6 anchors through global memory sets the time of a whole batch of long reads (BASELINE config 5: 256 reads of 10^6 anchors
+// 55 ms, one read per CU and fifteen sixteenths of every CU idle).  The same keys ((differing bits of x, squeezed) << id bits | position), the same stable LSD
+// passes through the read's 16 bytes of scratch per anchor -- block_sort_keys: per step of 1 024 records every wave ranks its own 64 and publishes its per-digit
+// counts --, the same gather, srt[] and prefix count of equal neighbours as seed_sort leaves them (what the tie replay reads): a stable sort of distinct
+// (key, position) pairs has one result, whoever computes it.  Reads whose keys do not fit 64 bits keep seed_sort's whole-anchor fall-back.
+constexpr int SORT_MW_WAVES = 16;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void seed_sort_mw(SeedArgs A)
+{
+	constexpr int NT = 64 * NW;
+	__shared__ int s_cnt[256], s_w[256 * NW], s_carry[NW + 1];
+	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const ReadGeom g = read_geom(A, read);
+	const int64_t a0 = g.a0;
+	const int na = g.na;
+	if (A.d_anchor_off[read + 1] - a0 <= SORT_LDS_CAP) return;                   // by capacity, as the launch order and seed_sort's test
+	if (A.status[read] != 0 || na == 0) { if (tid == 0) A.has_ties[read] = 0; return; }
+	const uint64_t diff = A.xdiff[read];
+	const uint32_t dlo = (uint32_t)diff, dhi = (uint32_t)(diff >> 32) & 0x7fffffffu;
+	const int b0 = dlo ? 32 - __clz((int)dlo) : 0, b1 = dhi ? 32 - __clz((int)dhi) : 0, bs = (int)(diff >> 63);   // position, target id, strand
+	const int kb = b0 + b1 + bs, idb = na > 1 ? 32 - __clz(na - 1) : 1;
+	if (kb + idb > 64) return;                                                   // seed_sort sorts the anchors themselves
+	const ulonglong2 *un = A.unsorted + a0;
+	ulonglong2 *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
+	int32_t *tiecnt = A.tiecnt + a0;
+	uint32_t *srt = A.tie_id + a0;
+	uint64_t *ka = (uint64_t *)tmp, *kbuf = ka + na;
+	const uint64_t m0 = b0 >= 32 ? 0xffffffffull : (1ull << b0) - 1, m1 = (1ull << b1) - 1;
+	for (int i = tid; i < na; i += NT) {
+		const uint64_t x = un[i].x;
+		ka[i] = ((x & m0) | (((x >> 32) & m1) << b0) | (bs ? (x >> 63) << (b0 + b1) : 0)) << idb | (uint64_t)i;   // order preserving: the dropped bits are constant
+	}
+	__syncthreads();
+	const uint64_t *ks = block_sort_keys<NW>(ka, kbuf, na, idb, kb, tid, s_cnt, s_w);
+	const uint64_t idm = (1ull << idb) - 1;
+	int run = 0;
+	for (int i0 = 0; i0 < na; i0 += NT) {
+		const int i = i0 + tid;
+		const uint64_t k = i < na ? ks[i] : 0, kn = i + 1 < na ? ks[i + 1] : ~0ull;
+		if (i < na) { out[i] = un[(int)(k & idm)]; srt[i] = (uint32_t)(k & idm); }
+		const int flag = (i + 1 < na && (k >> idb) == (kn >> idb)) ? 1 : 0;
+		const int incl = wave_incl_scan(flag, lane);
+		if (lane == 63) s_carry[wave + 1] = incl;
+		__syncthreads();
+		int before = run;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) { const int c = s_carry[w + 1]; before += w < wave ? c : 0; run += c; }
+		if (i < na) tiecnt[i] = before + incl - flag;
+		__syncthreads();
+	}
+	if (tid == 0) A.has_ties[read] = run > 0 ? 1 : 0;
+}
+
 // ---- kernel 3: replay of radix_sort_128x for reads with equal x (radix_replay.h) -----------------------------------
 // The sequential part of the replay (the walk of replay_walk) reads digits only, so a read needs ONE byte of LDS per anchor (the index
 // array, the permutation of a pass and the lists of the closed form live in global memory and are touched by all lanes); size classes keep
@@ -513,7 +569,8 @@ template <int CAP, int PREV, int NW>
 __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TIE_CAP0 ? 4 : 5) void seed_ties(SeedArgs A)   // one-wave classes: five waves per SIMD (102 VGPRs), as many reads in flight as their LDS allows
 {
 	__shared__ __attribute__((aligned(8))) uint8_t s_dg[CAP + 8];            // (the walk looks one byte beyond the digit it takes)
-	__shared__ __attribute__((aligned(8))) int s_cur[576 * NW];
+	constexpr int SC = 576;                                                      // ints of replay tables per wave
+	__shared__ __attribute__((aligned(8))) int s_cur[SC * NW];
 	__shared__ int s_lo[257 * NW], s_n[2];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
@@ -521,7 +578,8 @@ __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TI
 	const ReadGeom g = read_geom(A, read);
 	const int64_t a0 = g.a0;
 	const int na = g.na;
-	if (na <= 64 || na <= PREV || (CAP && na > CAP)) return;                     // <= 64: insertion sort only, stable (ksort.h:149)
+	if (na <= 64 || (CAP ? na <= PREV || na > CAP || na > A.tie_global_above : na <= A.tie_global_above)) return;   // <= 64: insertion sort only, stable (ksort.h:149); the bound between
+	                                                                             // the LDS classes and the one with the digits in memory moves with the batch (launch_seed_hits' caller)
 	if (A.debug_cut == 1) return;
 	ulonglong2 *un = A.unsorted + a0, *tmp = A.scratch + a0, *out = A.d_anchors + g.o0;
 	// The replay leaves an arrangement id[] (position -> anchor of the unsorted array).  The reference's array is the stable sort of that
@@ -551,8 +609,8 @@ __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TI
 		const int32_t *tiecnt = A.tiecnt + a0;
 		int32_t *inv = w, *place = w + na;
 		const int lane = tid & 63, wave = tid >> 6;
-		int *winp = CAP ? (int *)(s_dg + (CAP / NW) * wave) : s_cur + 576 * wave;
-		uint16_t *wint = CAP ? (uint16_t *)(s_cur + 576 * wave) : (uint16_t *)(s_lo + 257 * wave);
+		int *winp = CAP ? (int *)(s_dg + (CAP / NW) * wave) : s_cur + SC * wave;
+		uint16_t *wint = CAP ? (uint16_t *)(s_cur + SC * wave) : (uint16_t *)(s_lo + 257 * wave);
 		for (int q = tid; q < na; q += 64 * NW) inv[id[q]] = q;
 		__syncthreads();
 		for (int i = tid; i < na; i += 64 * NW) place[i] = inv[srt[i]];
@@ -705,6 +763,8 @@ __global__ __launch_bounds__(64) void seed_heap(SeedArgs A)
 } // namespace
 
 int seed_tie_lds_max() { return TIE_CAP4; }
+int seed_tie_mid_lower() { return TIE_CAP2; }
+static int64_t lower_of_class(int c) { static const int64_t lower[6] = { 64, TIE_CAP0, TIE_CAP1, TIE_CAP2, TIE_CAP3, TIE_CAP4 }; return lower[c]; }
 int seed_sort_lds_cap() { return SORT_LDS_CAP; }
 int seed_sort_lds_cap0() { return SORT_LDS_CAP0; }
 const int64_t *seed_tie_class_lower()
@@ -741,6 +801,11 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 			if (n_launches) ++*n_launches;
 		}
 	}
+	if (A.mw_sort && (A.d_order ? A.n_sort_huge : (int64_t)nr) > 0) {            // long reads: sixteen waves each (the first workgroups of the launch order)
+		hipLaunchKernelGGL((seed_sort_mw<SORT_MW_WAVES>), dim3(A.d_order ? (unsigned)A.n_sort_huge : nr), dim3(64 * SORT_MW_WAVES), 0, st, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (n_launches) ++*n_launches;
+	}
 	hipLaunchKernelGGL(seed_sort, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (n_launches) *n_launches += 2;
@@ -759,6 +824,7 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	int helper = 0;
 	for (int c = 5; c >= 0; --c) {
 		if (grid[c] == 0 || (c == 5 && !A.big_dg)) continue;
+		if (c < 5 && lower_of_class(c) >= A.tie_global_above) continue;             // the whole class has gone to the kernel with the digits in memory
 		hipStream_t s = st;
 		if (c != 0 && aux) {
 			const int h = helper++ % 3;
