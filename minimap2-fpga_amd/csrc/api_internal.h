@@ -62,6 +62,9 @@ struct Global {
 	                                                    // service time of the slot; 2: round 5's rule (booked predictions).  MM2C_DECLINE_WHEN_BUSY / mm2c_tune opt in.
 	std::atomic<int> direct_pass{1};                    // small staged passes: the two copies are kernels and the host polls a flag word (host_stage.hip; 0: copy commands + stream wait)
 	std::atomic<size_t> direct_max_anchors{1u << 18};   // ... passes of up to this many anchors
+	std::atomic<int> host_st{0};                        // ... bring their window starts along, computed by the host while it stages the anchors (no prepass launch).  Off: measured on the
+	                                                    // end-to-end run it trades 4.3 us of submission for 8 us of host sweep per pass (profiles/r6_per_read.md); mm2c_tune("host_st", 1) turns it on
+	std::atomic<int> fused_out{1};                      // ... that end in the cooperative kernel: the kernel writes f / p to the result buffer and raises the flag itself (no stage_out launch)
 	std::atomic<int> pipe_coop_chunks{1};               // pipelined host batches: this many of the LAST chunks run with several waves per piece when they have few enough pieces
 	std::atomic<int> combiner_lanes{4};                 // passes of the call combiner in flight at once (1 .. 16; round 5, with direct passes: 4.60 / 4.55 / 4.65 / 4.67 / 4.78 / 4.83 s for 3 / 4 / 6 / 8 / 12 / 16 on the 120 000-read run)
 	std::atomic<int> coop_plans{2};                     // plans and the cooperative kernel: 2 (default) per run, by coop_pays (few long pieces); 1: every plan of few tasks (tests); 0: never

@@ -190,12 +190,35 @@ __device__ __forceinline__ void coop_rows4_d1(bool edge, int lds_xq, int lds_f, 
 #undef MM2C_CROW
 #undef MM2C_CROWS_BODY
 
+// Round 6: a small per-read pass (mm2chain_host.cpp, the reference's call pattern chain_hardware.cpp:104-189) ends in this kernel -- it used to end in a fourth launch,
+// stage_out, that copied f / p to the caller's page-locked buffer and raised the flag the caller polls.  The walker stores every finished tile to the host buffer as
+// well as to the device arrays (the device copy is what the exact scans re-read), and the last workgroup to finish raises the flag behind a system-scope fence,
+// exactly as stage_out did (host_stage.hip).  Only for a pass whose tasks cannot be flagged for the general variant (segment ids ignored): nothing rewrites f / p then.
+struct CoopHostOut {
+	int32_t *f = nullptr, *p = nullptr;       // the caller's result buffer (page-locked, mapped), indexed like f_all / p_all; nullptr: device arrays only
+	unsigned *d_done = nullptr;               // workgroups finished (zeroed by stage_in of the same pass)
+	unsigned *h_flag = nullptr; unsigned seq = 0;
+};
+__device__ __forceinline__ void coop_host_done(const CoopHostOut &H)
+{
+	if (!H.h_flag) return;
+	__threadfence_system();                                  // this wave's stores to the host have left before the workgroup is counted (the walker is wave 0)
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const unsigned done = __hip_atomic_fetch_add(H.d_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (done == gridDim.x - 1) {
+			__threadfence_system();
+			__hip_atomic_store(H.h_flag, H.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
 template <int W, bool GS1, bool FAR, bool TAB>
 __global__ void __launch_bounds__(64 * W)
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H)
 {
 	constexpr int NX = COOP_NX, NF = COOP_NF;
 	constexpr bool SKIP = true, GEN = false;
@@ -209,7 +232,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int64_t task = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int64_t)blockIdx.x;
 	// every exit below is taken by all waves of the workgroup or by none: the conditions are the same values in every wave
-	if (task >= n_tasks) return;
+	if (task >= n_tasks) { coop_host_done(H); return; }
 	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut) that chain_route gave to this kernel: the grid is sized for the most it may give
 	if (only_flagged && status[task] == 0) return;
 	const int64_t base0 = offsets[task];
@@ -217,11 +240,12 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	// the one-word keys of the straight-line pushes (score << 7 | origin) need |score| < 2^23: at most 255 gained per link and a gap cost that cannot overflow
 	// the word either (<= gap_scale * (2.55 * bw + 17) before the shift)
 	const bool key32_ok = n < (1 << 15) && P.span_override <= 255 && P.gap_scale >= 0.f && P.gap_scale <= 4.f && P.bw <= (1 << 17);
-	if (n <= 0) return;
+	if (n <= 0) { coop_host_done(H); return; }
 	const uint4 *a = a_all + base0;
 	const int32_t *st = st_all + base0;
 	int32_t *f = f_all + base0, *p = p_all + base0, *t = FAR ? t_all + base0 : nullptr;
-	if ((uint32_t)(uintptr_t)(void *)lds != 0) { if (threadIdx.x == 0) status[task] = 3; return; }   // cannot happen: one LDS object per kernel
+	if ((uint32_t)(uintptr_t)(void *)lds != 0) { if (threadIdx.x == 0) status[task] = 3; coop_host_done(H); return; }   // cannot happen: one LDS object per kernel
+	int32_t *const hf = H.f ? H.f + base0 : nullptr, *const hp = H.p ? H.p + base0 : nullptr;
 
 	const int pbase = pbase_in ? pbase_in[task] : 0;
 	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative), as in chain_dp_tile
@@ -285,7 +309,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		own_g = (cur.w >> 16) & 0xff;
 		if (!(P.flags & KF_IGNORE_SEG)) {
 			if (i0 == 0) seg0 = rdlane(own_g, 63);
-			if (BALLOT(rl < cnt && own_g != seg0)) { if (threadIdx.x == 0) status[task] = 1; return; }   // (every wave sees the same tile: all leave together)
+			if (BALLOT(rl < cnt && own_g != seg0)) { if (threadIdx.x == 0) status[task] = 1; coop_host_done(H); return; }   // (every wave sees the same tile: all leave together)
 		}
 		const int stamp_lo = i0 - 64 * (NX - 1);
 		if (wv == 0) {
@@ -682,7 +706,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #endif
 			if (!all_done) flush(64);
 			// ---- the finished tile: results leave in coalesced stores and enter the f / p ring
-			if (rl < cnt) { f[idx] = own_f; p[idx] = own_p < 0 ? own_p : own_p + pbase; }
+			if (rl < cnt) {
+				const int pv = own_p < 0 ? own_p : own_p + pbase;
+				f[idx] = own_f; p[idx] = pv;
+				if (hf) { hf[idx] = own_f; hp[idx] = pv; }          // a per-read pass: straight to the caller's buffer as well
+			}
 			const int o = (idx << 3) & LY::FMASK;
 			*(int2 *)(lds + LY::FP + o) = make_int2(own_f - FBIAS, own_p);
 			// ... and the candidate rings of phase A (the slots of the tile COOP_NC back: the last rows that read them were dealt a tile ago, for this very tile)
@@ -709,6 +737,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #endif
 		cur = nxt; cur_st = nxt_st;
 	}
+	coop_host_done(H);
 #if MM2C_COOP_PROBE == 9
 	if (lane == 0 && (wv == 1 || wv == 8 || wv == 15) && task == 0) printf("coop helper wave %d ticks: prologue %lld, at barrier 1 %lld, A2 %lld, at barrier 2 %lld, A1 %lld, table %lld\n", wv, th[0], th[1], th[2], th[3], th[4], th[5]);
 	if (threadIdx.x == 0 && task == 0) printf("coop ticks (100 MHz) n=%d: to barrier1 %lld, A2 %lld, summary %lld, pushes %lld, rest of B %lld, tile end %lld\n", n, tp[1], tp[2], tp[3], tp[4], tp[5], tp[0]);

@@ -62,6 +62,10 @@ struct LaunchArgs {
 	int64_t max_task_anchors = 0;   // length of the longest task when the caller knows it (0: unknown): lets a small pass size a grid of one block per 256 anchors (chain_window_start_wide)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
 	                            // < 0 (with a device-side cut): decided on the device once the pieces are known (chain_route): few long pieces -> the cooperative kernel
+	// a small per-read pass that ends in the cooperative kernel (round 6): f / p also go straight to the caller's page-locked buffer and the last workgroup raises the
+	// flag the caller polls (what stage_out did in a launch of its own, host_stage.hip); taken only when that kernel is the pass's one DP launch (LaunchInfo::host_out)
+	int32_t *h_f = nullptr, *h_p = nullptr; unsigned *d_done = nullptr, *h_flag = nullptr; unsigned seq = 0;
+	int st_ready = 0;           // 1: d_st already holds the window starts (a per-read pass computes them on the host while it stages the anchors): no prepass for the cooperative kernel
 	int force_tab = 0;          // 1: the gap-cost table of the tile kernel also for gap_scale == 1 (mm2c_tune("force_tab"); slower, kept for the parity tests)
 	int ring_class;             // 3: tile kernel (general variant: first-generation kernel); 4: tile kernel for every variant; 0 / 1 / 2: first-generation kernel with 256 / 512 / 1024 anchors of LDS ring
 	CutArgs cut;                // plans: cut the tasks into independent pieces on the device first
@@ -79,6 +83,7 @@ struct LaunchInfo {
 	int q24;         // class-1 tasks (long ring) run the instantiation with the q24 ring (chain_dp_tile.h, Lds<> RING 2) instead of 32-bit slots
 	int cut;         // tasks are cut into pieces on the device first
 	int coop;        // waves per task of the cooperative kernel (chain_dp_coop), 0: one wave per task
+	int host_out;    // 1: the cooperative kernel wrote f / p to the caller's buffer and raised the flag itself (LaunchArgs::h_f ...)
 	int route_auto;  // 1: which of the two ran is decided on the device after the cut (chain_route; CutArgs::d_count[1], [2] say which)
 };
 constexpr int COOP_ROUTE_MAX_PIECES = 2048;   // the cooperative kernel is only considered for batches of at most this many pieces

@@ -783,15 +783,17 @@ static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream
 		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
 	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
-	                                            (const int64_t *)L.cut.d_end, (const int32_t *)(L.cut.d_count + 2))
+	                                            (const int64_t *)L.cut.d_end, (const int32_t *)(L.cut.d_count + 2), CoopHostOut())
 		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
 		return hipGetLastError();
 	}
 	const dim3 grid((unsigned)L.n_tasks);
+	CoopHostOut H;
+	if (L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG) && !only_flagged) { H.f = L.h_f; H.p = L.h_p; H.d_done = L.d_done; H.h_flag = L.h_flag; H.seq = L.seq; }
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
-	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr)
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -889,6 +891,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	if (coop_auto) L.cut.d_live = L.cut.d_count + 1;
 	if (info) {
 		info->route_auto = coop_auto ? 1 : 0;
+		info->host_out = (coop && L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG)) ? 1 : 0;
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
 		info->coop = coop ? COOP_W : 0;
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
@@ -909,7 +912,9 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	// 3.9 -> about 1 ms, one block per task walks its tiles one after the other)
 	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && (L.d_avg != nullptr || L.d_avg_ws != nullptr) && L.cut.max_pieces == 0
 	                          && (L.max_task_anchors + 255) / 256 <= 65535;
-	if (wide_prepass) {
+	if (coop && L.st_ready && L.d_avg != nullptr) {
+		// nothing to launch: st[] came with the pass (mm2chain_host.cpp), avg was handed in, the cooperative kernel has no classes
+	} else if (wide_prepass) {
 		unsigned *sums = L.d_avg ? nullptr : (unsigned *)L.d_avg_ws;
 		if (sums && hipMemsetAsync(sums, 0, (size_t)L.n_tasks * 4, st) != hipSuccess) return hipGetLastError();
 		hipLaunchKernelGGL(chain_window_start_wide, dim3((unsigned)L.n_tasks, (unsigned)((L.max_task_anchors + 255) / 256)), dim3(256), 0, st, P, L.n_tasks, L.d_offsets,

@@ -882,6 +882,14 @@ int mm2c_tune(const char *key, int value)
 		G.coop_plans = value;
 		return 0;
 	}
+	if (strcmp(key, "host_st") == 0) {
+		G.host_st = value != 0;
+		return 0;
+	}
+	if (strcmp(key, "fused_out") == 0) {
+		G.fused_out = value != 0;
+		return 0;
+	}
 	if (strcmp(key, "coop_max_tasks") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "coop_max_tasks must be >= 0");
 		G.coop_max_tasks = value;

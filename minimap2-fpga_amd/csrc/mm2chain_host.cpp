@@ -110,7 +110,11 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
 	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), o_cls = align16(o_stat + (size_t)n_seg * 4), o_cstat = align16(o_cls + (size_t)n_seg),
-	             in_bytes = align16(o_cstat + cstat_bytes * max_launches);
+	             o_hst = align16(o_cstat + cstat_bytes * max_launches);
+	// round 6: a small pass that the kernels stage themselves brings its window starts along (chain.c:192-193, computed below in one sweep of the host: the reference's own
+	// persistent pointer) -- 4 more bytes per anchor on PCIe instead of a launch of its own between the upload and the DP (17 -> 14.5 -> 10 us of submissions per pass)
+	const bool host_st = (size_t)total <= G.stage_max_anchors && G.direct_pass.load() != 0 && (size_t)total <= G.direct_max_anchors && G.host_st.load() != 0;
+	const size_t in_bytes = align16(o_hst + (host_st ? (size_t)total * 4 : 0));
 	const size_t meta_bytes = in_bytes - o_off;
 	const bool staged = (size_t)total <= G.stage_max_anchors;      // small passes go through pinned staging, big ones copy in place
 	if ((rc = grow_device(&c->d_in, &c->cap_in, in_bytes))) return rc;
@@ -137,6 +141,22 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			const size_t nb = (size_t)(reqs[r]->off[reqs[r]->n_tasks] - reqs[r]->off[0]) * 16;
 			memcpy(c->h_in + at, reqs[r]->a + reqs[r]->off[0], nb);
 			at += nb;
+		}
+		if (host_st) {
+			// st[i] of every piece, relative to the piece: the first j with x_i <= x_j + max_dist_x, clamped to i - max_iter (chain.c:192-193; what chain_window_start finds by search)
+			const mm2c_anchor_t *ha = (const mm2c_anchor_t *)(c->h_in + o_a);
+			int32_t *hst = (int32_t *)(c->h_in + o_hst);
+			const int64_t max_iter = std::max(par->max_iter, 0);
+			for (int64_t k = 0; k < n_seg; ++k) {
+				const int64_t b = seg_off[(size_t)k], n = seg_off[(size_t)k + 1] - b;
+				int64_t st = 0;
+				for (int64_t i = 0; i < n; ++i) {
+					const uint64_t xi = ha[b + i].x;
+					while (st < i && xi > ha[b + st].x + D) ++st;
+					if (i - st > max_iter) st = i - max_iter;
+					hst[b + i] = (int32_t)st;
+				}
+			}
 		}
 		pt1 = pt_now();
 		if (direct) HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
@@ -232,6 +252,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	L.d_status = (int32_t *)(c->d_in + o_stat);
 	L.d_f = (int32_t *)c->d_out; L.d_p = (int32_t *)(c->d_out + (size_t)total * 4);
 	L.d_t = (int32_t *)c->d_scratch; L.d_st = (int32_t *)(c->d_scratch + (size_t)total * 4);
+	if (staged && host_st) { L.d_st = (int32_t *)(c->d_in + o_hst); L.st_ready = 1; }   // (came up with the arena; a pass that runs one wave per piece after all computes them again, with its classes)
 	L.ring_class = G.ring_class; L.force_tab = G.force_tab; L.compact = G.compact_ring; L.q24 = G.q24_ring; L.noskip_loop = G.noskip_loop;
 	L.d_cls = (uint8_t *)(c->d_in + o_cls); L.d_cls_stat = (unsigned long long *)(c->d_in + o_cstat);
 	L.far_ring = G.far_ring; L.far_thr10 = G.far_thr10; L.wide_pct = G.wide_pct;
@@ -245,14 +266,18 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	}
 	if (one_seg_each && par->n_segs <= 1 && !par->is_cdna) L.P.flags |= mm2c::KF_IGNORE_SEG;
 	int nl = 0;
+	if (staged) { if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8 + 16, true))) return rc; }
+	if (direct) {
+		// round 6: a pass that ends in the cooperative kernel needs no fourth launch -- the kernel stores f / p to the result buffer as it goes and raises the flag
+		if (++c->seq == 0) c->seq = 1;
+		if (G.fused_out.load()) { L.h_f = (int32_t *)c->h_out; L.h_p = (int32_t *)(c->h_out + (size_t)total * 4); L.d_done = d_done; L.h_flag = c->h_flag; L.seq = c->seq; }
+	}
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
 	note_host_variant(c->last_info);
 	if (staged) {
-		if ((rc = grow_pinned(&c->h_out, &c->cap_hout, (size_t)total * 8 + 16, true))) return rc;
 		uint64_t pt2;
 		if (direct) {
-			if (++c->seq == 0) c->seq = 1;
-			HIP_TRY(mm2c::launch_stage_out(c->d_out, c->h_out, (size_t)total * 8, d_done, c->h_flag, c->seq, c->st));
+			if (!c->last_info.host_out) HIP_TRY(mm2c::launch_stage_out(c->d_out, c->h_out, (size_t)total * 8, d_done, c->h_flag, c->seq, c->st));
 			pt2 = pt_now();
 			// the flag is the last thing the pass writes (after a system-scope fence behind every store of f / p).  The calling thread has nothing else to do (the call is
 			// synchronous, chain_hardware.cpp:175 clFinish), so it polls; a pass that does not report within 50 ms is waited for through the runtime, which also surfaces
@@ -405,6 +430,9 @@ int book_pred(int tid, float hw_ms, float sw_ms)
 			const double ahead = (double)std::max(0, CB[s].inside.load(std::memory_order_relaxed));
 			if (!(hw_ms > 0.f && sw_ms > 0.f) || svc <= 0.0 || (ahead / lanes + 1.0) * svc <= (double)sw_ms) return s;
 		}
+		// turned away everywhere.  The estimate only moves when passes run, so a slot that looks slow (its first passes pay for code loading and arena growth) would
+		// be avoided for good: every decline lets it forget a little, and the slot is tried again
+		for (int k = 0; k < nd; ++k) { const float v = CB[k].svc_ms.load(std::memory_order_relaxed); CB[k].svc_ms.store(v * 0.98f, std::memory_order_relaxed); }
 		return -1;
 	}
 	for (int k = 0; k < nd; ++k) {
@@ -485,7 +513,7 @@ int submit_combined(HostReq *me, int slot)
 		if (rc == 0) {
 			const uint64_t t_pass = pt_now();
 			rc = run_requests(&cb.ctx[lane_k], batch.data(), (int)batch.size());
-			if (rc == 0) {                                            // what a pass of this slot takes, for the busy protocol (racy read-modify-write: an estimate)
+			if (rc == 0 && cb.passes.load(std::memory_order_relaxed) >= 8) {   // what a pass of this slot takes, for the busy protocol (racy read-modify-write: an estimate; not its first passes)
 				const float ms = (float)((pt_now() - t_pass) * 1e-6), old = cb.svc_ms.load(std::memory_order_relaxed);
 				cb.svc_ms.store(old > 0.f ? 0.875f * old + 0.125f * ms : ms, std::memory_order_relaxed);
 			}
