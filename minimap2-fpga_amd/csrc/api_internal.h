@@ -51,6 +51,8 @@ struct Global {
 	std::atomic<size_t> stage_max_anchors{1u << 21};     // host paths: calls up to this many anchors go through pinned staging buffers
 	std::atomic<int64_t> pipeline_chunk_anchors{20 << 20};  // host paths: batches of at least twice this size are pipelined in chunks of this size
 	std::atomic<int64_t> pipeline_pieces{8}, pipeline_min_chunk{4 << 20};   // host paths: a batch of a few chunks' worth is cut into about `pieces` chunks of at least `min_chunk` anchors
+	std::atomic<int64_t> pipeline_taper{0};             // host paths: the last chunks of a pipelined batch halve in size this many times (0, the default: equal chunks -- the sweep of
+	                                                    // round 6, profiles/r6_hoststream.md, shows nothing to gain: 16.4-16.7 ms for 0 .. 4 halvings)
 	std::atomic<int64_t> cut_below_tasks{4096};         // host paths: passes with at least this many tasks are not cut (they fill the GPU anyway)
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: 16 waves per task (chain_dp_coop; 0 or 1: never; the width is fixed, the value only switches)

@@ -835,6 +835,11 @@ int mm2c_tune(const char *key, int value)
 		G.pipeline_pieces = value;
 		return 0;
 	}
+	if (strcmp(key, "pipeline_taper") == 0) {
+		if (value < 0 || value > 6) return fail(MM2C_E_ARG, "pipeline_taper must be 0 .. 6");
+		G.pipeline_taper = value;
+		return 0;
+	}
 	if (strcmp(key, "pipeline_min_chunk") == 0) {
 		if (value < 1024) return fail(MM2C_E_ARG, "pipeline_min_chunk must be >= 1024");
 		G.pipeline_min_chunk = value;

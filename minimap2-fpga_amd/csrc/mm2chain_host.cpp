@@ -106,7 +106,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	                                             std::min<int64_t>(G.pipeline_chunk_anchors, G.pipeline_min_chunk));
 	// the prepass classes (which LDS ring a piece takes: chain_window_start -> chain_cls_settle -> the instantiations of chain_dp_tile), as plans have them:
 	// one byte per piece + one zeroed set of counter blocks per launch (a pipelined batch settles its classes chunk by chunk)
-	const size_t cstat_bytes = 32 * (size_t)mm2c::CLS_STAT_SLOTS, max_launches = (size_t)(total / std::max<int64_t>(pipe_chunk, 1)) + 2;
+	const size_t cstat_bytes = 32 * (size_t)mm2c::CLS_STAT_SLOTS, max_launches = (size_t)(total / std::max<int64_t>(pipe_chunk, 1)) + 10;   // (+ the small chunks of the tapered tail)
 	const size_t o_a = 0, o_off = align16((size_t)total * 16), o_ord = align16(o_off + ((size_t)n_seg + 1) * 8),
 	             o_pb = align16(o_ord + (size_t)n_seg * 4), o_avg = align16(o_pb + (size_t)n_seg * 4),
 	             o_stat = align16(o_avg + (size_t)n_seg * 4), o_cls = align16(o_stat + (size_t)n_seg * 4), o_cstat = align16(o_cls + (size_t)n_seg),
@@ -179,10 +179,23 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		const mm2c_anchor_t *src = q.a + q.off[0];
 		int32_t *dst_f = q.f + q.off[0], *dst_p = q.p + q.off[0];
 		const int64_t chunk_anchors = pipe_chunk;
+		// Round 6: a tapered schedule.  The batch takes (upload of everything) + (kernel and download of the LAST chunk), so the last chunks are made small: 1/2, 1/4, 1/8 of
+		// the chunk size ("pipeline_taper": how many halvings, 0 = equal chunks) -- what stays unhidden at the end is the kernel and download of an eighth of a chunk.
+		const int taper = (int)std::max<int64_t>(0, std::min<int64_t>(6, G.pipeline_taper.load()));
+		int64_t tail_total = 0;
+		for (int h = 1; h <= taper; ++h) tail_total += chunk_anchors >> h;
 		std::vector<int64_t> cuts(1, 0);
 		for (int64_t s0 = 0; s0 < n_seg;) {
+			// anchors left: the tail starts where what is left fits the tapered sizes; inside it the target halves from chunk to chunk
+			const int64_t left = total - seg_off[(size_t)s0];
+			int64_t target = chunk_anchors;
+			if (taper > 0 && left <= tail_total + chunk_anchors / 2) {
+				target = chunk_anchors >> 1;
+				int64_t rest = tail_total;
+				for (int h = 1; h <= taper && left < rest; ++h) { rest -= chunk_anchors >> h; target = chunk_anchors >> std::min(h + 1, taper); }
+			}
 			int64_t s1 = s0 + 1;
-			while (s1 < n_seg && seg_off[(size_t)s1 + 1] - seg_off[(size_t)s0] <= chunk_anchors) ++s1;
+			while (s1 < n_seg && seg_off[(size_t)s1 + 1] - seg_off[(size_t)s0] <= target) ++s1;
 			cuts.push_back(s1); s0 = s1;
 		}
 		const int n_chunks = (int)cuts.size() - 1;
@@ -216,7 +229,11 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			{
 				int64_t longest = 0;
 				for (int64_t q2 = s0; q2 < s1; ++q2) longest = std::max<int64_t>(longest, seg_off[(size_t)q2 + 1] - seg_off[(size_t)q2]);
-				if ((k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) || (G.coop_plans.load() == 2 && mm2c::coop_pays(s1 - s0, longest, a1 - a0))) {
+				// (inside the pipeline three chunks' kernels share the GPU and what counts is their joint rate: one wave per piece keeps up with the upload while a piece
+				// lasts no longer than about three chunk uploads -- 0.7 us per anchor against 16 bytes per anchor at 56 GB/s: pieces up to 1/800 of the chunk -- and the
+				// cooperative kernel, alone at 3 G anchors/s, would not: measured 2.6 -> 2.1 G anchors/s on the bench's batch when every chunk took it)
+				if ((k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) ||
+				    (G.coop_plans.load() == 2 && mm2c::coop_pays(s1 - s0, longest, a1 - a0) && longest * 800 > a1 - a0)) {
 					L.coop_waves = G.coop_waves.load();
 					L.max_task_anchors = longest;
 				}
