@@ -51,6 +51,7 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None, 
     S = dict(anchors=0, no_window=0, own_chunks=0, own_pass=0, ring_chunks=0, ring_pass=0, deep_fp=0, far_chunks=0, far_pass=0,
              fold_a=0, fold_b0=0, fold_b1=0, fold_b2_closed=0, fold_b2_scan=0, breaks=0, eq_run_anchors=0)
     S.update(dict.fromkeys(LABEL_KEYS, 0), fold_b0=0, fold_b1=0, own_pass=0, far_chunks=0, far_pass=0)
+    S.update(skip_tested=0, skip_rejects=0, skip_wrong=0, skip_missed=0)
     CM = 0xffff
     for i0 in range(0, n, 64):
         cnt = min(64, n - i0)
@@ -115,6 +116,19 @@ def chain_tile_model(P, anchors, avg, NX=8, NF=2, span_override=-1, stats=None, 
                 else:
                     ok = (dq1 >= 0) & (dq1 + 1 <= max_dq) & (dd <= P.bw)
                 valid = ok & inwin & (j < i - e)
+                if ring:
+                    # (round 6, tools/chunk_stats.py --tile-skip: would a 256-bit occupancy bitmap of the tile's diagonal buckets ((x - q) >> 9 mod 256) have rejected this
+                    # visit before its 13 instructions?  A pair passes only with |dr - dq| <= bw <= 511: the candidate's bucket is the anchor's or a neighbour)
+                    bj = (((xlo[jj] - q[jj]) >> 9) & 255)[j >= max(base, 0)]
+                    bi = ((int(xlo[i]) - int(q[i])) >> 9) & 255
+                    hit = np.isin(bj, [(bi - 1) & 255, bi, (bi + 1) & 255]).any()
+                    S["skip_tested"] += 1
+                    if not hit:
+                        S["skip_rejects"] += 1
+                        if valid.any():
+                            S["skip_wrong"] += 1                               # must stay 0: a rejected tile has no lane inside the band
+                    elif not valid.any():
+                        S["skip_missed"] += 1
                 if not valid.any():
                     base -= 64; continue
                 depth = (i0 - base) // 64

@@ -24,19 +24,25 @@ if __name__ == "__main__":
     m = int(args[args.index("--anchors") + 1]) if "--anchors" in args else 5000
     profiles = [a for a in args if not a.startswith("--") and not a.isdigit()] or ["mixed", "dense", "colinear"]
     P = params.map_ont()
+    NX = 16 if "--nx16" in args else 8
+    span = 19 if "--asm20" in args else 15
     keys = ("no_window", "own_chunks", "own_pass", "ring_chunks", "ring_pass", "deep_fp", "far_chunks", "far_pass", "fold_a", "fold_b0", "fold_b1",
             "fold_b2_closed", "fold_b2_scan", "breaks", "eq_run_anchors")
-    print(f"Per anchor, map-ont parameters, {reads} reads x {m} anchors of each bench.py stream (seed 1), NX 8 / NF 2:\n")
+    if "--tile-skip" in args:
+        # round 6: what a per-tile bitmap of diagonal buckets would reject (skip_rejects of skip_tested ring-tile visits; skip_missed: visits without a surviving lane that
+        # the bitmap lets through; skip_wrong must be 0)
+        keys = ("ring_chunks", "ring_pass", "skip_tested", "skip_rejects", "skip_missed", "skip_wrong")
+    print(f"Per anchor, map-ont parameters, {reads} reads x {m} anchors of each bench.py stream (seed 1, span {span}), NX {NX} / NF 2:\n")
     print("| stream | " + " | ".join(keys) + " |")
     print("|---|" + "---|" * len(keys))
     for prof in profiles:
-        off, a = synth.make_stream(prof, reads, m, seed=1)
+        off, a = synth.make_stream(prof, reads, m, seed=1, q_span=span)
         off = off.numpy(); a = a.numpy().view(np.uint64)
         tot = dict.fromkeys(("anchors",) + keys, 0)
         for k in range(reads):
             t = a[off[k]:off[k + 1]]
             st = {}
-            chain_tile_model(P, t, avg_qspan(t), stats=st)
+            chain_tile_model(P, t, avg_qspan(t), stats=st, NX=NX)
             for kk in tot:
                 tot[kk] += st[kk]
         print(f"| {prof} | " + " | ".join(f"{tot[k] / tot['anchors']:.3f}" for k in keys) + " |")
