@@ -17,7 +17,8 @@ if [ "${LONG_PROFILE:-1}" = "1" ]; then
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "mm2c::" in r["Name"]]
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:14]:
-    print(f"{r['Name'].split('(')[0].replace('void ', '')[:110]:110s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e6:10.3f} ms  total {float(r['TotalDurationNs'])/1e6:10.2f} ms")
+    name = r['Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
+    print(f"{name[:100]:100s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e6:10.3f} ms  total {float(r['TotalDurationNs'])/1e6:10.2f} ms")
 PY
   done > $OUT/kernel_stats.txt
   cat $OUT/kernel_stats.txt
