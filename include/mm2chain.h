@@ -33,7 +33,7 @@ enum {
 	MM2C_OK = 0,
 	MM2C_E_NODEVICE = -1,  /* no usable HIP device / mm2c_init not called (cf. hardware_init false, main.c:367) */
 	MM2C_E_ARG = -2,       /* bad argument (negative n, NULL pointer, negative max_dist_x, ...) */
-	MM2C_E_TOOBIG = -3,    /* task larger than the supported maximum (cf. chain_hardware.cpp:34-37) */
+	MM2C_E_TOOBIG = -3,    /* task larger than the supported maximum (cf. chain_hardware.cpp:34-37): see MM2C_MAX_TASK_ANCHORS */
 	MM2C_E_HIP = -4        /* HIP runtime error (cf. checkError, chain_hardware.cpp:208-235) */
 };
 
@@ -197,6 +197,19 @@ void *mm2c_pinned_alloc(size_t bytes);
 void  mm2c_pinned_free(void *ptr);
 
 /*
+ * THE LARGEST TASK (round 6).  The reference sizes its device buffers for BUFFER_N = 332 000 000 / 2 / 32 = 5 187 500 anchors per call (chain_hardware.h:62-64) and ends
+ * the process on a longer one (chain_hardware.cpp:34-37).  Here buffers grow on demand and indices, stamps and p bases are 32 bits wide:
+ *   - every entry that takes tasks (plans, batch entries, mm2c_chain_task_host[_pred], mm_chain_dp) accepts a task of up to MM2C_MAX_TASK_ANCHORS anchors and answers
+ *     MM2C_E_TOOBIG for a longer one -- nothing wraps;
+ *   - the device epilogue (mm2c_plan_chains_device, mm2c_mm_chain_dp_batch_host) takes batches (or pipeline chunks) of fewer than 2^31 anchors in all;
+ *   - run_chaining_on_hw (the reference's symbol) additionally keeps the reference's own contract for the size its host states in hardware_init(buf_size, ...):
+ *     n > buf_size -> "Error: The size of the call ..." on stderr and exit(1).
+ * Tested at the reference's limit: one task of 5 187 500 anchors through run_chaining_on_hw, one of 2 000 000 through mm2c_chain_task_host, element-wise against the
+ * oracle (tests/test_gpu_long_reads.py).
+ */
+#define MM2C_MAX_TASK_ANCHORS ((int64_t)2147483582)   /* 2^31 - 66 */
+
+/*
  * One task, synchronous, V1 (stock CPU) semantics: the EXTENDED form of run_chaining_on_hw
  * (chain_hardware.h:68) that also carries max_skip / max_iter / gap_scale / is_cdna / n_segs, which the
  * reference interface cannot express.  Re-entrant from many host threads (map.c:561); `tid` as chain.c:103.
@@ -207,11 +220,14 @@ int mm2c_chain_task_host(const mm2c_params_t *par, int64_t n, const mm2c_anchor_
 
 /*
  * The same call with the reference's busy protocol (chain_hardware.cpp:54-75, PROCESS_ON_SW_IF_HW_BUSY, chain_hardware.h:50): the caller hands in the two
- * predictions chain.c:80-81 computes (milliseconds) and the call is ACCEPTED by the first device slot, scanning from tid % n, on which
- *     (predicted device time of the calls already inside the slot) / (passes the slot runs at once) + hw_time_pred < sw_time_pred;
- * when no slot will do it returns 1 = "declined": nothing was computed, f / p are untouched, and the caller runs its own loop (chain.c:106,112-164).
- * Only a host that HAS such a loop may call it: the reference's chain.o through run_chaining_on_hw (INTEGRATION.md path A).  This library's own mm_chain_dp
- * (path B) never does -- it has no software DP.  Predictions that are not both positive never decline.  "decline_when_busy" 0 (mm2c_tune) = always accept.
+ * predictions chain.c:80-81 computes (milliseconds).  OFF BY DEFAULT since round 6 ("decline_when_busy" 0: every call is accepted) -- a chain.o built without
+ * PROCESS_ON_SW_IF_HW_BUSY ignores the answer 1 (chain.c:105,163-169) and would chain from uninitialised f / p, and on the measured end-to-end run no decline rule
+ * beat never declining (profiles/r6_per_read.md).  A host that HAS the software loop opts in (environment MM2C_DECLINE_WHEN_BUSY or mm2c_tune):
+ *   1: declined when (calls inside the device slot / passes it runs at once + 1) x (what a pass of that slot has taken lately) > sw_time_pred -- the measured thing;
+ *   2: round 5's rule: (predicted device time booked on the slot) / (passes at once) + hw_time_pred >= sw_time_pred;
+ * the slots are tried from tid % n, the call RUNS on the slot that accepted it (chain_hardware.cpp:58-72), and when none will it returns 1 = "declined": nothing was
+ * computed, f / p are untouched, the caller runs its own loop (chain.c:106,112-164).  This library's own mm_chain_dp (path B) never declines -- it has no software DP.
+ * Predictions that are not both positive never decline.
  */
 int mm2c_chain_task_host_pred(const mm2c_params_t *par, int64_t n, const mm2c_anchor_t *a, float avg_qspan_scaled,
                               int32_t *f, int32_t *p, int tid, float hw_time_pred, float sw_time_pred);
