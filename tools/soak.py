@@ -38,7 +38,15 @@ for r in range(rounds):
     mm2chain.tune("noskip_loop", int(rng.choice([1, 1, 0])))     # max_skip >= max_iter: through the hand-written loop with max_skip = max_iter - 1, or the C++ loop without the machinery
     mm2chain.tune("ring_class", int(rng.choice([3, 3, 3, 3, 4, 4, 0, 1, 2])))   # mostly the tile kernel (the default), sometimes the first-generation one
     # several waves per task (chain_dp_coop.h): always with MM2C_SOAK_COOP set, else in a third of the rounds
-    mm2chain.tune("coop_plans", 1 if os.environ.get("MM2C_SOAK_COOP") or rng.random() < 0.33 else 0)
+    # round 6: gpu_batch runs every input on BOTH routes (one wave per piece, and the library's default, which sends few long pieces -- most soak batches -- to the
+    # cooperative kernel, through the device-side route when tasks are cut first) and compares them; in a third of the rounds the cooperative kernel is forced instead
+    import helpers
+    if os.environ.get("MM2C_SOAK_COOP") or rng.random() < 0.33:
+        helpers.PINNED_ROUTE = 1; mm2chain.tune("coop_plans", 1)
+    else:
+        helpers.PINNED_ROUTE = None; mm2chain.tune("coop_plans", 2)
+    mm2chain.tune("fused_out", int(rng.choice([1, 1, 0])))       # per-read passes: the cooperative kernel writes the caller's buffer and raises the flag, or stage_out does
+    mm2chain.tune("host_st", int(rng.choice([0, 0, 1])))         # ... and their window starts from the prepass kernel or from the host
     tasks = []
     for _ in range(int(rng.integers(1, 12))):
         kind = rng.random()
@@ -81,5 +89,6 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("q24_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1); mm2chain.tune("coop_plans", 0)
+mm2chain.tune("coop_plans", 2); mm2chain.tune("fused_out", 1); mm2chain.tune("host_st", 0)
+mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("q24_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
