@@ -164,6 +164,10 @@ int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
  * else with one wave per piece; with long tasks cut into pieces on the device the choice is made there (chain_route), so this call waits for the run and reads it back.
  * pieces = the tasks, or the pieces they were cut into; one_wave_pieces + coop_pieces = pieces.  mm2c_tune("coop_plans", 0 | 1 | 2): never / every small plan / per run. */
 int mm2c_plan_last_route(mm2c_plan_t *plan, int64_t *pieces, int64_t *one_wave_pieces, int64_t *coop_pieces);
+/* The rule itself (pure arithmetic, no device): waves per piece -- 16 or 1 -- that a batch of `pieces` pieces, the longest of `longest` anchors, `total` anchors in all, is
+ * given under "coop_plans" 2.  One wave per piece is bound by its longest piece (about 0.7 us per anchor), sixteen waves per piece by the anchors a CU is dealt (about
+ * 0.1 us per anchor: total / 256 + the longest piece at worst): sixteen when pieces <= 2048 and 1450 * longest > total (profiles/r6_long_reads.md). */
+int mm2c_route_pieces(int64_t pieces, int64_t longest, int64_t total);
 /* Which kernel instantiation the most recent mm2c_plan_run_device launched for the tasks' first pass, as text, e.g.
  * "chain_dp_tile<NX=8,NF=2,SKIP=1,GEN=0,GS1=1,FAR=1,TAB=0> loop=asm classes=1 cut=0" (loop=asm: the hand-written per-tile loop, loop=c++: its
  * C++ restatement; chain_dp_wave<...>: the first-generation kernel).  For tests and logs: results never depend on the instantiation. */

@@ -1191,6 +1191,8 @@ int mm2c_plan_last_route(mm2c_plan_t *pl, int64_t *pieces, int64_t *one_wave_pie
 	return 0;
 }
 
+int mm2c_route_pieces(int64_t pieces, int64_t longest, int64_t total) { return mm2c::coop_pays(pieces, longest, total) ? 16 : 1; }
+
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 {
 	if (!pl || !ms) return fail(MM2C_E_ARG, "NULL argument");

@@ -67,6 +67,7 @@ C_SYMBOLS = {
     "mm2c_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mm2c_plan_last_variant": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "mm2c_plan_last_route": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mm2c_route_pieces": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "mm2c_last_host_variant": (C.c_int, [C.c_char_p, C.c_size_t]),
     "mm2c_debug_label_hits": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "mm2c_plan_last_prepass_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
