@@ -160,13 +160,15 @@ int mm2c_plan_run_device_n(mm2c_plan_t *plan, const void *d_anchors, int64_t n_a
  * (chain_window_start) that runs just before it. */
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *plan, float *ms);
 /* Round 6: which of the two DP kernels took the pieces of the most recent run.  A batch of few long pieces -- fewer pieces than the GPU has wave slots, BASELINE config 5's
- * long reads -- runs with sixteen waves per piece (chain_dp_coop, the analogue of the reference's one deep pipeline per task, device/minimap2_opencl.cl:49,71), anything
+ * long reads -- runs with sixteen (or eight) waves per piece (chain_dp_coop, the analogue of the reference's one deep pipeline per task, device/minimap2_opencl.cl:49,71), anything
  * else with one wave per piece; with long tasks cut into pieces on the device the choice is made there (chain_route), so this call waits for the run and reads it back.
  * pieces = the tasks, or the pieces they were cut into; one_wave_pieces + coop_pieces = pieces.  mm2c_tune("coop_plans", 0 | 1 | 2): never / every small plan / per run. */
 int mm2c_plan_last_route(mm2c_plan_t *plan, int64_t *pieces, int64_t *one_wave_pieces, int64_t *coop_pieces);
-/* The rule itself (pure arithmetic, no device): waves per piece -- 16 or 1 -- that a batch of `pieces` pieces, the longest of `longest` anchors, `total` anchors in all, is
- * given under "coop_plans" 2.  One wave per piece is bound by its longest piece (about 0.7 us per anchor), sixteen waves per piece by the anchors a CU is dealt (about
- * 0.1 us per anchor: total / 256 + the longest piece at worst): sixteen when pieces <= 2048 and 1450 * longest > total (profiles/r6_long_reads.md). */
+/* The rule itself (pure arithmetic, no device): waves per piece -- 16, 8 or 1 -- that a batch of `pieces` pieces, the longest of `longest` anchors, `total` anchors in all, is
+ * given under "coop_plans" 2.  One wave per piece is bound by its longest piece (about 0.7 us per anchor), several waves per piece by the anchors a CU is dealt (about
+ * 0.1 us per anchor: total / 256 + the longest piece at worst): several when pieces <= 2048 and 1450 * longest > total; of these sixteen (one workgroup per CU) up to
+ * mm2c_tune("coop_w8_above", 256) pieces, eight (two workgroups per CU, each filling the other's waits) beyond -- where pieces of at least 8 192 anchors also take
+ * them when 2300 * longest > total (profiles/r6_long_reads.md). */
 int mm2c_route_pieces(int64_t pieces, int64_t longest, int64_t total);
 /* Which kernel instantiation the most recent mm2c_plan_run_device launched for the tasks' first pass, as text, e.g.
  * "chain_dp_tile<NX=8,NF=2,SKIP=1,GEN=0,GS1=1,FAR=1,TAB=0> loop=asm classes=1 cut=0" (loop=asm: the hand-written per-tile loop, loop=c++: its

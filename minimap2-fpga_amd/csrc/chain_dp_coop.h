@@ -214,7 +214,7 @@ __device__ __forceinline__ void coop_host_done(const CoopHostOut &H)
 }
 
 template <int W, bool GS1, bool FAR, bool TAB>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4)))   // at most 128 VGPRs: sixteen waves per CU whichever the width (one workgroup of sixteen waves, two of eight)
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,

@@ -27,7 +27,8 @@ struct CutArgs {
 	int32_t seg_min = 256;
 	int32_t min_anchors = 8192;     // only tasks at least this long are cut: the others do not make the tail
 	int64_t *d_start = nullptr, *d_end = nullptr;
-	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;   // d_count: three words -- [0] pieces cut, [1] / [2] the pieces chain_route gives to the one-wave / the cooperative kernel
+	int32_t *d_pbase = nullptr, *d_status = nullptr, *d_count = nullptr;   // d_count: four words -- [0] pieces cut, [1] / [2] / [3] the pieces chain_route gives to the one-wave kernels / the cooperative kernel of sixteen / of eight waves
+	int32_t w8_above = 256;         // chain_route: more pieces than this -> eight waves per piece instead of sixteen (LaunchArgs::coop_w8_above)
 	int32_t *d_live = nullptr;      // the count the one-wave kernels go by (nullptr: d_count; under the device-side route: d_count + 1)
 	int32_t *d_has_cut = nullptr;   // per task (n_tasks entries), zero on entry: set by the prepass where a window is empty
 	float *d_avg = nullptr;
@@ -61,6 +62,7 @@ struct LaunchArgs {
 	int32_t *d_status;          // per task, must be zero on entry
 	int64_t max_task_anchors = 0;   // length of the longest task when the caller knows it (0: unknown): lets a small pass size a grid of one block per 256 anchors (chain_window_start_wide)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
+	int coop_w8_above = 256;    // the cooperative kernel takes eight waves per piece (two workgroups per CU) beyond this many pieces, sixteen up to it (chain_kernel.hip: launch_coop)
 	                            // < 0 (with a device-side cut): decided on the device once the pieces are known (chain_route): few long pieces -> the cooperative kernel
 	// a small per-read pass that ends in the cooperative kernel (round 6): f / p also go straight to the caller's page-locked buffer and the last workgroup raises the
 	// flag the caller polls (what stage_out did in a launch of its own, host_stage.hip); taken only when that kernel is the pass's one DP launch (LaunchInfo::host_out)
@@ -89,8 +91,15 @@ struct LaunchInfo {
 constexpr int COOP_ROUTE_MAX_PIECES = 2048;   // the cooperative kernel is only considered for batches of at most this many pieces
 // few long pieces -> several waves per piece.  One wave per piece is bound by its longest piece (about 0.7 us per anchor); the cooperative kernel by the anchors a CU
 // is dealt (about 0.1 us per anchor: total / 256 + the longest piece at worst): 7 Lmax > 1.05 (total / 256 + Lmax)  <=>  1450 Lmax > total (measured on long ava-ont
-// reads, round 6: 2 048 x 100 000 anchors 80 ms / 94 ms, 1 020 x 300 000 210 / 127, 255 x 10^6 618 / 102 for one wave / sixteen)
-__host__ __device__ inline bool coop_pays(long long n_pieces, long long longest, long long total) { return n_pieces > 0 && n_pieces <= COOP_ROUTE_MAX_PIECES && 1450ll * longest > total; }
+// reads, round 6: 2 048 x 100 000 anchors 80 ms / 94 ms, 1 020 x 300 000 210 / 127, 255 x 10^6 618 / 102 for one wave / sixteen).  With more pieces than `w8_above` the
+// kernel runs eight waves per piece, two workgroups per CU (launch_coop): 0.38 ns per anchor of the batch against 0.47 -- for LONG pieces (a tile of 64 anchors costs the
+// workgroup its barriers however few predecessors the anchors have) that moves the line to 2 048 equal pieces: 2 048 x 100 000 80.1 / 77.4, 2 048 x 10 000 11.9 / 10.9,
+// 1 533 x 150 000 117.8 / 85.1, but 2 048 x 3 000 3.2 / 5.8 ms (gpurun_out/coop_w_sweep.txt, coop_w_small.txt -> profiles/r6_long_reads.md).
+__host__ __device__ inline bool coop_pays(long long n_pieces, long long longest, long long total, long long w8_above = 256)
+{
+	if (n_pieces <= 0 || n_pieces > COOP_ROUTE_MAX_PIECES) return false;
+	return 1450ll * longest > total || (n_pieces > w8_above && longest >= 8192 && 2300ll * longest > total);
+}
 
 
 int chain_ring_anchors(int ring_class);

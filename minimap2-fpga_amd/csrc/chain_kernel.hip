@@ -397,14 +397,15 @@ chain_window_start_wide(KParams P, int64_t n_tasks, const int64_t *__restrict__ 
 }
 
 // Which kernel takes the pieces of a batch, decided where the pieces are known: chain_cut has just counted them.  Few long pieces (coop_pays, chain_kernel.h) go to the
-// cooperative kernel, anything else to one wave per piece; both kernels are launched, each goes by its own count word and the one that was not chosen finds 0 there.
+// cooperative kernel, anything else to one wave per piece; both kernels are launched, each goes by its own count word and the one that was not chosen finds 0 there
+// (the cooperative kernel in two widths, see launch_coop).
 __global__ void __launch_bounds__(256)
 chain_route(CutArgs C)
 {
 	__shared__ unsigned long long s_tot;
 	__shared__ int s_max;
 	const int n = *C.d_count;
-	if (n > COOP_ROUTE_MAX_PIECES) { if (threadIdx.x == 0) { C.d_count[1] = n; C.d_count[2] = 0; } return; }
+	if (n > COOP_ROUTE_MAX_PIECES) { if (threadIdx.x == 0) { C.d_count[1] = n; C.d_count[2] = 0; C.d_count[3] = 0; } return; }
 	if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
 	__syncthreads();
 	unsigned long long tot = 0; int mx = 0;
@@ -412,8 +413,9 @@ chain_route(CutArgs C)
 	atomicAdd(&s_tot, tot); atomicMax(&s_max, mx);
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const bool coop = coop_pays(n, s_max, (long long)s_tot);
-		C.d_count[1] = coop ? 0 : n; C.d_count[2] = coop ? n : 0;
+		const bool coop = coop_pays(n, s_max, (long long)s_tot, C.w8_above);
+		const bool eight = n > C.w8_above;                                  // more pieces than CUs: two workgroups of eight waves per CU
+		C.d_count[1] = coop ? 0 : n; C.d_count[2] = coop && !eight ? n : 0; C.d_count[3] = coop && eight ? n : 0;
 	}
 }
 
@@ -773,17 +775,20 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 }
 
 // ---- several waves per task (chain_dp_coop.h): passes too small to fill the GPU with one wave per task; the variants of the hand-written loop only
-constexpr int COOP_W = 16;
-static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged)
+// Waves per piece: sixteen (one workgroup per CU: the pieces of a pass of at most one per CU get a CU each) or eight (two workgroups per CU: with more pieces than CUs a CU
+// that holds two fills the waits of one -- its barriers, 52 % of the wave cycles at sixteen -- with the rows of the other: 1 020 reads of 300 000 anchors 129.3 -> 111.3 ms,
+// 2 048 of 100 000 96.1 -> 77.7, while 255 of 10^6 take 153.9 instead of 101.5: profiles/r6_long_reads.md).  `w8_above`: pieces beyond which eight are taken.
+template <int W>
+static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, const int32_t *n_live)
 {
 	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);
-	const dim3 block(64 * COOP_W);
+	const dim3 block(64 * W);
 	if (L.cut.max_pieces > 0) {
-		// the pieces chain_route gave to this kernel (d_count[2] of them: at most COOP_ROUTE_MAX_PIECES, or none)
+		// the pieces chain_route gave to this kernel (*n_live of them: at most COOP_ROUTE_MAX_PIECES, or none)
 		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
-#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
+#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
 	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
-	                                            (const int64_t *)L.cut.d_end, (const int32_t *)(L.cut.d_count + 2), CoopHostOut())
+	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut())
 		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -792,12 +797,27 @@ static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream
 	const dim3 grid((unsigned)L.n_tasks);
 	CoopHostOut H;
 	if (L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG) && !only_flagged) { H.f = L.h_f; H.p = L.h_p; H.d_done = L.d_done; H.h_flag = L.h_flag; H.seq = L.seq; }
-#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<COOP_W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
+#define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
 	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
 	return hipGetLastError();
+}
+
+static int coop_width(const LaunchArgs &L) { return L.n_tasks > (int64_t)L.coop_w8_above ? 8 : 16; }   // (pieces = tasks: no cut on the device)
+
+static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, int *n_launches)
+{
+	if (L.cut.max_pieces > 0) {
+		// cut on the device: chain_route put the count under the width it chose (d_count[2]: sixteen waves, [3]: eight); the launch that was not chosen finds 0
+		hipError_t e = launch_coop_w<16>(L, d_avg, st, tab, only_flagged, L.cut.d_count + 2);
+		if (n_launches) ++*n_launches;
+		if (e == hipSuccess && L.cut.max_pieces > (int64_t)L.coop_w8_above) { e = launch_coop_w<8>(L, d_avg, st, tab, only_flagged, L.cut.d_count + 3); if (n_launches) ++*n_launches; }
+		return e;
+	}
+	if (n_launches) ++*n_launches;
+	return coop_width(L) == 8 ? launch_coop_w<8>(L, d_avg, st, tab, only_flagged, nullptr) : launch_coop_w<16>(L, d_avg, st, tab, only_flagged, nullptr);
 }
 
 template <bool SKIP, bool FAR>
@@ -888,12 +908,12 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	const bool coop = L.coop_waves > 1 && coop_cfg && L.cut.max_pieces == 0;
 	// ... or left to the device: with a cut, how many pieces there are and how long is only known there (chain_route, after chain_cut)
 	const bool coop_auto = L.coop_waves < 0 && coop_cfg && L.cut.max_pieces > 0 && L.cut.d_count != nullptr;
-	if (coop_auto) L.cut.d_live = L.cut.d_count + 1;
+	if (coop_auto) { L.cut.d_live = L.cut.d_count + 1; L.cut.w8_above = L.coop_w8_above; }
 	if (info) {
 		info->route_auto = coop_auto ? 1 : 0;
 		info->host_out = (coop && L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG)) ? 1 : 0;
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
-		info->coop = coop ? COOP_W : 0;
+		info->coop = coop ? coop_width(L) : 0;
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
 		info->skip = skip; info->gen = want_gen; info->gs1 = gs1; info->far_ = t0 ? far_ : (tile ? far_old : far_); info->tab = t0 && tab && !want_gen;
 		info->asm_loop = t0 && skip && !want_gen && (gs1 || tab) && P.bw >= 0 && P.max_dq - 1 >= P.bw;   // = ASM of chain_dp_tile
@@ -954,8 +974,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		if (pass == 1 && (want_gen || (P.flags & KF_IGNORE_SEG))) break;
 		const int flagged = pass;
 		if (pass == 1) { L.cut.d_live = nullptr; L1.cut.d_live = nullptr; }   // the pieces flagged for the general variant come from either kernel: every piece is looked at
-		if (coop && !gen) { e = launch_coop(L, d_avg, st, tab, flagged); if (n_launches) ++*n_launches; continue; }
-		if (coop_auto && !gen) { e = launch_coop(L, d_avg, st, tab, flagged); if (n_launches) ++*n_launches; }   // (and the one-wave kernels below: each goes by its own count)
+		if (coop && !gen) { e = launch_coop(L, d_avg, st, tab, flagged, n_launches); continue; }
+		if (coop_auto && !gen) e = launch_coop(L, d_avg, st, tab, flagged, n_launches);   // (and the one-wave kernels below: each goes by its own count)
 		if (tile && (!gen || tile_gen)) { e = launch_tile(L, d_avg, st, skip, gen, gs1, far_, tab, flagged, n_launches); if (n_launches) ++*n_launches; continue; }
 		if (tile) { e = launch_r<256>(L1, st, skip, gen, gs1, far_old, flagged); if (n_launches) ++*n_launches; continue; }
 		switch (R) {

@@ -895,6 +895,11 @@ int mm2c_tune(const char *key, int value)
 		G.fused_out = value != 0;
 		return 0;
 	}
+	if (strcmp(key, "coop_w8_above") == 0) {
+		if (value < 0) return fail(MM2C_E_ARG, "coop_w8_above must be >= 0 (pieces beyond which the cooperative kernel takes eight waves per piece instead of sixteen)");
+		G.coop_w8_above = (int)std::min<int64_t>(value, 1 << 30);
+		return MM2C_OK;
+	}
 	if (strcmp(key, "coop_max_tasks") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "coop_max_tasks must be >= 0");
 		G.coop_max_tasks = value;
@@ -1070,9 +1075,9 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	const int coop_mode = G.coop_waves.load() > 1 ? G.coop_plans.load() : 0;
 	const int64_t longest = pl->sizes_desc.empty() ? 0 : (int64_t)pl->sizes_desc[0];
 	const bool will_cut = G.plan_cut && G.seg_min > 0 && longest >= G.plan_cut_min;
-	L.coop_waves = 0;
+	L.coop_waves = 0; L.coop_w8_above = G.coop_w8_above.load();
 	if (coop_mode == 1 && pl->n_tasks <= G.coop_max_tasks) L.coop_waves = G.coop_waves.load();
-	else if (coop_mode == 2 && !will_cut && !pl->d_off_user && mm2c::coop_pays(pl->n_tasks, longest, pl->total)) L.coop_waves = G.coop_waves.load();
+	else if (coop_mode == 2 && !will_cut && !pl->d_off_user && mm2c::coop_pays(pl->n_tasks, longest, pl->total, G.coop_w8_above.load())) L.coop_waves = G.coop_waves.load();
 	else if (coop_mode == 2 && will_cut) L.coop_waves = -1;
 	if (L.coop_waves > 1) L.max_task_anchors = longest;
 	if (L.coop_waves <= 1 && G.plan_cut && G.seg_min > 0) {
@@ -1173,9 +1178,9 @@ int mm2c_plan_last_route(mm2c_plan_t *pl, int64_t *pieces, int64_t *one_wave_pie
 		DeviceScope on(pl->device);
 		HIP_TRY(on.err);
 		HIP_TRY(hipEventSynchronize(pl->ev1));
-		int32_t w[3] = {0, 0, 0};
+		int32_t w[4] = {0, 0, 0, 0};
 		HIP_TRY(hipMemcpy(w, pl->d_cut, sizeof(w), hipMemcpyDeviceToHost));
-		*pieces = w[0]; *one_wave_pieces = w[1]; *coop_pieces = w[2];
+		*pieces = w[0]; *one_wave_pieces = w[1]; *coop_pieces = w[2] + w[3];              // (sixteen waves per piece or eight: only one of the two is set)
 		return 0;
 	}
 	*pieces = pl->n_tasks;
@@ -1191,7 +1196,7 @@ int mm2c_plan_last_route(mm2c_plan_t *pl, int64_t *pieces, int64_t *one_wave_pie
 	return 0;
 }
 
-int mm2c_route_pieces(int64_t pieces, int64_t longest, int64_t total) { return mm2c::coop_pays(pieces, longest, total) ? 16 : 1; }
+int mm2c_route_pieces(int64_t pieces, int64_t longest, int64_t total) { const int w8 = G.coop_w8_above.load(); return mm2c::coop_pays(pieces, longest, total, w8) ? (pieces > w8 ? 8 : 16) : 1; }
 
 int mm2c_plan_last_kernel_ms(mm2c_plan_t *pl, float *ms)
 {

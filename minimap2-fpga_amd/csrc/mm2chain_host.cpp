@@ -211,7 +211,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			HIP_TRY(hipMemcpyAsync(c->d_in + o_a + (size_t)a0 * 16, src + a0, (size_t)(a1 - a0) * 16, hipMemcpyHostToDevice, c->st_up));
 			HIP_TRY(hipEventRecord(ev_up, c->st_up));
 			HIP_TRY(hipStreamWaitEvent(st, ev_up, 0));
-			mm2c::LaunchArgs L;
+			mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
 			L.P = to_kparams(par);
 			L.n_tasks = s1 - s0; L.d_offsets = (const int64_t *)(c->d_in + o_off) + s0; L.d_order = nullptr;
 			L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg) + s0;
@@ -233,7 +233,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 				// lasts no longer than about three chunk uploads -- 0.7 us per anchor against 16 bytes per anchor at 56 GB/s: pieces up to 1/800 of the chunk -- and the
 				// cooperative kernel, alone at 3 G anchors/s, would not: measured 2.6 -> 2.1 G anchors/s on the bench's batch when every chunk took it)
 				if ((k >= n_chunks - G.pipe_coop_chunks.load() && s1 - s0 <= G.coop_max_tasks) ||
-				    (G.coop_plans.load() == 2 && mm2c::coop_pays(s1 - s0, longest, a1 - a0) && longest * 800 > a1 - a0)) {
+				    (G.coop_plans.load() == 2 && mm2c::coop_pays(s1 - s0, longest, a1 - a0, G.coop_w8_above.load()) && longest * 800 > a1 - a0)) {
 					L.coop_waves = G.coop_waves.load();
 					L.max_task_anchors = longest;
 				}
@@ -262,7 +262,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			at += nb;
 		}
 	}
-	mm2c::LaunchArgs L;
+	mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
 	L.P = to_kparams(par);
 	L.n_tasks = n_seg; L.d_offsets = (const int64_t *)(c->d_in + o_off); L.d_order = (const int32_t *)(c->d_in + o_ord);
 	L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
@@ -278,7 +278,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	{
 		int64_t longest = 0;
 		for (int64_t k = 0; k < n_seg; ++k) longest = std::max<int64_t>(longest, seg_off[(size_t)k + 1] - seg_off[(size_t)k]);
-		L.coop_waves = (n_seg <= G.coop_max_tasks || (G.coop_plans.load() == 2 && mm2c::coop_pays(n_seg, longest, total))) ? G.coop_waves.load() : 0;
+		L.coop_waves = (n_seg <= G.coop_max_tasks || (G.coop_plans.load() == 2 && mm2c::coop_pays(n_seg, longest, total, G.coop_w8_above.load()))) ? G.coop_waves.load() : 0;
 		if (L.coop_waves > 1) L.max_task_anchors = longest;
 	}
 	if (one_seg_each && par->n_segs <= 1 && !par->is_cdna) L.P.flags |= mm2c::KF_IGNORE_SEG;
@@ -701,7 +701,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		HIP_TRY(hipMemcpyAsync(w.d_in + o_off, w.h_meta, meta_bytes, hipMemcpyHostToDevice, w.st));
 		HIP_TRY(hipMemcpyAsync(w.d_in, a0 + (h_offsets[k0] - h_offsets[0]), tot * 16, hipMemcpyHostToDevice, w.st));
 		int32_t *d_f = (int32_t *)w.d_work, *d_p = d_f + tot;
-		mm2c::LaunchArgs L;
+		mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
 		L.P = to_kparams(par);
 		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);
@@ -720,7 +720,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		} else if (G.coop_plans.load() == 2 && G.coop_waves.load() > 1) {
 			int64_t longest = 0;
 			for (size_t k = 0; k < nt; ++k) longest = std::max<int64_t>(longest, m_off[k + 1] - m_off[k]);
-			if (mm2c::coop_pays((int64_t)nt, longest, (int64_t)tot)) { L.coop_waves = G.coop_waves.load(); L.max_task_anchors = longest; }
+			if (mm2c::coop_pays((int64_t)nt, longest, (int64_t)tot, G.coop_w8_above.load())) { L.coop_waves = G.coop_waves.load(); L.max_task_anchors = longest; }
 		}
 		HIP_TRY(mm2c::launch_chain_dp(L, w.st, &nl, nullptr, &c->last_info));
 		note_host_variant(c->last_info);

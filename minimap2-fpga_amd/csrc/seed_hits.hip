@@ -82,6 +82,14 @@ __device__ __forceinline__ bool hit_anchor(const SeedArgs &A, uint64_t r, uint32
 	return keep;
 }
 
+// Long reads (round 6): which reads the sixteen-wave expansion takes (seed_expand_mw below) -- more anchors than the LDS sorts hold, every hit kept (with skip_seed the
+// place of an anchor depends on what the hits before it decided: one wave), no more chunks of 64 matches than its table of chunk totals holds
+constexpr int EXPAND_MW_WAVES = 16, EXPAND_MW_CHUNKS = 16384, EXPAND_MW_ABOVE = 16384;   // (EXPAND_MW_ABOVE = SORT_LDS_CAP below: the reads the host counts in n_sort_huge)
+__device__ __forceinline__ bool expand_mw_takes(const SeedArgs &A, int read)
+{
+	return A.mw_sort && !A.d_count && A.d_anchor_off[read + 1] - A.d_anchor_off[read] > EXPAND_MW_ABOVE && (A.d_match_off[read + 1] - A.d_match_off[read] + 63) / 64 <= EXPAND_MW_CHUNKS;
+}
+
 // ---- kernel 1: expansion (map.c:222-243) ----------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 {
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 	__shared__ uint32_t s_qpos[64], s_span[64], s_segt[64];
 	__shared__ int64_t s_cr[64];
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	if (expand_mw_takes(A, read)) return;
 	const int lane = (int)threadIdx.x;
 	const int64_t m0 = A.d_match_off[read], a0 = A.d_anchor_off[read];
 	const int nm = (int)(A.d_match_off[read + 1] - m0), na = (int)(A.d_anchor_off[read + 1] - a0);
@@ -138,6 +147,96 @@ __global__ __launch_bounds__(64) void seed_expand(SeedArgs A)
 	else if (run != na && lane == 0) A.status[read] = 1;
 	x_or = wave_or(x_or); x_and = ~wave_or(~x_and);
 	if (lane == 0) A.xdiff[read] = run > 0 ? x_or ^ x_and : 0;
+}
+
+// ---- kernel 1b (round 6): the expansion of a LONG read on sixteen waves.  seed_expand walks a read's matches 64 at a time on one wave -- 34 ms for a read of 10^6
+// anchors, one read per CU and the other waves of the CU idle.  Where an anchor lands is the prefix sum of the hit counts before its match, so: (1) every wave adds up the hit
+// counts of its chunks of 64 matches, (2) one block-wide exclusive scan over the chunk totals, (3) every wave expands its chunks at their places -- the same lanes, the same
+// owner search, the same encoding (hit_anchor) as seed_expand, chunk by chunk.  Every hit is kept here (no skip_seed), so the totals are the places.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void seed_expand_mw(SeedArgs A)
+{
+	constexpr int NT = 64 * NW;
+	__shared__ int s_tot[EXPAND_MW_CHUNKS];
+	__shared__ int s_start[NW][65];
+	__shared__ uint32_t s_qpos[NW][64], s_span[NW][64], s_segt[NW][64];
+	__shared__ int64_t s_cr[NW][64];
+	__shared__ int s_part[NT], s_bad;
+	__shared__ unsigned long long s_or, s_and;
+	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
+	if (!expand_mw_takes(A, read)) return;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t m0 = A.d_match_off[read], a0 = A.d_anchor_off[read];
+	const int nm = (int)(A.d_match_off[read + 1] - m0), na = (int)(A.d_anchor_off[read + 1] - a0);
+	const int qlen = A.d_qlen[read];
+	const Match *m = A.d_matches + m0;
+	ulonglong2 *out = A.unsorted + a0;
+	const int n_chunks = (nm + 63) / 64;
+	if (tid == 0) { s_bad = 0; s_or = 0; s_and = ~0ull; }
+	__syncthreads();
+	// (1) totals of the chunks (and the check of seed_expand: no match may reach beyond the hit pool the caller declared)
+	for (int c = wave; c < n_chunks; c += NW) {
+		const int i = 64 * c + lane;
+		Match q = {};
+		if (i < nm) q = m[i];
+		if (A.n_hits > 0 && i < nm && (q.cr_off < 0 || q.cr_off + (int64_t)q.n > A.n_hits)) s_bad = 2;
+		unsigned long long n64 = q.n;                                               // the chunk's hits in 64 bits: a chunk with more than the read's anchors is an error (and keeps the int sums exact)
+		for (int d = 1; d < 64; d <<= 1) n64 += (unsigned long long)__shfl_xor((long long)n64, d);
+		if (n64 > (unsigned long long)na) { if (!s_bad) s_bad = 1; n64 = 0; }
+		if (lane == 63) s_tot[c] = (int)n64;
+	}
+	__syncthreads();
+	if (s_bad) { if (tid == 0) A.status[read] = s_bad; return; }
+	// (2) exclusive scan over the chunk totals: every thread a run of consecutive chunks
+	const int per = (n_chunks + NT - 1) / NT, c_lo = min(tid * per, n_chunks), c_hi = min(c_lo + per, n_chunks);
+	long long mine = 0;
+	for (int c = c_lo; c < c_hi; ++c) mine += s_tot[c];
+	{
+		// (an int suffices for the places: the grand total must equal na < 2^31, checked below; a partial sum that overflowed shows up as a mismatch there)
+		int v = (int)min(mine, (long long)INT_MAX);
+		const int incl = wave_incl_scan(v, lane);
+		if (lane == 63) s_part[wave] = incl;
+		__syncthreads();
+		int before = 0;
+		for (int w = 0; w < wave; ++w) before += s_part[w];
+		int at = before + incl - v;
+		int grand = 0;
+		for (int w = 0; w < NW; ++w) grand += s_part[w];
+		__syncthreads();
+		for (int c = c_lo; c < c_hi; ++c) { const int t = s_tot[c]; s_tot[c] = at; at += t; }
+		if (grand != na || mine > INT_MAX) { if (tid == 0) A.status[read] = 1; return; }        // the caller's anchor offsets do not match the hit counts (uniform: every thread sees the same sums)
+	}
+	__syncthreads();
+	// (3) expansion, chunk by chunk as seed_expand does it
+	uint64_t x_or = 0, x_and = ~0ull;
+	for (int c = wave; c < n_chunks; c += NW) {
+		const int i = 64 * c + lane;
+		Match q = {};
+		if (i < nm) q = m[i];
+		const int incl = wave_incl_scan((int)q.n, lane);
+		const int total = __shfl(incl, 63);
+		s_start[wave][lane] = incl - (int)q.n; s_cr[wave][lane] = q.cr_off; s_qpos[wave][lane] = q.q_pos; s_span[wave][lane] = q.q_span; s_segt[wave][lane] = q.seg_tandem;
+		if (lane == 63) s_start[wave][64] = total;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (a wave's own rows: no workgroup barrier)
+		const int run = s_tot[c];
+		for (int t0 = 0; t0 < total; t0 += 64) {
+			const int t = t0 + lane;
+			if (t < total) {
+				int lo = 0, hi = 63;                                            // last match of the chunk with start <= t
+				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[wave][mid] <= t) lo = mid; else hi = mid - 1; }
+				const uint64_t r = A.d_hits[s_cr[wave][lo] + (t - s_start[wave][lo])];
+				ulonglong2 a = {0, 0};
+				hit_anchor(A, r, s_qpos[wave][lo], s_span[wave][lo], s_segt[wave][lo], qlen, 0, 0, a);   // (skip_flag is 0 here: every hit is kept)
+				out[run + t] = a;
+				x_or |= a.x; x_and &= a.x;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the rows are rewritten for the wave's next chunk
+	}
+	x_or = wave_or(x_or); x_and = ~wave_or(~x_and);
+	if (lane == 0) { atomicOr(&s_or, x_or); atomicAnd(&s_and, x_and); }
+	__syncthreads();
+	if (tid == 0) A.xdiff[read] = na > 0 ? s_or ^ s_and : 0;
 }
 
 // ---- packed offsets of the result: exclusive prefix sums of the per-read counts (one block of 1024 threads) ----------------
@@ -782,6 +881,11 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 	hipError_t e;
 	hipLaunchKernelGGL(seed_expand, dim3(nr), dim3(64), 0, st, A);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
+	if (A.mw_sort && !A.d_count && (A.d_order ? A.n_sort_huge : (int64_t)nr) > 0) {   // long reads: sixteen waves each (the first workgroups of the launch order)
+		hipLaunchKernelGGL((seed_expand_mw<EXPAND_MW_WAVES>), dim3(A.d_order ? (unsigned)A.n_sort_huge : nr), dim3(64 * EXPAND_MW_WAVES), 0, st, A);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (n_launches) ++*n_launches;
+	}
 	if (A.d_count) {                                                             // skip_seed in force: the reads keep fewer anchors than they have hits
 		hipLaunchKernelGGL(seed_offsets, dim3(1), dim3(1024), 0, st, A);
 		if ((e = hipGetLastError()) != hipSuccess) return e;

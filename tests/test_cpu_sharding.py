@@ -225,13 +225,16 @@ def test_device_to_cpu_set_mapping_reads_the_numa_node_of_the_pci_device(tmp_pat
 def test_route_of_a_batch_between_the_two_dp_kernels():
     """Round 6: which DP kernel a batch takes under the library's default ("coop_plans" 2) -- pure arithmetic (mm2c_route_pieces = coop_pays, csrc/chain_kernel.h), the same
     rule on the host (plans whose tasks run as they are, host passes and chunks) and on the device (chain_route, after long tasks have been cut).  Few long pieces get
-    sixteen waves each, the analogue of the reference's one deep pipeline per task (device/minimap2_opencl.cl:49,71); anything else one wave each."""
+    sixteen waves each (eight when there are more pieces than CUs), the analogue of the reference's one deep pipeline per task (device/minimap2_opencl.cl:49,71); anything else one wave each."""
     from mm2chain import _native as N
     lib = N.load()
     r = lib.mm2c_route_pieces
     assert r(1, 5000, 5000) == 16                                   # a lone per-read call
-    assert r(255, 1000000, 255000000) == 16 and r(1020, 300000, 306000000) == 16      # the long-read batches of profiles/r6_long_reads.md ...
-    assert r(2048, 100000, 204800000) == 1                          # ... and the one where one wave per piece wins (80 ms against 94)
+    assert r(255, 1000000, 255000000) == 16 and r(256, 10**6, 256 * 10**6) == 16      # at most one piece per CU: sixteen waves, one workgroup per CU
+    assert r(1020, 300000, 306000000) == 8 and r(510, 500000, 255000000) == 8         # more pieces than CUs: eight waves, two workgroups per CU (129.3 -> 111.3 ms)
+    assert r(2048, 100000, 204800000) == 8 and r(1533, 150000, 1533 * 150000) == 8    # long pieces: up to 2 048 equal ones (80.1 / 77.4 ms, 117.8 / 85.1)
+    assert r(2048, 3000, 2048 * 3000) == 1 and r(2048, 8191, 2048 * 8191) == 1        # ... short ones only under the round's first rule (3.2 / 5.8 ms)
+    assert r(1024, 1000, 1024000) == 8                              # (that rule: 1450 * longest > total)
     assert r(65536, 5000, 327680000) == 1 and r(2049, 10**6, 2049 * 10**6) == 1       # never above 2 048 pieces: the GPU is full of waves anyway
     assert r(2000, 300, 600000) == 1 and r(100, 300, 30000) == 16   # short pieces: only when there are few of them
     assert r(0, 0, 0) == 1

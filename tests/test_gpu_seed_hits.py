@@ -161,6 +161,47 @@ def test_anchor_offsets_that_do_not_match_the_hit_counts_are_reported():
     plan.close()
 
 
+def test_long_reads_expand_on_sixteen_waves_and_on_one_alike(monkeypatch):
+    """reads beyond 16 384 anchors with every hit kept are expanded by the sixteen waves of a workgroup (seed_expand_mw: chunk totals, one scan, chunks at their places);
+    MM2C_MW_SORT=0 leaves them to the one-wave kernels.  Both against the oracle: a match count that is no multiple of 64, long runs of matches without hits, one match with
+    thousands of hits (a chunk far bigger than the others), next to short reads in the same batch"""
+    rng = np.random.default_rng(6161)
+    q1 = _random_read(rng, 9001, 6, 2, 1 << 24, qlen=120000, dup_frac=0.1)
+    qlen, m, h = _random_read(rng, 6000, 9, 1, 1 << 25, qlen=100000)
+    m = m.copy(); lists = [h[int(c):int(c) + int(n)] for c, n in zip(m["cr_off"], m["n"])]
+    for k in range(1000, 2500):
+        lists[k] = lists[k][:0]                                                     # 1 500 matches in a row without a hit
+    big = np.sort(rng.integers(0, 1 << 25, 7000)).astype(np.uint64) << np.uint64(1)
+    lists[4000] = big                                                               # one minimizer with 7 000 hits
+    m["n"] = [x.size for x in lists]; m["cr_off"] = np.concatenate([[0], np.cumsum(m["n"].astype(np.int64))[:-1]])
+    q2 = (qlen, m, np.concatenate(lists))
+    reads = [_random_read(rng, 300, 5, 1, 1 << 20), q1, _random_read(rng, 0, 0, 1, 10), q2, _random_read(rng, 2500, 8, 2, 1 << 22, qlen=40000)]
+    sizes = [int(r[1]["n"].sum()) for r in reads]
+    assert sizes[1] > 16384 and sizes[3] > 16384 and max(sizes[0], sizes[4]) <= 16384, sizes
+    ties = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MM2C_MW_SORT", flag)                                  # read when a seed plan is made
+        ties[flag] = _check(reads, f"MM2C_MW_SORT={flag}")
+    assert ties["1"] == ties["0"]
+
+
+def test_anchor_offsets_of_a_long_read_that_do_not_match_are_reported():
+    """the same check as above in the sixteen-wave expansion: the grand total of the chunk sums against the read's anchor range, before anything is written"""
+    import mm2chain
+    rng = np.random.default_rng(31)
+    qlen, m, h = _random_read(rng, 6000, 8, 1, 1 << 24, qlen=90000)
+    n = int(m["n"].sum())
+    assert n > 16384
+    for wrong in (n + 5, n - 5):
+        plan = mm2chain.SeedPlan(np.array([0, m.size], np.int64), np.array([0, wrong], np.int64))
+        d_m = torch.from_numpy(m.view(np.uint8)).cuda(); d_h = torch.from_numpy(h.view(np.int64)).cuda()
+        d_q = torch.tensor([qlen], dtype=torch.int32, device="cuda")
+        plan.run(d_m, d_h, d_q)
+        with pytest.raises(mm2chain.Mm2cError):
+            plan.check()
+        plan.close()
+
+
 def test_seeds_to_chains_without_leaving_the_device():
     """matches -> anchors -> f/p -> chains on the GPU (SeedPlan, ChainPlan.run, ChainPlan.chains on one stream) against the oracle's
     collect_seed_hits + mm_chain_dp per read"""

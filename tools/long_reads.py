@@ -3,7 +3,7 @@
 seed-hit path on batches that have FEWER tasks than the GPU has wave slots, at the anchor density of the bench's ava-ont stream (20 000 anchors in a
 400 kb locus = 50 per kb: locus = 20 x anchors per read; -x ava-ont scalars, options.c:83-86).
 
-usage: python tools/long_reads.py [--sizes 2048x100000,1024x300000,256x1000000] [--routes auto,one-wave,coop16] [--no-seed] [--distinct N] [--profile mixed]
+usage: python tools/long_reads.py [--sizes 2048x100000,1024x300000,256x1000000] [--routes auto,one-wave,coop16,coop8] [--no-seed] [--distinct N] [--profile mixed]
 Every route's f / p of the first distinct reads are compared with the CPU oracle; one line per (size, route).  bench.py imports measure() for its `long_reads` leg."""
 import argparse
 import os
@@ -21,13 +21,15 @@ import oracle_binding as ob          # noqa: E402
 ROUTES = {   # tuning knobs of a route (the library's defaults are route 'auto': chosen per run, on the device when long tasks are cut first)
     "auto": {"coop_plans": 2},
     "one-wave": {"coop_plans": 0},
-    "coop16": {"coop_plans": 1, "coop_max_tasks": 1 << 30},
+    "coop": {"coop_plans": 1, "coop_max_tasks": 1 << 30},                             # several waves per piece always; sixteen or eight by the number of pieces
+    "coop16": {"coop_plans": 1, "coop_max_tasks": 1 << 30, "coop_w8_above": 1 << 30},
+    "coop8": {"coop_plans": 1, "coop_max_tasks": 1 << 30, "coop_w8_above": 0},
 }
 QLEN = 1 << 26
 
 
 def set_route(name):
-    mm2chain.tune("coop_max_tasks", 1024)
+    mm2chain.tune("coop_max_tasks", 1024); mm2chain.tune("coop_w8_above", 256)
     for k, v in ROUTES[name].items():
         mm2chain.tune(k, v)
 
@@ -67,7 +69,7 @@ def measure(reads, per, routes=("auto",), dp=True, seed=True, reps=3, check=2, p
             ok = ok and bool(torch.equal(d_f[total - int(off1[-1]):], d_f[: int(off1[-1])])) and bool(torch.equal(d_p[total - int(off1[-1]):], d_p[: int(off1[-1])]))
             pieces, one_wave, coop = plan.last_route()
             out["dp"][route] = {"kernel_ms": round(k_ms, 3), "prepass_ms": round(pre_ms, 3), "value": total / ((k_ms + pre_ms) * 1e-3), "unit": "anchors/s",
-                                "pieces": pieces, "pieces_one_wave_each": one_wave, "pieces_sixteen_waves_each": coop, "identical_to_oracle": ok}
+                                "pieces": pieces, "pieces_one_wave_each": one_wave, "pieces_several_waves_each": coop, "identical_to_oracle": ok}
             say(f"DP {route:9s}: kernel {k_ms:9.2f} ms + prepass {pre_ms:6.2f} ms = {total / ((k_ms + pre_ms) * 1e-3) / 1e9:6.3f} G anchors/s  "
                 f"(all runs {[round(m[0], 2) for m in ms]})  identical to the oracle: {ok}  pieces {pieces}: {one_wave} x 1 wave, {coop} x 16 waves")
             plan.close()
@@ -112,7 +114,7 @@ def measure(reads, per, routes=("auto",), dp=True, seed=True, reps=3, check=2, p
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="2048x100000,1024x300000,256x1000000")
-    ap.add_argument("--routes", default="auto,one-wave,coop16")
+    ap.add_argument("--routes", default="auto,one-wave,coop16,coop8")
     ap.add_argument("--profile", default="mixed")
     ap.add_argument("--distinct", type=int, default=0, help="distinct reads generated per size (0: about 3.2e6 anchors' worth, at least 2)")
     ap.add_argument("--no-seed", action="store_true")
