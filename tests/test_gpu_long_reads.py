@@ -80,16 +80,19 @@ def test_few_long_reads_take_sixteen_waves_each_and_many_short_ones_one():
     assert route[2] == 0 and "chain_dp_tile" in variant, (route, variant)
 
 
-@pytest.mark.parametrize("case", ["few-pieces", "many-pieces", "segments"])
+@pytest.mark.parametrize("case", ["few-pieces", "more-pieces-than-cus", "many-pieces", "segments"])
 def test_pieces_cut_on_the_device_are_routed_there(case):
     """long tasks that the device cuts at empty windows (chain_cut): 8 reads x 5 loci -> 40 pieces -> sixteen waves per piece, through the piece arrays (start / end / p base /
-    avg per piece, st[] relative to the task); 300 reads x 9 loci -> 2 700 pieces -> one wave per piece.  `segments`: a read whose anchors carry two segment ids is
+    avg per piece, st[] relative to the task); 60 reads x 6 loci -> 360 pieces, more than the GPU has CUs -> EIGHT waves per piece, two workgroups per CU (the count word of
+    that width, chain_route); 300 reads x 9 loci -> 2 700 pieces -> one wave per piece.  `segments`: a read whose anchors carry two segment ids is
     flagged by whichever kernel met it and redone by the general variant"""
     import mm2chain
     from mm2chain import params
     P = params.map_ont()
     if case == "few-pieces":
         tasks = _multi_locus(5, 8, 5, 2500)
+    elif case == "more-pieces-than-cus":
+        tasks = _multi_locus(8, 60, 6, 1500)
     elif case == "many-pieces":
         tasks = _multi_locus(6, 300, 9, 950)
     else:
@@ -103,6 +106,8 @@ def test_pieces_cut_on_the_device_are_routed_there(case):
     assert_same(f, p, f_ref, p_ref, off, f"{case}: {variant}, route {route}")
     if case == "few-pieces":
         assert route == (40, 0, 40), route
+    elif case == "more-pieces-than-cus":
+        assert route == (360, 0, 360), route
     elif case == "many-pieces":
         assert route[0] == 2700 and route[2] == 0, route
     else:

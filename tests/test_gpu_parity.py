@@ -971,12 +971,12 @@ def knobs():
     yield tune
     helpers.PINNED_ROUTE = None
     for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
-                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 2), ("coop_waves", 16), ("coop_max_tasks", 1024), ("q24_ring", 1)):
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 2), ("coop_waves", 16), ("coop_w8_above", 256), ("coop_max_tasks", 1024), ("q24_ring", 1)):
         mm2chain.tune(key, val)
 
 
 @pytest.mark.parametrize("route", ["asm", "asm-32-bit-ring", "asm-tab", "asm-tab-32-bit-ring", "asm-short-ring-only", "asm-long-ring-only", "asm-device-cut", "wave-256", "wave-512", "wave-1024",
-                                   "coop", "coop-tab", "coop-v2-scalars", "asm-q24-ring", "asm-tab-q24-ring", "asm-long-32-bit-ring"])
+                                   "coop", "coop-tab", "coop-v2-scalars", "coop8", "coop8-tab", "coop8-v2-scalars", "asm-q24-ring", "asm-tab-q24-ring", "asm-long-32-bit-ring"])
 def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs):
     """The reference-produced vectors through the instantiations that carry the throughput.  With max_skip = 1023 and max_iter = 1024 the
     max-skip machinery of chain.c:226-233 is compiled in and runs (stamps, skip counter, the folds) but cannot fire: among at most 1024
@@ -995,9 +995,10 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
     if route == "asm-device-cut": knobs("plan_cut_min", 1000); knobs("seg_min", 64)
     if route.startswith("wave-"): knobs("ring_class", {"256": 0, "512": 1, "1024": 2}[route[5:]])
     if route.startswith("coop"): knobs("coop_plans", 1)      # several waves per task (chain_dp_coop.h): what a lone run_chaining_on_hw call runs
-    if route == "coop-tab": knobs("force_tab", 1)
+    if route.startswith("coop8"): knobs("coop_w8_above", 0)  # ... in the width the launcher takes for more pieces than CUs: eight waves, two workgroups per CU
+    if route.endswith("-tab") and route.startswith("coop"): knobs("force_tab", 1)
     # coop-v2-scalars: the scalars of the reference symbol itself (max_skip = INT_MAX, max_iter = 1024), which the launcher maps onto max_skip = max_iter - 1
-    ms = INT32_MAX if route == "coop-v2-scalars" else 1023
+    ms = INT32_MAX if route.endswith("-v2-scalars") else 1023
     z, groups = _ref_cl_groups()
     assert (5000, 5000, 500) in groups and (10000, 10000, 2000) in groups
     n = 0
@@ -1006,7 +1007,8 @@ def test_hand_written_loop_equals_the_references_own_device_kernel(route, knobs)
         f, p = gpu_batch(params.make_params(mdx, mdy, bw, max_skip=ms, max_iter=1024), off, a, variant=v)
         assert_same(f, p, f_ref, p_ref, off, f"{route}, scalars {(mdx, mdy, bw)}: {v[0]}")
         if route.startswith("coop"):
-            assert v[0].startswith("chain_dp_coop<W=16") and "FAR=1" in v[0] and "loop=asm" in v[0] and ("TAB=1" in v[0]) == (route == "coop-tab" and bw <= 511), v
+            assert v[0].startswith("chain_dp_coop<W=8," if route.startswith("coop8") else "chain_dp_coop<W=16,") and "FAR=1" in v[0] and "loop=asm" in v[0], v
+            assert ("TAB=1" in v[0]) == (route.endswith("-tab") and bw <= 511), v
         elif route.startswith("wave-"):
             assert v[0].startswith(f"chain_dp_wave<R={route[5:]},SKIP=1"), v
         else:
