@@ -57,6 +57,7 @@ struct Global {
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never; the value only switches, the width -- 16 or 8 -- goes by coop_w8_above)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> seg_prepass{1};                    // plans with long tasks: the window-start prepass with a block per segment of a task instead of a block per task
 	std::atomic<int> coop_w8_above{256};                // the cooperative kernel: eight waves per piece (two workgroups per CU) in passes of more pieces than this, sixteen up to it
 	std::atomic<int> pin_workers{1};                    // the worker thread of a device slot is pinned to the CPUs of the device's NUMA node (sysfs; 0: left to the scheduler)
 	std::atomic<int> decline_when_busy{0};              // mm2c_chain_task_host_pred / run_chaining_on_hw: the reference's busy protocol (chain_hardware.cpp:54-75).  0 (default since round 6):

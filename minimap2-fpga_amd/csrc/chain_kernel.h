@@ -61,6 +61,8 @@ struct LaunchArgs {
 	int32_t *d_st;              // window start per anchor (chain.c:192-193), filled by the prepass kernel
 	int32_t *d_status;          // per task, must be zero on entry
 	int64_t max_task_anchors = 0;   // length of the longest task when the caller knows it (0: unknown): lets a small pass size a grid of one block per 256 anchors (chain_window_start_wide)
+	int64_t longest_task = 0;       // the same for a batch of any size, with d_seg_ws: long tasks are given a prepass block per segment (chain_window_start_t<true>) -- 0: a block per task
+	unsigned long long *d_seg_ws = nullptr;   // 4 words of 64 bits per task, zero before the first run (the prepass leaves them zero)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
 	int coop_w8_above = 256;    // the cooperative kernel takes eight waves per piece (two workgroups per CU) beyond this many pieces, sixteen up to it (chain_kernel.hip: launch_coop)
 	                            // < 0 (with a device-side cut): decided on the device once the pieces are known (chain_route): few long pieces -> the cooperative kernel

@@ -240,24 +240,35 @@ __device__ __forceinline__ void scan_window(const KParams &P, float avg, int lan
 	}
 }
 
+constexpr int PREPASS_SEG = 32768;   // anchors of a long task per block of the prepass (chain_window_start_t<true>)
 // ---------------------------------------------------------------- prepass: window start of every anchor
 // st[i] = max(first j of the task with x_i <= x_j + max_dist_x, i - max_iter), chain.c:192-193 (the `st` pointer of the
 // reference is monotone, so its value at i is exactly this).  Full 64-bit compares, so inside
 // [st[i], i) every x difference fits 31 bits and the DP kernel works on low words.  One 256-thread block per task,
 // each lane a binary search over the task's sorted x (L2-resident); O(n log max_iter) and ~1 % of the DP.
+// SEG (round 6, long reads): a block walks its task's tiles one after the other, so a batch of 255 tasks of 10^6 anchors had 255 blocks at work for 3 900 steps each (2.6 ms
+// of a 4.7 ms prepass, on a GPU that reads the anchors in 0.5).  With SEG a task is `seg_anchors` (a multiple of 256: the tiles, and with them the lanes' neighbours in the
+// class count, stay the same) per block, blockIdx.y the segment: the first tiles of a segment search in memory until the window start of the tile before lies inside the
+// segment (two tiles, typically), the sums and extremes of a task are added up in `seg_ws` (4 words of 64 bits per task, zero between runs) and the block that arrives
+// last writes avg / class and puts the words back to zero.  The answers are the same by construction: same bounds, same condition, integer sums.
+template <bool SEG>
 __global__ void __launch_bounds__(256)
-chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+chain_window_start_t(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
                    const ulonglong2 *__restrict__ a_all, int32_t *__restrict__ st_all, int32_t *__restrict__ has_cut /* per task, or nullptr */,
                    float *__restrict__ avg_out /* per task, or nullptr */, uint8_t *__restrict__ cls_out /* per task, or nullptr */, int far_ring, int far_thr10,
                    unsigned long long *__restrict__ cls_stat /* CLS_STAT_SLOTS sets of [anchors of class-1 tasks, of all tasks, -, of tasks with the 32-bit ring], or nullptr */,
                    unsigned q_span_max /* compact x / q ring: the widest span of q values a task may have (0: no task takes it) */,
-                   int q24 /* the long ring is the q24 ring: a task with a q value of 2^24 or more stays out of class 1 (and carries bit 2) */)
+                   int q24 /* the long ring is the q24 ring: a task with a q value of 2^24 or more stays out of class 1 (and carries bit 2) */,
+                   int seg_anchors, unsigned long long *__restrict__ seg_ws)
 {
 	const int lane = threadIdx.x;
 	const int64_t task = order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
 	if (task >= n_tasks) return;
 	const int64_t base = offsets[task];
 	const int n = (int)(offsets[task + 1] - base);
+	const int s0 = SEG ? (int)min((long long)blockIdx.y * seg_anchors, (long long)INT_MAX) : 0;
+	if (SEG && s0 >= n) return;
+	const int s1 = SEG ? (int)min((long long)s0 + seg_anchors, (long long)n) : n;
 	const ulonglong2 *a = a_all + base;
 	int32_t *st = st_all + base;
 	const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
@@ -277,8 +288,8 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 	const int max_dq = min(P.max_dist_x, P.max_dist_y);
 	uint64_t far_sum = 0;                                             // expected tiles beyond the short ring, see below
 	uint64_t span_sum = 0;                                            // chain.c:48: spans of this lane's anchors
-	ulonglong2 nxt = lane < n ? a[lane] : make_ulonglong2(0, 0);
-	for (int i0 = 0; i0 < n; i0 += 256) {                          // 4 waves per task
+	ulonglong2 nxt = s0 + lane < n ? a[s0 + lane] : make_ulonglong2(0, 0);
+	for (int i0 = s0; i0 < s1; i0 += 256) {                        // 4 waves per task (or segment)
 		const int i = i0 + lane, cnt = min(256, n - i0);
 		const ulonglong2 cur = nxt;
 		if (i < n) { s_x[i & (RING - 1)] = cur.x; span_sum += (cur.y >> 32) & 0xff; q_min = min(q_min, (int)(uint32_t)cur.y); q_max = max(q_max, (int)(uint32_t)cur.y); }
@@ -290,7 +301,7 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 			const uint64_t xi = cur.x;
 			int hi = i;
 			lo = max(i - P.max_iter, range_lo);                       // answer in [lo, hi]; x_i <= x_i + D always holds
-			if (len <= RING) {
+			if (len <= RING && (!SEG || range_lo >= s0)) {           // (SEG: the ring holds the segment's own anchors only)
 				while (lo < hi) {
 					const int mid = (lo + hi) >> 1;
 					if (xi > s_x[mid & (RING - 1)] + D) lo = mid + 1; else hi = mid;   // chain.c:192 condition for "++st"
@@ -324,6 +335,32 @@ chain_window_start(KParams P, int64_t n_tasks, const int64_t *__restrict__ offse
 		}
 		__syncthreads();                                            // everybody has read s_prev and is done with the ring slots the next tile overwrites
 		if (i < n && lane == cnt - 1) s_prev = lo;
+	}
+	if constexpr (SEG) {
+		// the segment's share of the task's sums and extremes -> seg_ws[4 * task ..]: [0] spans, [1] far tiles, [2] low word max of ~(q_min biased), high word max of
+		// (q_max biased) (unsigned maxima: zero is "nothing yet"), [3] segments done; the last segment to arrive goes on with the totals
+		for (int o = 32; o > 0; o >>= 1) { q_min = min(q_min, __shfl_xor(q_min, o)); q_max = max(q_max, __shfl_xor(q_max, o)); far_sum += __shfl_xor(far_sum, o); span_sum += __shfl_xor(span_sum, o); }
+		if ((lane & 63) == 0) { atomicMin(&s_qmin, q_min); atomicMax(&s_qmax, q_max); if (far_sum) atomicAdd(&s_far, (unsigned long long)far_sum); atomicAdd(&s_sum, (unsigned long long)span_sum); }
+		__syncthreads();
+		__shared__ int s_last;
+		unsigned long long *ws = seg_ws + 4 * task;
+		if (lane == 0) {
+			atomicAdd(&ws[0], s_sum); if (s_far) atomicAdd(&ws[1], s_far);
+			atomicMax((unsigned *)&ws[2], ~((unsigned)s_qmin ^ 0x80000000u)); atomicMax((unsigned *)&ws[2] + 1, (unsigned)s_qmax ^ 0x80000000u);
+			__threadfence();
+			const unsigned n_seg = (unsigned)(((long long)n + seg_anchors - 1) / seg_anchors);
+			const bool last = atomicAdd((unsigned *)&ws[3], 1u) == n_seg - 1;
+			s_last = last;
+			if (last) {
+				__threadfence();
+				s_sum = atomicAdd(&ws[0], 0ull); s_far = atomicAdd(&ws[1], 0ull);
+				s_qmin = (int)(~atomicMax((unsigned *)&ws[2], 0u) ^ 0x80000000u); s_qmax = (int)(atomicMax((unsigned *)&ws[2] + 1, 0u) ^ 0x80000000u);
+				ws[0] = 0; ws[1] = 0; ws[2] = 0; ws[3] = 0;                      // zero again for the next run
+			}
+		}
+		__syncthreads();
+		if (!s_last) return;
+		far_sum = 0; span_sum = 0; q_min = s_qmin; q_max = s_qmax;              // (the tail below adds the lanes' shares to the LDS totals: nothing left to add)
 	}
 	if (cls_out && n > 0) {
 		// bit 1: the task's q values span more than the compact x / q ring tells apart (chain_dp_tile.h, Lds<>): it runs with the 32-bit ring
@@ -940,12 +977,19 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		hipLaunchKernelGGL(chain_window_start_wide, dim3((unsigned)L.n_tasks, (unsigned)((L.max_task_anchors + 255) / 256)), dim3(256), 0, st, P, L.n_tasks, L.d_offsets,
 		                   (const ulonglong2 *)L.d_anchors, L.d_st, sums);
 		if (sums) hipLaunchKernelGGL(chain_avg_finish, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_offsets, sums);
-	} else
-	hipLaunchKernelGGL(chain_window_start, dim3((unsigned)L.n_tasks), dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order,
-	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out,
-	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr,
-	                   coop ? 0u : c16_bound,                     // (the cooperative kernel has one ring form: no classes to find)
-	                   (!coop && tile && q24_ring(L, skip, want_gen, gs1, tab)) ? 1 : 0);
+	} else {
+		// long tasks (the caller knows the longest and lends the words for the sums): a block per segment of PREPASS_SEG anchors instead of a block per task
+		// (few tasks only: 2 048 blocks fill the GPU as they are -- 2 048 tasks of 100 000 anchors 1.12 ms by task, 1.46 by segment; 255 of 10^6: 4.7 -> 1.6 ms)
+		const bool seg = L.d_seg_ws != nullptr && L.n_tasks <= 512 && L.longest_task >= 2 * PREPASS_SEG && (L.longest_task + PREPASS_SEG - 1) / PREPASS_SEG <= 65535;
+#define MM2C_WS(SEG, GRID, SEGN, WS) hipLaunchKernelGGL(chain_window_start_t<SEG>, GRID, dim3(256), 0, st, P, L.n_tasks, L.d_offsets, L.d_order, \
+	                   (const ulonglong2 *)L.d_anchors, L.d_st, L.cut.max_pieces > 0 ? L.cut.d_has_cut : (int32_t *)nullptr, avg_out, \
+	                   tile && !coop ? L.d_cls : (uint8_t *)nullptr, L.far_ring, L.far_thr10, tile && !coop ? L.d_cls_stat : (unsigned long long *)nullptr, \
+	                   coop ? 0u : c16_bound,                     /* (the cooperative kernel has one ring form: no classes to find) */ \
+	                   (!coop && tile && q24_ring(L, skip, want_gen, gs1, tab)) ? 1 : 0, SEGN, WS)
+		if (seg) MM2C_WS(true, dim3((unsigned)L.n_tasks, (unsigned)((L.longest_task + PREPASS_SEG - 1) / PREPASS_SEG)), PREPASS_SEG, L.d_seg_ws);
+		else MM2C_WS(false, dim3((unsigned)L.n_tasks), 0, (unsigned long long *)nullptr);
+#undef MM2C_WS
+	}
 	hipError_t e = hipGetLastError();
 	if (n_launches) ++*n_launches;
 	if (e == hipSuccess && tile && !coop && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {

@@ -485,6 +485,7 @@ struct mm2c_plan {
 	const int64_t *d_off_user = nullptr;    // mm2c_plan_set_device_offsets: task sizes that only the device knows
 	int64_t n_tasks = 0, total = 0;
 	int64_t *d_off = nullptr; int32_t *d_order = nullptr, *d_status = nullptr, *d_t = nullptr, *d_st = nullptr; float *d_avg_ws = nullptr; uint8_t *d_cls = nullptr;
+	unsigned long long *d_seg_ws = nullptr; // plans with long tasks: the words in which the segments of a task add up the prepass's sums (chain_window_start_t<true>; zero between runs)
 	hipEvent_t ev_pre = nullptr, ev0 = nullptr, ev1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr;
 	mm2c_api::AuxSet aux;                   // helper stream + fork / join events (pooled): taken by the first run that may split its tasks over two instantiations
 	bool ran = false, epi_ran = false;
@@ -895,6 +896,7 @@ int mm2c_tune(const char *key, int value)
 		G.fused_out = value != 0;
 		return 0;
 	}
+	if (strcmp(key, "seg_prepass") == 0) { G.seg_prepass = value != 0; return MM2C_OK; }   // plans with tasks of 65 536 anchors or more: a prepass block per 32 768 anchors (1) or per task (0)
 	if (strcmp(key, "coop_w8_above") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "coop_w8_above must be >= 0 (pieces beyond which the cooperative kernel takes eight waves per piece instead of sixteen)");
 		G.coop_w8_above = (int)std::min<int64_t>(value, 1 << 30);
@@ -1004,6 +1006,10 @@ mm2c_plan_t *mm2c_plan_create(const mm2c_params_t *par, int64_t n_tasks, const i
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_st, tot * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_avg_ws, nt * 4);
 	if (e == hipSuccess) e = dev_alloc((void **)&pl->d_cls, ((nt + 15) & ~(size_t)15) + 32 * mm2c::CLS_STAT_SLOTS);   // class per task + the counter sets of chain_cls_settle
+	if (e == hipSuccess && n_tasks > 0 && pl->sizes_desc[0] >= 65536) {                                              // long tasks: a prepass block per segment of a task
+		e = dev_alloc((void **)&pl->d_seg_ws, nt * 32);
+		if (e == hipSuccess) e = hipMemset(pl->d_seg_ws, 0, nt * 32);
+	}
 	if (e == hipSuccess && n_tasks > 0) {
 		// rebase offsets so that task 0 starts at 0 of the arrays handed to mm2c_plan_run_device
 		std::vector<int64_t> off((size_t)n_tasks + 1);
@@ -1029,7 +1035,7 @@ static void plan_destroy_impl(mm2c_plan_t *pl, bool wait)
 		DeviceScope on(pl->device);
 		if (wait && (pl->ran || pl->epi_ran)) { ScopedNs timed(SS.free_ns); (void)hipDeviceSynchronize(); }   // ONE wait, as hipFree would: the blocks go back to the cache and may be reused at once
 		dev_free_synced(pl->d_off); dev_free_synced(pl->d_order); dev_free_synced(pl->d_status); dev_free_synced(pl->d_t); dev_free_synced(pl->d_st);
-		dev_free_synced(pl->d_avg_ws); dev_free_synced(pl->d_cls); dev_free_synced(pl->d_epi); dev_free_synced(pl->d_cut);
+		dev_free_synced(pl->d_avg_ws); dev_free_synced(pl->d_seg_ws); dev_free_synced(pl->d_cls); dev_free_synced(pl->d_epi); dev_free_synced(pl->d_cut);
 		if (pl->ev_pre) (void)hipEventDestroy(pl->ev_pre);
 		if (pl->ev0) (void)hipEventDestroy(pl->ev0); if (pl->ev1) (void)hipEventDestroy(pl->ev1);
 		if (pl->ev_e0) (void)hipEventDestroy(pl->ev_e0); if (pl->ev_e1) (void)hipEventDestroy(pl->ev_e1);
@@ -1075,6 +1081,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	const int coop_mode = G.coop_waves.load() > 1 ? G.coop_plans.load() : 0;
 	const int64_t longest = pl->sizes_desc.empty() ? 0 : (int64_t)pl->sizes_desc[0];
 	const bool will_cut = G.plan_cut && G.seg_min > 0 && longest >= G.plan_cut_min;
+	if (pl->d_seg_ws && !pl->d_off_user && G.seg_prepass.load()) { L.d_seg_ws = pl->d_seg_ws; L.longest_task = longest; }
 	L.coop_waves = 0; L.coop_w8_above = G.coop_w8_above.load();
 	if (coop_mode == 1 && pl->n_tasks <= G.coop_max_tasks) L.coop_waves = G.coop_waves.load();
 	else if (coop_mode == 2 && !will_cut && !pl->d_off_user && mm2c::coop_pays(pl->n_tasks, longest, pl->total, G.coop_w8_above.load())) L.coop_waves = G.coop_waves.load();

@@ -131,6 +131,34 @@ def test_one_read_of_300000_anchors_among_short_ones():
     assert_same(f, p, f_ref, p_ref, off, f"{variant}, route {route}")
 
 
+def test_prepass_of_long_tasks_by_segments_and_by_task_alike():
+    """plans with a task of 65 536 anchors or more run the window-start prepass with a block per 32 768 anchors of a task (the segments add up the task's sums, the last to
+    arrive writes avg and the ring class); "seg_prepass" 0 keeps a block per task.  Both against the oracle, twice each (the words of the sums must be zero again after a
+    run): uncuttable long reads of sizes around the segment length among short ones, and a long read of several loci (cut flags from every segment)"""
+    import mm2chain
+    from mm2chain import params
+    P = params.ava_ont()
+    parts = [_stream("mixed", 1, n, seed=60 + k, locus=20 * n) for k, n in enumerate((32768 * 2, 32768 * 3 + 1, 70001, 131072 + 255))]
+    parts.append(_stream("mixed", 40, (300, 4000), seed=66))
+    t = np.concatenate(_multi_locus(9, 1, 7, 12000))                                              # 84 000 anchors, seven loci
+    parts.append((np.array([0, t.shape[0]], np.int64), t))
+    a = np.concatenate([x[1] for x in parts])
+    off = np.concatenate([[0]] + [x[0][1:] + sum(y[0][-1] for y in parts[:k]) for k, x in enumerate(parts)]).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    seen = {}
+    try:
+        for seg in (1, 0, 1):
+            mm2chain.tune("seg_prepass", seg)
+            for rep in range(2):
+                f, p, route, variant = _plan_run(P, off, a)
+                assert_same(f, p, f_ref, p_ref, off, f"seg_prepass {seg}, run {rep}: {variant}, route {route}")
+                seen.setdefault(seg, (route, variant))
+                assert (route, variant) == seen[seg]
+        assert seen[0] == seen[1], seen                                                            # the same pieces, the same kernels either way
+    finally:
+        mm2chain.tune("seg_prepass", 1)
+
+
 def test_one_task_at_the_references_buffer_limit():
     """chain_hardware.h:62-64: BUFFER_N = 332 000 000 / 2 / 32 = 5 187 500 anchors is the longest call the reference's device buffers hold (chain_hardware.cpp:34-37 refuses
     more).  One task of exactly that size through the reference's own symbol run_chaining_on_hw (V2 scalars: look-back <= 1 024, no max-skip), compared with the oracle

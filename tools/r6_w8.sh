@@ -1,4 +1,5 @@
 cd /root/repo
 export GPU_MAX_HW_QUEUES=16
-timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu > gpurun_out/w8_suite.txt 2>&1; tail -8 gpurun_out/w8_suite.txt
-MM2C_SOAK_SECONDS=100 timeout -k 10 300 python3 tools/soak.py 100000 600000 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/w8_soak.txt; cat gpurun_out/w8_soak.txt
+timeout -k 10 600 python3 -m pytest tests/test_gpu_long_reads.py -x -q -m gpu > gpurun_out/seg_tests.txt 2>&1 || { tail -30 gpurun_out/seg_tests.txt; exit 1; }
+tail -3 gpurun_out/seg_tests.txt
+timeout -k 10 600 python tools/long_reads.py --no-seed --reps 3 --routes auto --sizes 2048x100000,1024x300000,256x1000000 2>&1 | grep "^==\|^DP" > gpurun_out/seg_long.txt; cat gpurun_out/seg_long.txt
