@@ -302,8 +302,13 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	for (int i0 = 0; i0 < n; i0 += 64) {
 		const int idx = i0 + rl;
 		const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - i0));
-		uint4 nxt = make_uint4(0, 0, 0, 0); int nxt_st = 0;
-		if (idx + 64 < n) { nxt = a[idx + 64]; nxt_st = st[idx + 64] - st_sub; }
+		// The next tile's anchors and window starts, requested a tile ahead -- and NOT looked at before phase A1 (the helpers) or the end of the walk (wave 0): as
+		// `if (in range) load, else 0` the compiler merged the loaded registers with the zeros under the lanes' mask right here, i.e. waited for the memory it had just
+		// asked for, in every wave, at the top of every tile (0.6 us of a tile's 6.5).  So: an unconditional load from a clamped index, the values of lanes beyond the
+		// task's end (copies of its last anchor: phase A1 computes rows for them that nobody reads) replaced by zeros only where `cur` is made from them, a tile later.
+		const bool nxt_in = idx + 64 < n;
+		const int nxt_i = min(idx + 64, n - 1);
+		uint4 nxt = a[nxt_i]; int nxt_st = st[nxt_i];                     // (nxt_st: still relative to the task, st_sub comes off at the uses)
 		int prev_last = rdlane(own_x, 0);
 		own_x = (int)cur.x; own_q = (int)cur.z;
 		own_g = (cur.w >> 16) & 0xff;
@@ -705,6 +710,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			{ const long long tn = wall_clock64(); tp[4] += tn - tq; tq = tn; }
 #endif
 			if (!all_done) flush(64);
+			// (The next tile's anchors, requested at the top of this iteration and not looked at by this wave since: they have long arrived, and saying so HERE -- before
+			// the stores below, which vmcnt would count in front of them -- keeps the wait for `cur = nxt` at the end of the iteration from waiting for the stores as well.)
+			__builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
 			// ---- the finished tile: results leave in coalesced stores and enter the f / p ring
 			if (rl < cnt) {
 				const int pv = own_p < 0 ? own_p : own_p + pbase;
@@ -721,7 +729,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// the candidates of the tiles before this one -- final f, and ring slots nobody writes during the walk (wave 0 puts this tile's f / p into the slot of the tile
 			// NF + 1 back from the next one, which the next tile reads from memory; the x / q of the next tile enter the ring after the barrier)
 			const int t0 = i0 + 64, idn = t0 + rl;
-			const int lo_n = no_pairs ? idn : min(nxt_st, idn);
+			const int lo_n = no_pairs ? idn : min(nxt_st - st_sub, idn);
 			const int lo_first_n = rdlane(lo_n, 63);
 			// (FAR: up to COOP_FAR_TILES tiles beyond the ring are dealt as well, their x / q from memory, so that an anchor whose window reaches a little further back
 			// than the ring -- the 1 024 anchors of a V2 scan are up to 17 tiles -- keeps the short cut)
@@ -735,11 +743,11 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 #if MM2C_COOP_PROBE == 9
 		if (wv == 0) { const long long tn = wall_clock64(); tp[5] += tn - tq; tq = tn; }
 #endif
-		cur = nxt; cur_st = nxt_st;
+		cur = nxt_in ? nxt : make_uint4(0, 0, 0, 0); cur_st = nxt_in ? nxt_st - st_sub : 0;
 	}
 	coop_host_done(H);
 #if MM2C_COOP_PROBE == 9
-	if (lane == 0 && (wv == 1 || wv == 8 || wv == 15) && task == 0) printf("coop helper wave %d ticks: prologue %lld, at barrier 1 %lld, A2 %lld, at barrier 2 %lld, A1 %lld, table %lld\n", wv, th[0], th[1], th[2], th[3], th[4], th[5]);
+	if (lane == 0 && wv >= 1 && task == 0) printf("coop helper wave %d ticks: prologue %lld, at barrier 1 %lld, A2 %lld, at barrier 2 %lld, A1 %lld, table %lld\n", wv, th[0], th[1], th[2], th[3], th[4], th[5]);
 	if (threadIdx.x == 0 && task == 0) printf("coop ticks (100 MHz) n=%d: to barrier1 %lld, A2 %lld, summary %lld, pushes %lld, rest of B %lld, tile end %lld\n", n, tp[1], tp[2], tp[3], tp[4], tp[5], tp[0]);
 #endif
 }
