@@ -57,6 +57,7 @@ struct Global {
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never; the value only switches, the width -- 16 or 8 -- goes by coop_w8_above)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> fuse_st{1};                        // per-read passes: the window starts inside the cooperative kernel (no prepass launch)
 	std::atomic<int> seg_prepass{1};                    // plans with long tasks: the window-start prepass with a block per segment of a task instead of a block per task
 	std::atomic<int> coop_w8_above{256};                // the cooperative kernel: eight waves per piece (two workgroups per CU) in passes of more pieces than this, sixteen up to it
 	std::atomic<int> pin_workers{1};                    // the worker thread of a device slot is pinned to the CPUs of the device's NUMA node (sysfs; 0: left to the scheduler)
@@ -167,8 +168,8 @@ struct ThreadCtx {
 // "chain_dp_tile<...> loop=asm ... compact=1": the text of mm2c_plan_last_variant / mm2c_last_host_variant
 inline void format_variant(const mm2c::LaunchInfo &I, char *buf, size_t len)
 {
-	if (I.tile && I.coop) snprintf(buf, len, "chain_dp_coop<W=%d,NX=%d,NF=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=0 cut=0 compact=0 coop=%d", I.coop, I.nx, I.nf, I.gs1,
-	                               I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.coop);
+	if (I.tile && I.coop) snprintf(buf, len, "chain_dp_coop<W=%d,NX=%d,NF=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=0 cut=0 compact=0 coop=%d st=%s", I.coop, I.nx, I.nf, I.gs1,
+	                               I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.coop, I.fused_st ? "kernel" : "prepass");
 	else if (I.tile) snprintf(buf, len, "chain_dp_tile<NX=%d,NF=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d,TAB=%d> loop=%s classes=%d cut=%d compact=%d q24=%d", I.nx, I.nf, I.skip, I.gen, I.gs1,
 	                     I.far_, I.tab, I.asm_loop ? "asm" : "c++", I.classes, I.cut, I.c16, I.q24);
 	else snprintf(buf, len, "chain_dp_wave<R=%d,SKIP=%d,GEN=%d,GS1=%d,FAR=%d> loop=c++ classes=0 cut=%d", I.r, I.skip, I.gen, I.gs1, I.far_, I.cut);

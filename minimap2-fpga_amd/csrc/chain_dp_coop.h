@@ -51,6 +51,7 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // broadcast read: no bank conflict, no scalar side), f only when some lane passed the filters.  32 tiles cover everything phase A deals (NX - 1 + COOP_FAR_TILES = 19 tiles back), so
 // no candidate of phase A comes from memory any more.
 constexpr int COOP_NC = 32;
+constexpr int COOP_ST_MAX = (2 * 64 * 64 * 4 + COOP_NC * 64 * 12) / 8;   // = 7 168: anchors of a task whose window starts the kernel makes itself (their x in the LDS of the tables and candidate rings)
 template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, CXQ = PAIRS + 2 * 64 * 64 * 4,
                                                        CF = CXQ + COOP_NC * 64 * 8, QCNT = CF + COOP_NC * 64 * 4, BYTES = QCNT + 16; };   // (two sets of summaries and two tables: see the schedule; QCNT: the group counters of phase A1, by tile parity)
 static_assert(COOP_NC >= COOP_NX + COOP_FAR_TILES, "the candidate rings hold every tile phase A deals");
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H, int32_t *st_out, float *avg_out)
 {
 	constexpr int NX = COOP_NX, NF = COOP_NF;
 	constexpr bool SKIP = true, GEN = false;
@@ -242,7 +243,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	const bool key32_ok = n < (1 << 15) && P.span_override <= 255 && P.gap_scale >= 0.f && P.gap_scale <= 4.f && P.bw <= (1 << 17);
 	if (n <= 0) { coop_host_done(H); return; }
 	const uint4 *a = a_all + base0;
-	const int32_t *st = st_all + base0;
+	const int32_t *st = (st_out ? (const int32_t *)st_out : st_all) + base0;   // (st_out: the window starts are made below, by this workgroup)
 	int32_t *f = f_all + base0, *p = p_all + base0, *t = FAR ? t_all + base0 : nullptr;
 	if ((uint32_t)(uintptr_t)(void *)lds != 0) { if (threadIdx.x == 0) status[task] = 3; coop_host_done(H); return; }   // cannot happen: one LDS object per kernel
 	int32_t *const hf = H.f ? H.f + base0 : nullptr, *const hp = H.p ? H.p + base0 : nullptr;
@@ -255,8 +256,30 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		for (int k = lane; k < n; k += 64) sum += (a[k].w & 0xffu);
 		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
 		avg = (float)(__dmul_rn(.01, (double)(float)sum) / (double)n);
+		if (avg_out && threadIdx.x == 0) avg_out[task] = avg;         // (for the second pass of tasks with several segment ids, which expects it in the workspace)
 	}
 	avg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, avg)));
+	if (st_out) {
+		// ---- the window starts of a SHORT task made here instead of by a prepass launch (a per-read pass: one launch less to submit and to wait for; round 6).  st[i] = max(first j
+		// with x_i <= x_j + max_dist_x, i - max_iter), chain.c:192-193, the bounds and the condition of chain_window_start: the task's x (64 bits) go into LDS -- the
+		// space of the pair tables and the candidate rings, not in use before the first tile: COOP_ST_MAX anchors -- and every thread searches there.
+		uint64_t *const s_xs = (uint64_t *)(lds + LY::BYTES + CL::PAIRS);
+		int32_t *const so = st_out + base0;
+		for (int i = (int)threadIdx.x; i < n; i += 64 * W) { const uint4 v = a[i]; s_xs[i] = (uint64_t)v.y << 32 | v.x; }
+		__syncthreads();
+		const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
+		for (int i = (int)threadIdx.x; i < n; i += 64 * W) {
+			const uint64_t xi = s_xs[i];
+			int hi = i, lo = max(i - P.max_iter, 0);
+			while (lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if (xi > s_xs[mid] + D) lo = mid + 1; else hi = mid;               // chain.c:192 condition for "++st"
+			}
+			so[i] = lo;
+		}
+		__threadfence_block();
+		__syncthreads();                                                         // st[] is read below by other threads than wrote it; the LDS space goes back to its owners
+	}
 	if (TAB && wv == 0) {
 		int16_t *const s_gap = (int16_t *)(lds + LY::GAP);
 		for (int dd = lane; dd <= P.bw && dd < 512; dd += 64) {

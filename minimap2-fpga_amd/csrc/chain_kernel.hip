@@ -816,7 +816,7 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 // that holds two fills the waits of one -- its barriers, 52 % of the wave cycles at sixteen -- with the rows of the other: 1 020 reads of 300 000 anchors 129.3 -> 111.3 ms,
 // 2 048 of 100 000 96.1 -> 77.7, while 255 of 10^6 take 153.9 instead of 101.5: profiles/r6_long_reads.md).  `w8_above`: pieces beyond which eight are taken.
 template <int W>
-static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, const int32_t *n_live)
+static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, const int32_t *n_live, int32_t *st_out = nullptr, float *avg_out = nullptr)
 {
 	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);
 	const dim3 block(64 * W);
@@ -825,7 +825,7 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
 	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
-	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut())
+	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut(), (int32_t *)nullptr, (float *)nullptr)
 		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -835,7 +835,7 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 	CoopHostOut H;
 	if (L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG) && !only_flagged) { H.f = L.h_f; H.p = L.h_p; H.d_done = L.d_done; H.h_flag = L.h_flag; H.seq = L.seq; }
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
-	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H)
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H, st_out, avg_out)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -843,6 +843,12 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 }
 
 static int coop_width(const LaunchArgs &L) { return L.n_tasks > (int64_t)L.coop_w8_above ? 8 : 16; }   // (pieces = tasks: no cut on the device)
+
+// a pass of few SHORT tasks whose window starts nobody has made: the sixteen-wave kernel makes them itself (chain_dp_coop.h, st_out) -- no prepass launch
+static bool coop_makes_st(const LaunchArgs &L)
+{
+	return L.fuse_st && !L.st_ready && L.cut.max_pieces == 0 && coop_width(L) == 16 && L.max_task_anchors > 0 && L.max_task_anchors <= COOP_ST_MAX && (L.d_avg != nullptr || L.d_avg_ws != nullptr);
+}
 
 static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, int *n_launches)
 {
@@ -854,7 +860,10 @@ static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream
 		return e;
 	}
 	if (n_launches) ++*n_launches;
-	return coop_width(L) == 8 ? launch_coop_w<8>(L, d_avg, st, tab, only_flagged, nullptr) : launch_coop_w<16>(L, d_avg, st, tab, only_flagged, nullptr);
+	if (coop_width(L) == 8) return launch_coop_w<8>(L, d_avg, st, tab, only_flagged, nullptr);
+	const bool makes = coop_makes_st(L) && !only_flagged;
+	// (no avg handed in: the kernel sweeps the task itself and leaves the value in the workspace)
+	return launch_coop_w<16>(L, makes && !L.d_avg ? (const float *)nullptr : d_avg, st, tab, only_flagged, nullptr, makes ? L.d_st : (int32_t *)nullptr, makes && !L.d_avg ? L.d_avg_ws : (float *)nullptr);
 }
 
 template <bool SKIP, bool FAR>
@@ -948,6 +957,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	if (coop_auto) { L.cut.d_live = L.cut.d_count + 1; L.cut.w8_above = L.coop_w8_above; }
 	if (info) {
 		info->route_auto = coop_auto ? 1 : 0;
+		info->fused_st = coop && coop_makes_st(L) ? 1 : 0;
 		info->host_out = (coop && L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG)) ? 1 : 0;
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
 		info->coop = coop ? coop_width(L) : 0;
@@ -969,8 +979,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	// 3.9 -> about 1 ms, one block per task walks its tiles one after the other)
 	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && (L.d_avg != nullptr || L.d_avg_ws != nullptr) && L.cut.max_pieces == 0
 	                          && (L.max_task_anchors + 255) / 256 <= 65535;
-	if (coop && L.st_ready && L.d_avg != nullptr) {
-		// nothing to launch: st[] came with the pass (mm2chain_host.cpp), avg was handed in, the cooperative kernel has no classes
+	if (coop && ((L.st_ready && L.d_avg != nullptr) || coop_makes_st(L))) {
+		// nothing to launch: st[] came with the pass (mm2chain_host.cpp) and avg was handed in, or the cooperative kernel makes both itself (short tasks); it has no classes
 	} else if (wide_prepass) {
 		unsigned *sums = L.d_avg ? nullptr : (unsigned *)L.d_avg_ws;
 		if (sums && hipMemsetAsync(sums, 0, (size_t)L.n_tasks * 4, st) != hipSuccess) return hipGetLastError();

@@ -896,6 +896,7 @@ int mm2c_tune(const char *key, int value)
 		G.fused_out = value != 0;
 		return 0;
 	}
+	if (strcmp(key, "fuse_st") == 0) { G.fuse_st = value != 0; return MM2C_OK; }   // passes of few tasks of at most 7 168 anchors: the sixteen-wave kernel makes the window starts itself (1) or a prepass launch does (0)
 	if (strcmp(key, "seg_prepass") == 0) { G.seg_prepass = value != 0; return MM2C_OK; }   // plans with tasks of 65 536 anchors or more: a prepass block per 32 768 anchors (1) or per task (0)
 	if (strcmp(key, "coop_w8_above") == 0) {
 		if (value < 0) return fail(MM2C_E_ARG, "coop_w8_above must be >= 0 (pieces beyond which the cooperative kernel takes eight waves per piece instead of sixteen)");
@@ -1082,7 +1083,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	const int64_t longest = pl->sizes_desc.empty() ? 0 : (int64_t)pl->sizes_desc[0];
 	const bool will_cut = G.plan_cut && G.seg_min > 0 && longest >= G.plan_cut_min;
 	if (pl->d_seg_ws && !pl->d_off_user && G.seg_prepass.load()) { L.d_seg_ws = pl->d_seg_ws; L.longest_task = longest; }
-	L.coop_waves = 0; L.coop_w8_above = G.coop_w8_above.load();
+	L.coop_waves = 0; L.coop_w8_above = G.coop_w8_above.load(); L.fuse_st = G.fuse_st.load();
 	if (coop_mode == 1 && pl->n_tasks <= G.coop_max_tasks) L.coop_waves = G.coop_waves.load();
 	else if (coop_mode == 2 && !will_cut && !pl->d_off_user && mm2c::coop_pays(pl->n_tasks, longest, pl->total, G.coop_w8_above.load())) L.coop_waves = G.coop_waves.load();
 	else if (coop_mode == 2 && will_cut) L.coop_waves = -1;

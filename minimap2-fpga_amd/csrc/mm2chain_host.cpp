@@ -211,7 +211,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			HIP_TRY(hipMemcpyAsync(c->d_in + o_a + (size_t)a0 * 16, src + a0, (size_t)(a1 - a0) * 16, hipMemcpyHostToDevice, c->st_up));
 			HIP_TRY(hipEventRecord(ev_up, c->st_up));
 			HIP_TRY(hipStreamWaitEvent(st, ev_up, 0));
-			mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
+			mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load(); L.fuse_st = G.fuse_st.load();
 			L.P = to_kparams(par);
 			L.n_tasks = s1 - s0; L.d_offsets = (const int64_t *)(c->d_in + o_off) + s0; L.d_order = nullptr;
 			L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg) + s0;
@@ -262,7 +262,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			at += nb;
 		}
 	}
-	mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
+	mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load(); L.fuse_st = G.fuse_st.load();
 	L.P = to_kparams(par);
 	L.n_tasks = n_seg; L.d_offsets = (const int64_t *)(c->d_in + o_off); L.d_order = (const int32_t *)(c->d_in + o_ord);
 	L.d_anchors = c->d_in + o_a; L.d_avg = kernel_avg ? nullptr : (const float *)(c->d_in + o_avg); L.d_pbase = (const int32_t *)(c->d_in + o_pb);
@@ -701,7 +701,7 @@ int mm2c_mm_chain_dp_batch_host(const mm2c_params_t *par, int min_cnt, int min_s
 		HIP_TRY(hipMemcpyAsync(w.d_in + o_off, w.h_meta, meta_bytes, hipMemcpyHostToDevice, w.st));
 		HIP_TRY(hipMemcpyAsync(w.d_in, a0 + (h_offsets[k0] - h_offsets[0]), tot * 16, hipMemcpyHostToDevice, w.st));
 		int32_t *d_f = (int32_t *)w.d_work, *d_p = d_f + tot;
-		mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load();
+		mm2c::LaunchArgs L; L.coop_w8_above = G.coop_w8_above.load(); L.fuse_st = G.fuse_st.load();
 		L.P = to_kparams(par);
 		L.n_tasks = (int64_t)nt; L.d_offsets = (const int64_t *)(w.d_in + o_off); L.d_order = (const int32_t *)(w.d_in + o_ord);
 		L.d_anchors = w.d_in; L.d_avg = nullptr; L.d_pbase = nullptr; L.d_status = (int32_t *)(w.d_in + o_stat);

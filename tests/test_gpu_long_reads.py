@@ -131,6 +131,46 @@ def test_one_read_of_300000_anchors_among_short_ones():
     assert_same(f, p, f_ref, p_ref, off, f"{variant}, route {route}")
 
 
+@pytest.mark.parametrize("preset", ["map_ont", "ava_ont", "v2"])
+def test_window_starts_made_inside_the_sixteen_wave_kernel(preset):
+    """a pass of few short tasks (a per-read call): the cooperative kernel makes st[] itself -- the task's x in LDS, every thread a binary search with the bounds and the
+    condition of chain.c:192-193 -- instead of a prepass launch; tasks of more than 7 168 anchors keep the prepass.  Both ways against the oracle: sizes around the tile
+    (64) and the cap, one target id and several (the search compares 64 bits), and the host entry a per-read call takes (run_chaining_on_hw's scalars for `v2`)"""
+    import mm2chain
+    from mm2chain import params
+    P = {"map_ont": params.map_ont(), "ava_ont": params.ava_ont(),
+         "v2": params.make_params(max_skip=2**31 - 1, max_iter=1024, q_span_override=15, flags=mm2chain.MM2C_F_IGNORE_SEG)}[preset]
+    sizes = [1, 2, 63, 64, 65, 129, 700, 3000, 7167, 7168]
+    parts = [_stream("mixed", 1, n, seed=80 + k) for k, n in enumerate(sizes)]
+    t = np.concatenate(_multi_locus(10, 1, 4, 1200))                                               # 4 800 anchors on four target ids
+    parts.append((np.array([0, t.shape[0]], np.int64), t))
+    a = np.concatenate([x[1] for x in parts])
+    off = np.concatenate([[0]] + [x[0][1:] + sum(y[0][-1] for y in parts[:k]) for k, x in enumerate(parts)]).astype(np.int64)
+    f_ref, p_ref = oracle_batch(P, off, a)
+    try:
+        mm2chain.tune("coop_plans", 1)
+        for fuse, want in ((1, "st=kernel"), (0, "st=prepass"), (1, "st=kernel")):
+            mm2chain.tune("fuse_st", fuse)
+            f, p, route, variant = _plan_run(P, off, a)
+            assert_same(f, p, f_ref, p_ref, off, f"{preset}, fuse_st {fuse}: {variant}")
+            assert variant.startswith("chain_dp_coop<W=16") and want in variant, variant
+        # one task beyond the cap in the plan: the prepass again
+        o2, a2 = _stream("mixed", 1, 7169, seed=99)
+        off2 = np.concatenate([off, off[-1:] + 7169]); a_2 = np.concatenate([a, a2])
+        f_ref2, p_ref2 = oracle_batch(P, off2, a_2)
+        f, p, route, variant = _plan_run(P, off2, a_2)
+        assert_same(f, p, f_ref2, p_ref2, off2, f"{preset}, a task of 7 169 anchors: {variant}")
+        assert "st=prepass" in variant, variant
+        # the per-read host entry (staged pass -> the same kernel)
+        for k in (3, 6, 10):
+            t_k = a[off[k]:off[k + 1]]
+            avg = ob.avg_qspan(t_k)
+            f, p = mm2chain.chain_task(P, t_k, avg)
+            assert_same(f, p, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"{preset}, chain_task of {t_k.shape[0]} anchors: {mm2chain.last_host_variant()}")
+    finally:
+        mm2chain.tune("coop_plans", 2); mm2chain.tune("fuse_st", 1)
+
+
 def test_prepass_of_long_tasks_by_segments_and_by_task_alike():
     """plans with a task of 65 536 anchors or more run the window-start prepass with a block per 32 768 anchors of a task (the segments add up the task's sums, the last to
     arrive writes avg and the ring class); "seg_prepass" 0 keeps a block per task.  Both against the oracle, twice each (the words of the sums must be zero again after a
