@@ -578,6 +578,8 @@ int mm2c_init(int device_ordinal)
 	if (q4) G.q24_ring = atoi(q4) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
+	const char *fs = getenv("MM2C_FUSE_ST");             // 0: per-read passes keep the prepass launch for the window starts (experiments)
+	if (fs) G.fuse_st = atoi(fs) != 0;
 	const char *dwb = getenv("MM2C_DECLINE_WHEN_BUSY");  // a path-A host (no mm2c_tune call site) opts into the busy protocol here: 1 / 2 = the rules of mm2chain_host.cpp, book_pred
 	if (dwb) G.decline_when_busy = std::max(0, std::min(2, atoi(dwb)));
 	const char *ft = getenv("MM2C_FAR_RING_THRESHOLD");  // tenths of an expected far tile per anchor from which a task takes the long ring
