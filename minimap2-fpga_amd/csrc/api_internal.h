@@ -57,6 +57,7 @@ struct Global {
 	std::atomic<int> seg_min{256};                      // shortest piece a task is cut into at empty-window positions (0 = never cut)
 	std::atomic<int> coop_waves{16};                    // passes of at most coop_max_tasks tasks: several waves per task (chain_dp_coop; 0 or 1: never; the value only switches, the width -- 16 or 8 -- goes by coop_w8_above)
 	std::atomic<int64_t> coop_max_tasks{1024};
+	std::atomic<int> single_launch{1};                  // per-read passes of short tasks: ONE launch -- the cooperative kernel reads the pass from the pinned arena itself (no stage_in)
 	std::atomic<int> fuse_st{1};                        // per-read passes: the window starts inside the cooperative kernel (no prepass launch)
 	std::atomic<int> seg_prepass{1};                    // plans with long tasks: the window-start prepass with a block per segment of a task instead of a block per task
 	std::atomic<int> coop_w8_above{256};                // the cooperative kernel: eight waves per piece (two workgroups per CU) in passes of more pieces than this, sixteen up to it
@@ -151,11 +152,12 @@ struct ThreadCtx {
 	char *h_in = nullptr, *h_out = nullptr;                          // pinned host
 	unsigned *h_flag = nullptr;                                      // pinned host: the word stage_out raises when a direct pass is done (host_stage.hip)
 	unsigned seq = 0;                                                // number of the context's last direct pass (the value the flag takes)
+	unsigned *d_cnt = nullptr;                                       // device: the counter of finished workgroups of a direct pass (zero between passes: whoever counts last puts it back)
 	size_t cap_in = 0, cap_out = 0, cap_scratch = 0, cap_hin = 0, cap_hout = 0;
 	void release()
 	{
 		if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_scratch) (void)hipFree(d_scratch);
-		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); if (h_flag) (void)hipHostFree(h_flag);
+		if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); if (h_flag) (void)hipHostFree(h_flag); if (d_cnt) (void)hipFree(d_cnt);
 		if (st) (void)hipStreamDestroy(st); if (st2) (void)hipStreamDestroy(st2); if (ev) (void)hipEventDestroy(ev);
 		if (st3) (void)hipStreamDestroy(st3); if (st_up) (void)hipStreamDestroy(st_up);
 		for (hipEvent_t e : evs) (void)hipEventDestroy(e);

@@ -197,7 +197,7 @@ __device__ __forceinline__ void coop_rows4_d1(bool edge, int lds_xq, int lds_f, 
 // exactly as stage_out did (host_stage.hip).  Only for a pass whose tasks cannot be flagged for the general variant (segment ids ignored): nothing rewrites f / p then.
 struct CoopHostOut {
 	int32_t *f = nullptr, *p = nullptr;       // the caller's result buffer (page-locked, mapped), indexed like f_all / p_all; nullptr: device arrays only
-	unsigned *d_done = nullptr;               // workgroups finished (zeroed by stage_in of the same pass)
+	unsigned *d_done = nullptr;               // workgroups finished (zero between passes: the last to be counted puts it back)
 	unsigned *h_flag = nullptr; unsigned seq = 0;
 };
 __device__ __forceinline__ void coop_host_done(const CoopHostOut &H)
@@ -208,6 +208,7 @@ __device__ __forceinline__ void coop_host_done(const CoopHostOut &H)
 	if (threadIdx.x == 0) {
 		const unsigned done = __hip_atomic_fetch_add(H.d_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == gridDim.x - 1) {
+			__hip_atomic_store(H.d_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next pass (a single-launch pass has no stage_in to do it)
 			__threadfence_system();
 			__hip_atomic_store(H.h_flag, H.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H, int32_t *st_out, float *avg_out)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H, int32_t *st_out, float *avg_out, const uint4 *a_src)
 {
 	constexpr int NX = COOP_NX, NF = COOP_NF;
 	constexpr bool SKIP = true, GEN = false;
@@ -263,9 +264,13 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		// ---- the window starts of a SHORT task made here instead of by a prepass launch (a per-read pass: one launch less to submit and to wait for; round 6).  st[i] = max(first j
 		// with x_i <= x_j + max_dist_x, i - max_iter), chain.c:192-193, the bounds and the condition of chain_window_start: the task's x (64 bits) go into LDS -- the
 		// space of the pair tables and the candidate rings, not in use before the first tile: COOP_ST_MAX anchors -- and every thread searches there.
+		// a_src (a single-launch pass, round 6): the anchors are still in the caller's pinned arena -- this sweep IS their upload (every workgroup its own task: what
+		// stage_in did for the whole pass in a launch of its own), the copy in device memory is what the tiles below read.
 		uint64_t *const s_xs = (uint64_t *)(lds + LY::BYTES + CL::PAIRS);
 		int32_t *const so = st_out + base0;
-		for (int i = (int)threadIdx.x; i < n; i += 64 * W) { const uint4 v = a[i]; s_xs[i] = (uint64_t)v.y << 32 | v.x; }
+		const uint4 *const src = a_src ? a_src + base0 : a;
+		uint4 *const aw = a_src ? const_cast<uint4 *>(a_all) + base0 : nullptr;
+		for (int i = (int)threadIdx.x; i < n; i += 64 * W) { const uint4 v = src[i]; if (aw) aw[i] = v; s_xs[i] = (uint64_t)v.y << 32 | v.x; }
 		__syncthreads();
 		const uint64_t D = (uint64_t)(int64_t)P.max_dist_x;
 		for (int i = (int)threadIdx.x; i < n; i += 64 * W) {
@@ -279,6 +284,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 		}
 		__threadfence_block();
 		__syncthreads();                                                         // st[] is read below by other threads than wrote it; the LDS space goes back to its owners
+		if (a_src) asm volatile("" : "+s"(a) :: "memory");                       // (the anchors were WRITTEN through another name a moment ago: what is read through `a` from here on is not known to the compiler)
 	}
 	if (TAB && wv == 0) {
 		int16_t *const s_gap = (int16_t *)(lds + LY::GAP);

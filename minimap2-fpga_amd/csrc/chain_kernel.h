@@ -64,6 +64,9 @@ struct LaunchArgs {
 	int64_t longest_task = 0;       // the same for a batch of any size, with d_seg_ws: long tasks are given a prepass block per segment (chain_window_start_t<true>) -- 0: a block per task
 	unsigned long long *d_seg_ws = nullptr;   // 4 words of 64 bits per task, zero before the first run (the prepass leaves them zero)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
+	int dry_run = 0;            // 1: launch_chain_dp fills `info` (which kernel a pass would take, whether it makes its window starts, whether it writes the caller's buffer) and launches nothing
+	const void *h_anchors = nullptr;   // a single-launch per-read pass: d_anchors has not been uploaded -- the cooperative kernel copies every task from here (same layout, pinned and mapped) itself;
+	                                   // d_offsets / d_order / d_avg / d_pbase then point into the pinned arena as well (the kernel reads them once per workgroup)
 	int fuse_st = 1;            // a pass of few short tasks (<= COOP_ST_MAX anchors each, max_task_anchors known) for the sixteen-wave kernel: it makes the window starts itself, no prepass launch
 	int coop_w8_above = 256;    // the cooperative kernel takes eight waves per piece (two workgroups per CU) beyond this many pieces, sixteen up to it (chain_kernel.hip: launch_coop)
 	                            // < 0 (with a device-side cut): decided on the device once the pieces are known (chain_route): few long pieces -> the cooperative kernel
@@ -89,6 +92,7 @@ struct LaunchInfo {
 	int cut;         // tasks are cut into pieces on the device first
 	int coop;        // waves per task of the cooperative kernel (chain_dp_coop), 0: one wave per task
 	int host_out;    // 1: the cooperative kernel wrote f / p to the caller's buffer and raised the flag itself (LaunchArgs::h_f ...)
+	int single_ok;   // 1: a pass like this one can run as ONE launch (the cooperative kernel makes the window starts, writes the caller's buffer and can read the pinned arena itself)
 	int fused_st;    // 1: the cooperative kernel made the window starts itself (no prepass launch)
 	int route_auto;  // 1: which of the two ran is decided on the device after the cut (chain_route; CutArgs::d_count[1], [2] say which)
 };

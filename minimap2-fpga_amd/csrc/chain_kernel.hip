@@ -816,7 +816,7 @@ static hipError_t launch_tile_one(const LaunchArgs &L, const float *d_avg, hipSt
 // that holds two fills the waits of one -- its barriers, 52 % of the wave cycles at sixteen -- with the rows of the other: 1 020 reads of 300 000 anchors 129.3 -> 111.3 ms,
 // 2 048 of 100 000 96.1 -> 77.7, while 255 of 10^6 take 153.9 instead of 101.5: profiles/r6_long_reads.md).  `w8_above`: pieces beyond which eight are taken.
 template <int W>
-static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, const int32_t *n_live, int32_t *st_out = nullptr, float *avg_out = nullptr)
+static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStream_t st, bool tab, int only_flagged, const int32_t *n_live, int32_t *st_out = nullptr, float *avg_out = nullptr, const uint4 *a_src = nullptr)
 {
 	const bool far_ = (int64_t)L.P.max_iter > 64 * (COOP_NX - 1);
 	const dim3 block(64 * W);
@@ -825,7 +825,7 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
 	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
-	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut(), (int32_t *)nullptr, (float *)nullptr)
+	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut(), (int32_t *)nullptr, (float *)nullptr, (const uint4 *)nullptr)
 		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -835,7 +835,7 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 	CoopHostOut H;
 	if (L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG) && !only_flagged) { H.f = L.h_f; H.p = L.h_p; H.d_done = L.d_done; H.h_flag = L.h_flag; H.seq = L.seq; }
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
-	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H, st_out, avg_out)
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H, st_out, avg_out, H.h_flag ? a_src : (const uint4 *)nullptr)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -863,7 +863,8 @@ static hipError_t launch_coop(const LaunchArgs &L, const float *d_avg, hipStream
 	if (coop_width(L) == 8) return launch_coop_w<8>(L, d_avg, st, tab, only_flagged, nullptr);
 	const bool makes = coop_makes_st(L) && !only_flagged;
 	// (no avg handed in: the kernel sweeps the task itself and leaves the value in the workspace)
-	return launch_coop_w<16>(L, makes && !L.d_avg ? (const float *)nullptr : d_avg, st, tab, only_flagged, nullptr, makes ? L.d_st : (int32_t *)nullptr, makes && !L.d_avg ? L.d_avg_ws : (float *)nullptr);
+	return launch_coop_w<16>(L, makes && !L.d_avg ? (const float *)nullptr : d_avg, st, tab, only_flagged, nullptr, makes ? L.d_st : (int32_t *)nullptr, makes && !L.d_avg ? L.d_avg_ws : (float *)nullptr,
+	                         makes && L.d_avg ? (const uint4 *)L.h_anchors : (const uint4 *)nullptr);
 }
 
 template <bool SKIP, bool FAR>
@@ -959,6 +960,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		info->route_auto = coop_auto ? 1 : 0;
 		info->fused_st = coop && coop_makes_st(L) ? 1 : 0;
 		info->host_out = (coop && L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG)) ? 1 : 0;
+		info->single_ok = info->fused_st && info->host_out && L.d_avg != nullptr;   // such a pass can do without stage_in (LaunchArgs::h_anchors)
 		const bool t0 = tile && (!want_gen || tile_gen);          // pass 0 runs in the tile kernel
 		info->coop = coop ? coop_width(L) : 0;
 		info->tile = t0; info->nx = t0 ? MM2C_NX : 0; info->nf = t0 ? MM2C_NF : 0; info->r = t0 ? 64 * (MM2C_NX - 1) : (tile ? 256 : R);
@@ -970,6 +972,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 		info->cut = L.cut.max_pieces > 0;
 		if (coop) { info->nx = COOP_NX; info->nf = COOP_NF; info->r = 64 * (COOP_NX - 1); info->far_ = (int64_t)P.max_iter > 64 * (COOP_NX - 1); info->classes = 0; info->c16 = 0; info->q24 = 0; }
 	}
+	if (L.dry_run) return hipSuccess;                                  // the caller only wanted to know (info)
 	// avg_qspan_scaled per task: the caller's, or computed by the prepass into the workspace (else the DP kernel sweeps the task itself)
 	float *avg_out = L.d_avg ? nullptr : L.d_avg_ws;
 	const float *d_avg = L.d_avg ? L.d_avg : L.d_avg_ws;
@@ -979,7 +982,8 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 	// 3.9 -> about 1 ms, one block per task walks its tiles one after the other)
 	const bool wide_prepass = coop && L.max_task_anchors > 0 && L.max_task_anchors <= (1 << 22) && (L.d_avg != nullptr || L.d_avg_ws != nullptr) && L.cut.max_pieces == 0
 	                          && (L.max_task_anchors + 255) / 256 <= 65535;
-	if (coop && ((L.st_ready && L.d_avg != nullptr) || coop_makes_st(L))) {
+	const bool no_prepass = coop && ((L.st_ready && L.d_avg != nullptr) || coop_makes_st(L));
+	if (no_prepass) {
 		// nothing to launch: st[] came with the pass (mm2chain_host.cpp) and avg was handed in, or the cooperative kernel makes both itself (short tasks); it has no classes
 	} else if (wide_prepass) {
 		unsigned *sums = L.d_avg ? nullptr : (unsigned *)L.d_avg_ws;
@@ -1001,7 +1005,7 @@ hipError_t launch_chain_dp(const LaunchArgs &L_in, hipStream_t st, int *n_launch
 #undef MM2C_WS
 	}
 	hipError_t e = hipGetLastError();
-	if (n_launches) ++*n_launches;
+	if (n_launches && !no_prepass) ++*n_launches;
 	if (e == hipSuccess && tile && !coop && L.d_cls && L.d_cls_stat && (L.far_ring == 1 || c16_bound != 0)) {
 		hipLaunchKernelGGL(chain_cls_settle, dim3((unsigned)((L.n_tasks + 255) / 256)), dim3(256), 0, st, L.n_tasks, L.d_cls, L.d_cls_stat, L.far_ring == 1 ? 1 : 0,
 		                   c16_bound != 0 ? L.wide_pct : 100);

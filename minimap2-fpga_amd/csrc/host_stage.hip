@@ -34,6 +34,7 @@ stage_out(const uint4 *__restrict__ d_src, uint4 *__restrict__ h_dst, int64_t n1
 	if (threadIdx.x == 0) {
 		const unsigned done = __hip_atomic_fetch_add(d_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		if (done == gridDim.x - 1) {
+			__hip_atomic_store(d_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next pass (which may have no stage_in)
 			__threadfence_system();
 			__hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}

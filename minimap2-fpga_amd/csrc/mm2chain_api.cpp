@@ -578,6 +578,8 @@ int mm2c_init(int device_ordinal)
 	if (q4) G.q24_ring = atoi(q4) != 0;
 	const char *cr = getenv("MM2C_COMPACT_RING");        // 0: never the compact x / q ring of the tile kernel (experiments; the tests use mm2c_tune)
 	if (cr) G.compact_ring = atoi(cr) != 0;
+	const char *sl = getenv("MM2C_SINGLE_LAUNCH");       // 0: per-read passes keep stage_in (experiments)
+	if (sl) G.single_launch = atoi(sl) != 0;
 	const char *fs = getenv("MM2C_FUSE_ST");             // 0: per-read passes keep the prepass launch for the window starts (experiments)
 	if (fs) G.fuse_st = atoi(fs) != 0;
 	const char *dwb = getenv("MM2C_DECLINE_WHEN_BUSY");  // a path-A host (no mm2c_tune call site) opts into the busy protocol here: 1 / 2 = the rules of mm2chain_host.cpp, book_pred
@@ -898,6 +900,7 @@ int mm2c_tune(const char *key, int value)
 		G.fused_out = value != 0;
 		return 0;
 	}
+	if (strcmp(key, "single_launch") == 0) { G.single_launch = value != 0; return MM2C_OK; }   // per-read passes of short tasks: the cooperative kernel reads the pinned arena itself (1) or stage_in uploads it first (0)
 	if (strcmp(key, "fuse_st") == 0) { G.fuse_st = value != 0; return MM2C_OK; }   // passes of few tasks of at most 7 168 anchors: the sixteen-wave kernel makes the window starts itself (1) or a prepass launch does (0)
 	if (strcmp(key, "seg_prepass") == 0) { G.seg_prepass = value != 0; return MM2C_OK; }   // plans with tasks of 65 536 anchors or more: a prepass block per 32 768 anchors (1) or per task (0)
 	if (strcmp(key, "coop_w8_above") == 0) {

@@ -135,6 +135,11 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		HIP_TRY(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
 		*c->h_flag = 0; c->seq = 0;
 	}
+	if (direct && !c->d_cnt) {
+		HIP_TRY(hipMalloc((void **)&c->d_cnt, 64));
+		HIP_TRY(hipMemset(c->d_cnt, 0, 64));
+	}
+	if (direct) d_done = c->d_cnt;                                 // zero between passes: the workgroup counted last puts it back (stage_out, chain_dp_coop)
 	if (staged) {
 		size_t at = o_a;
 		for (int r = 0; r < n_req; ++r) {
@@ -159,8 +164,8 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			}
 		}
 		pt1 = pt_now();
-		if (direct) HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
-		else HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));            // cf. chain_hardware.cpp:110,114
+		if (!direct) HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->st));           // cf. chain_hardware.cpp:110,114
+		// (direct: stage_in is launched below, once it is known whether the pass needs it -- a pass of short tasks that ends in the cooperative kernel does not)
 	} else if (n_req == 1 && total >= 2 * pipe_chunk) {
 		// big batch: a three-stage pipeline over chunks of whole pieces.  One stream uploads the chunks back to back (PCIe never idles), the
 		// kernels of chunk k start when its upload has landed -- on one of three compute streams in turn, so that the kernels of consecutive
@@ -288,6 +293,23 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		// round 6: a pass that ends in the cooperative kernel needs no fourth launch -- the kernel stores f / p to the result buffer as it goes and raises the flag
 		if (++c->seq == 0) c->seq = 1;
 		if (G.fused_out.load()) { L.h_f = (int32_t *)c->h_out; L.h_p = (int32_t *)(c->h_out + (size_t)total * 4); L.d_done = d_done; L.h_flag = c->h_flag; L.seq = c->seq; }
+	}
+	if (direct) {
+		// round 6: ONE launch for a pass of short tasks.  When the pass ends in the sixteen-wave kernel, which makes its own window starts and writes the caller's buffer, the
+		// kernel can read the pass from the pinned arena as well: the metadata where it lies (a few words per workgroup), the anchors copied to the device by the workgroup that
+		// chains them.  Asked of the launcher itself (dry run), so that the conditions live in one place.
+		bool single = false;
+		if (G.single_launch.load() && !host_st) {
+			mm2c::LaunchArgs Ld = L; Ld.dry_run = 1;
+			mm2c::LaunchInfo inf = {};
+			HIP_TRY(mm2c::launch_chain_dp(Ld, c->st, nullptr, nullptr, &inf));
+			single = inf.single_ok != 0;
+		}
+		if (single) {
+			L.h_anchors = c->h_in + o_a;
+			L.d_offsets = (const int64_t *)(c->h_in + o_off); L.d_order = (const int32_t *)(c->h_in + o_ord);
+			L.d_avg = (const float *)(c->h_in + o_avg); L.d_pbase = (const int32_t *)(c->h_in + o_pb);
+		} else HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
 	}
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
 	note_host_variant(c->last_info);

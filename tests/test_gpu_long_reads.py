@@ -161,14 +161,18 @@ def test_window_starts_made_inside_the_sixteen_wave_kernel(preset):
         f, p, route, variant = _plan_run(P, off2, a_2)
         assert_same(f, p, f_ref2, p_ref2, off2, f"{preset}, a task of 7 169 anchors: {variant}")
         assert "st=prepass" in variant, variant
-        # the per-read host entry (staged pass -> the same kernel)
-        for k in (3, 6, 10):
-            t_k = a[off[k]:off[k + 1]]
-            avg = ob.avg_qspan(t_k)
-            f, p = mm2chain.chain_task(P, t_k, avg)
-            assert_same(f, p, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None, f"{preset}, chain_task of {t_k.shape[0]} anchors: {mm2chain.last_host_variant()}")
+        # the per-read host entry (a staged pass -> the same kernel): as ONE launch -- the kernel copies the anchors from the pinned arena itself -- and with stage_in first;
+        # alternating, so that the counter of finished workgroups is handed from one kind of pass to the other
+        for single in (1, 0, 1, 1, 0):
+            mm2chain.tune("single_launch", single)
+            for k in (3, 6, 10, 0, 9):
+                t_k = a[off[k]:off[k + 1]]
+                avg = ob.avg_qspan(t_k)
+                f, p = mm2chain.chain_task(P, t_k, avg)
+                assert_same(f, p, f_ref[off[k]:off[k + 1]], p_ref[off[k]:off[k + 1]], None,
+                            f"{preset}, single_launch {single}, chain_task of {t_k.shape[0]} anchors: {mm2chain.last_host_variant()}")
     finally:
-        mm2chain.tune("coop_plans", 2); mm2chain.tune("fuse_st", 1)
+        mm2chain.tune("coop_plans", 2); mm2chain.tune("fuse_st", 1); mm2chain.tune("single_launch", 1)
 
 
 def test_prepass_of_long_tasks_by_segments_and_by_task_alike():

@@ -971,7 +971,7 @@ def knobs():
     yield tune
     helpers.PINNED_ROUTE = None
     for key, val in (("ring_class", int(os.environ.get("MM2C_RING_CLASS", "3"))), ("far_ring", int(os.environ.get("MM2C_FAR_RING", "1"))), ("force_tab", 0), ("noskip_loop", 1), ("compact_ring", 1), ("wide_share_threshold", 40), ("split_streams", 1),
-                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 2), ("coop_waves", 16), ("coop_w8_above", 256), ("fuse_st", 1), ("coop_max_tasks", 1024), ("q24_ring", 1)):
+                     ("plan_cut", 1), ("plan_cut_min", 8192), ("seg_min", 256), ("coop_plans", 2), ("coop_waves", 16), ("coop_w8_above", 256), ("fuse_st", 1), ("single_launch", 1), ("coop_max_tasks", 1024), ("q24_ring", 1)):
         mm2chain.tune(key, val)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, second pass over the per-read hosts: path B with the window starts made inside the cooperative kernel (MM2C_FUSE_ST=1, the default) and by the prepass launch (0)
+# round 6, second pass over the per-read hosts: path B as one launch per pass (the default), with stage_in in front (MM2C_SINGLE_LAUNCH=0) and with the prepass launch as well (MM2C_FUSE_ST=0)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 W=/tmp/pathb; mkdir -p $W $REPO/gpurun_out
 export GPU_MAX_HW_QUEUES=16
@@ -14,7 +14,8 @@ run() {  # name exe env...
   done
 }
 run "cpu host" mm2_refhost A=1
-run "path B, window starts in the kernel" mm2_gpuhost MM2C_FUSE_ST=1
-run "path B, prepass launch" mm2_gpuhost MM2C_FUSE_ST=0
-run "split host, never decline, window starts in the kernel" mm2_splithost MM2C_DECLINE_WHEN_BUSY=0
+run "path B, one launch per pass (default)" mm2_gpuhost A=1
+run "path B, stage_in + kernel with its own window starts" mm2_gpuhost MM2C_SINGLE_LAUNCH=0
+run "path B, stage_in + prepass + kernel (round 6's first form)" mm2_gpuhost MM2C_SINGLE_LAUNCH=0 MM2C_FUSE_ST=0
+run "split host, never decline (default)" mm2_splithost MM2C_DECLINE_WHEN_BUSY=0
 run "cpu host again" mm2_refhost A=1

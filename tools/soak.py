@@ -46,6 +46,7 @@ for r in range(rounds):
     else:
         helpers.PINNED_ROUTE = None; mm2chain.tune("coop_plans", 2)
     mm2chain.tune("coop_w8_above", int(rng.choice([256, 256, 0, 3])))   # the cooperative kernel's width: sixteen waves per piece, eight beyond this many pieces
+    mm2chain.tune("single_launch", int(rng.choice([1, 1, 0])))    # per-read passes: the cooperative kernel reads the pinned arena itself, or stage_in uploads it first
     mm2chain.tune("fuse_st", int(rng.choice([1, 1, 0])))          # short tasks in the sixteen-wave kernel: window starts made by the kernel itself, or by a prepass launch
     mm2chain.tune("fused_out", int(rng.choice([1, 1, 0])))       # per-read passes: the cooperative kernel writes the caller's buffer and raises the flag, or stage_out does
     mm2chain.tune("host_st", int(rng.choice([0, 0, 1])))         # ... and their window starts from the prepass kernel or from the host
@@ -91,6 +92,6 @@ for r in range(rounds):
         bad += 1
         i = int(np.nonzero((f != f_ref) | (p != p_ref))[0][0])
         print(f"MISMATCH round {r} seed {seed0 + r}: first at {i}: f {f[i]} vs {f_ref[i]}, p {p[i]} vs {p_ref[i]}; params {params.as_dict(P)}")
-mm2chain.tune("coop_plans", 2); mm2chain.tune("coop_w8_above", 256); mm2chain.tune("fuse_st", 1); mm2chain.tune("fused_out", 1); mm2chain.tune("host_st", 0)
+mm2chain.tune("coop_plans", 2); mm2chain.tune("coop_w8_above", 256); mm2chain.tune("fuse_st", 1); mm2chain.tune("single_launch", 1); mm2chain.tune("fused_out", 1); mm2chain.tune("host_st", 0)
 mm2chain.tune("ring_class", 3); mm2chain.tune("far_ring", 1); mm2chain.tune("compact_ring", 1); mm2chain.tune("q24_ring", 1); mm2chain.tune("wide_share_threshold", 40); mm2chain.tune("split_streams", 1); mm2chain.tune("noskip_loop", 1)
 print(f"soak: {rounds} rounds, {n_anchor} anchors, {bad} mismatching rounds, {time.time() - t0:.1f} s")
