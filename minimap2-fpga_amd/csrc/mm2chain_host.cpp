@@ -307,7 +307,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 		}
 		if (single) {
 			L.h_anchors = c->h_in + o_a;
-			L.d_offsets = (const int64_t *)(c->h_in + o_off); L.d_order = (const int32_t *)(c->h_in + o_ord);
+			L.d_offsets = (const int64_t *)(c->h_in + o_off); L.d_order = nullptr;   // (no launch order: a handful of workgroups start together anyway, and the look-up would be one more trip to host memory in front of the others)
 			L.d_avg = (const float *)(c->h_in + o_avg); L.d_pbase = (const int32_t *)(c->h_in + o_pb);
 		} else HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
 	}
