@@ -200,6 +200,10 @@ struct CoopHostOut {
 	unsigned *d_done = nullptr;               // workgroups finished (zero between passes: the last to be counted puts it back)
 	unsigned *h_flag = nullptr; unsigned seq = 0;
 };
+// A single-launch pass of at most COOP_META_MAX pieces brings its metadata in the kernel's arguments (piece offsets, avg_qspan_scaled, p base): read through the scalar cache
+// like any argument, instead of a trip to the pinned arena in front of the trip for the anchors.  n = 0: read offsets / avg_in / pbase_in as usual.
+constexpr int COOP_META_MAX = 32;
+struct CoopMeta { int32_t n = 0; int32_t pbase[COOP_META_MAX]; float avg[COOP_META_MAX]; int64_t off[COOP_META_MAX + 1]; };
 __device__ __forceinline__ void coop_host_done(const CoopHostOut &H)
 {
 	if (!H.h_flag) return;
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 
 chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
               const uint4 *__restrict__ a_all, const float *__restrict__ avg_in, const int32_t *__restrict__ pbase_in,
               const int32_t *__restrict__ st_all, int32_t *__restrict__ f_all, int32_t *__restrict__ p_all, int32_t *__restrict__ t_all,
-              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H, int32_t *st_out, float *avg_out, const uint4 *a_src)
+              int32_t *__restrict__ status, int only_flagged, const int64_t *__restrict__ ends, const int32_t *__restrict__ n_live, CoopHostOut H, int32_t *st_out, float *avg_out, const uint4 *a_src, CoopMeta MT)
 {
 	constexpr int NX = COOP_NX, NF = COOP_NF;
 	constexpr bool SKIP = true, GEN = false;
@@ -237,8 +241,10 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if (task >= n_tasks) { coop_host_done(H); return; }
 	if (n_live && task >= (int64_t)*n_live) return;           // pieces cut on the device (chain_cut) that chain_route gave to this kernel: the grid is sized for the most it may give
 	if (only_flagged && status[task] == 0) return;
-	const int64_t base0 = offsets[task];
-	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : offsets[task + 1]) - base0));
+	const bool mt = MT.n > 0;                                   // (then task < MT.n <= COOP_META_MAX: the grid is the pass's pieces)
+	const int64_t base0_v = mt ? MT.off[task] : offsets[task];
+	const int64_t base0 = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base0_v >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)base0_v));   // (the same in every lane; said so)
+	const int n = __builtin_amdgcn_readfirstlane((int)((ends ? ends[task] : mt ? MT.off[task + 1] : offsets[task + 1]) - base0));
 	// the one-word keys of the straight-line pushes (score << 7 | origin) need |score| < 2^23: at most 255 gained per link and a gap cost that cannot overflow
 	// the word either (<= gap_scale * (2.55 * bw + 17) before the shift)
 	const bool key32_ok = n < (1 << 15) && P.span_override <= 255 && P.gap_scale >= 0.f && P.gap_scale <= 4.f && P.bw <= (1 << 17);
@@ -249,9 +255,9 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 	if ((uint32_t)(uintptr_t)(void *)lds != 0) { if (threadIdx.x == 0) status[task] = 3; coop_host_done(H); return; }   // cannot happen: one LDS object per kernel
 	int32_t *const hf = H.f ? H.f + base0 : nullptr, *const hp = H.p ? H.p + base0 : nullptr;
 
-	const int pbase = pbase_in ? pbase_in[task] : 0;
+	const int pbase = mt ? MT.pbase[task] : pbase_in ? pbase_in[task] : 0;
 	const int st_sub = ends ? pbase : 0;                      // device-cut pieces: st[] was computed for the whole task (task-relative), as in chain_dp_tile
-	float avg = avg_in ? avg_in[task] : -1.0f;
+	float avg = mt ? MT.avg[task] : avg_in ? avg_in[task] : -1.0f;
 	if (avg < 0.f) {
 		uint64_t sum = 0;
 		for (int k = lane; k < n; k += 64) sum += (a[k].w & 0xffu);

@@ -65,6 +65,7 @@ struct LaunchArgs {
 	unsigned long long *d_seg_ws = nullptr;   // 4 words of 64 bits per task, zero before the first run (the prepass leaves them zero)
 	int coop_waves = 0;         // > 1: a pass of few tasks -- each task gets a workgroup of several waves that share its LDS rings (chain_dp_coop.h; the variants of the hand-written loop, no device-side cut)
 	int dry_run = 0;            // 1: launch_chain_dp fills `info` (which kernel a pass would take, whether it makes its window starts, whether it writes the caller's buffer) and launches nothing
+	const int64_t *hm_off = nullptr; const float *hm_avg = nullptr; const int32_t *hm_pbase = nullptr;   // ... and the HOST's view of that metadata (plain host pointers): a pass of few pieces hands it over in the kernel's arguments
 	const void *h_anchors = nullptr;   // a single-launch per-read pass: d_anchors has not been uploaded -- the cooperative kernel copies every task from here (same layout, pinned and mapped) itself;
 	                                   // d_offsets / d_order / d_avg / d_pbase then point into the pinned arena as well (the kernel reads them once per workgroup)
 	int fuse_st = 1;            // a pass of few short tasks (<= COOP_ST_MAX anchors each, max_task_anchors known) for the sixteen-wave kernel: it makes the window starts itself, no prepass launch

@@ -825,7 +825,7 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 		const dim3 grid((unsigned)std::min<int64_t>(L.cut.max_pieces, COOP_ROUTE_MAX_PIECES));
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.cut.max_pieces, L.cut.d_start, (const int32_t *)nullptr, \
 	                                            (const uint4 *)L.d_anchors, (const float *)L.cut.d_avg, L.cut.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.cut.d_status, only_flagged, \
-	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut(), (int32_t *)nullptr, (float *)nullptr, (const uint4 *)nullptr)
+	                                            (const int64_t *)L.cut.d_end, n_live, CoopHostOut(), (int32_t *)nullptr, (float *)nullptr, (const uint4 *)nullptr, CoopMeta())
 		if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 		else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP
@@ -834,8 +834,14 @@ static hipError_t launch_coop_w(const LaunchArgs &L, const float *d_avg, hipStre
 	const dim3 grid((unsigned)L.n_tasks);
 	CoopHostOut H;
 	if (L.h_flag && L.h_f && L.h_p && L.d_done && (L.P.flags & KF_IGNORE_SEG) && !only_flagged) { H.f = L.h_f; H.p = L.h_p; H.d_done = L.d_done; H.h_flag = L.h_flag; H.seq = L.seq; }
+	CoopMeta MT;
+	if (a_src && H.h_flag && L.hm_off && L.hm_avg && L.hm_pbase && L.n_tasks <= COOP_META_MAX && !L.d_order) {
+		MT.n = (int32_t)L.n_tasks;
+		for (int64_t k = 0; k < L.n_tasks; ++k) { MT.off[k] = L.hm_off[k]; MT.avg[k] = L.hm_avg[k]; MT.pbase[k] = L.hm_pbase[k]; }
+		MT.off[L.n_tasks] = L.hm_off[L.n_tasks];
+	}
 #define MM2C_COOP(GS1, FAR, TAB) hipLaunchKernelGGL((chain_dp_coop<W, GS1, FAR, TAB>), grid, block, 0, st, L.P, L.n_tasks, L.d_offsets, L.d_order, (const uint4 *)L.d_anchors, \
-	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H, st_out, avg_out, H.h_flag ? a_src : (const uint4 *)nullptr)
+	                                            d_avg, L.d_pbase, L.d_st, L.d_f, L.d_p, L.d_t, L.d_status, only_flagged, (const int64_t *)nullptr, (const int32_t *)nullptr, H, st_out, avg_out, H.h_flag ? a_src : (const uint4 *)nullptr, MT)
 	if (tab) { if (far_) MM2C_COOP(true, true, true); else MM2C_COOP(true, false, true); }
 	else { if (far_) MM2C_COOP(true, true, false); else MM2C_COOP(true, false, false); }
 #undef MM2C_COOP

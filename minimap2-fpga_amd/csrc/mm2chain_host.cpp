@@ -137,7 +137,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 	}
 	if (direct && !c->d_cnt) {
 		HIP_TRY(hipMalloc((void **)&c->d_cnt, 64));
-		HIP_TRY(hipMemset(c->d_cnt, 0, 64));
+		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, 64, c->st));             // on the pass's own stream: in front of its kernels (hipMemset may return before the words are zero, and c->st does not wait for the null stream)
 	}
 	if (direct) d_done = c->d_cnt;                                 // zero between passes: the workgroup counted last puts it back (stage_out, chain_dp_coop)
 	if (staged) {
@@ -309,6 +309,7 @@ int run_requests(ThreadCtx *c, HostReq **reqs, int n_req)
 			L.h_anchors = c->h_in + o_a;
 			L.d_offsets = (const int64_t *)(c->h_in + o_off); L.d_order = nullptr;   // (no launch order: a handful of workgroups start together anyway, and the look-up would be one more trip to host memory in front of the others)
 			L.d_avg = (const float *)(c->h_in + o_avg); L.d_pbase = (const int32_t *)(c->h_in + o_pb);
+			L.hm_off = (const int64_t *)(c->h_in + o_off); L.hm_avg = (const float *)(c->h_in + o_avg); L.hm_pbase = (const int32_t *)(c->h_in + o_pb);   // (few pieces: these travel in the kernel's arguments)
 		} else HIP_TRY(mm2c::launch_stage_in(c->h_in, c->d_in, in_bytes, d_done, c->st));
 	}
 	HIP_TRY(mm2c::launch_chain_dp(L, c->st, &nl, nullptr, &c->last_info));                                           // cf. chain_hardware.cpp:156
