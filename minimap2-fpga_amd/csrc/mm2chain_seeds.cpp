@@ -149,6 +149,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 		for (int64_t r = 0; r < n_reads; ++r) { const int64_t cap = h_anchor_off[r + 1] - h_anchor_off[r]; for (int k = 0; k < 5; ++k) S.n_above[k] += cap > lower[k]; S.n_above[5] += cap > tie_global_above; S.n_sort_big += cap > sort_cap; S.n_sort_huge += cap > sort_cap2; }
 		{ const char *ls = getenv("MM2C_LDS_SORT"); if (ls) S.lds_sort = atoi(ls) != 0; }
 		{ const char *ms = getenv("MM2C_MW_SORT"); if (ms) S.mw_sort = atoi(ms) != 0; }
+		{ const char *tm = getenv("MM2C_TIE_GLOBAL_MW_BELOW"); if (tm) S.tie_global_mw_below = atoi(tm); }
 	}
 	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);
 	return pl;

@@ -937,7 +937,12 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 			used[h] = true;
 		}
 		switch (c) {
-		case 5: hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A); break;
+		case 5:
+			// digits in memory.  Few such reads (a batch of reads of 10^6 anchors: fewer than the GPU has CUs): eight waves per read -- the buckets of a level are independent
+			// walks, only a level of one bucket stays on one wave (255 reads of 10^6 anchors: 414 -> 224 ms, 1 020 of 3e5: 225 -> 178); many: one wave per read, eight reads per CU in flight
+			if (grid[c] <= (unsigned)A.tie_global_mw_below) hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A);
+			else hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A);
+			break;
 		case 4: hipLaunchKernelGGL((seed_ties<TIE_CAP4, TIE_CAP3, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
 		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
 		case 2: hipLaunchKernelGGL((seed_ties<TIE_CAP2, TIE_CAP1, TIE_SW>), dim3(grid[c]), dim3(64 * TIE_SW), 0, s, A); break;

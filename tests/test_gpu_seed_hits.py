@@ -114,6 +114,23 @@ def test_reads_too_long_for_the_lds_replay():
     assert _check(reads, "long") > 1000
 
 
+def test_replay_with_the_digits_in_memory_on_eight_waves_and_on_one(monkeypatch):
+    """reads beyond 131 072 anchors replay with their digits in memory: few of them on eight waves each (the buckets of a level side by side), many on one wave each
+    (MM2C_TIE_GLOBAL_MW_BELOW moves the line); MM2C_TIE_GLOBAL_ABOVE sends shorter reads the same way.  Both forms against the oracle"""
+    rng = np.random.default_rng(78)
+    reads = [_random_read(rng, 38000, 8, 3, 1 << 23, qlen=200000, dup_frac=0.2), _random_read(rng, 2500, 8, 2, 30000, qlen=40000),
+             _random_read(rng, 36000, 8, 1, 1 << 25, qlen=200000, dup_frac=0.1), _random_read(rng, 9000, 6, 3, 1 << 25, qlen=90000, dup_frac=0.25)]
+    sizes = [int(r[1]["n"].sum()) for r in reads]
+    assert sizes[0] > 131072 and sizes[2] > 131072, sizes
+    ties = {}
+    for below in ("1536", "0"):
+        monkeypatch.setenv("MM2C_TIE_GLOBAL_MW_BELOW", below)                     # read when a seed plan is made
+        ties[below] = _check(reads, f"MM2C_TIE_GLOBAL_MW_BELOW={below}")
+    monkeypatch.setenv("MM2C_TIE_GLOBAL_ABOVE", "5000")                           # the 9 000-match read (about 30 000 anchors) takes the same kernel
+    ties["above"] = _check(reads, "MM2C_TIE_GLOBAL_ABOVE=5000")
+    assert ties["1536"] == ties["0"] == ties["above"] > 1000
+
+
 @pytest.mark.parametrize("seed", range(3))
 @pytest.mark.parametrize("lo,hi,n_matches", [(12288, 16384, 3400), (6144, 12288, 2300)])
 def test_reads_of_the_multi_wave_replay_classes(seed, lo, hi, n_matches):
