@@ -315,11 +315,18 @@ __device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_strid
 		if (tid == 0) s_n[cur ^ 1] = 0;
 		__syncthreads();
 		int32_t *in = cur ? list_b : list_a, *out = cur ? list_a : list_b;
+#ifdef MM2C_REPLAY_PROBE
+		if (tid == 0 && blockIdx.x == 0) { int big = 0; long long tot = 0; for (int k = 0; k < n_seg; ++k) { big = max(big, in[2 * k + 1] - in[2 * k]); tot += in[2 * k + 1] - in[2 * k]; }
+			printf("replay level %d: %d buckets, largest %d, total %lld, clock %lld\n", level, n_seg, big, tot, (long long)wall_clock64()); }
+#endif
 		for (int k = wave; k < n_seg; k += NW)
 			replay_bucket<IdT, TWO_BUCKET, LDS_DG>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, moved, fa, fb, lane,
 			                               s_cur + 576 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1]);
 	}
 	__syncthreads();
+#ifdef MM2C_REPLAY_PROBE
+	if (tid == 0 && blockIdx.x == 0) printf("replay end: clock %lld\n", (long long)wall_clock64());
+#endif
 }
 
 } // namespace mm2c
