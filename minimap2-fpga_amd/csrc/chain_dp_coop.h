@@ -464,7 +464,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			// `cnt` rows jt, jt - 1, ..., contiguous in the rings: one base address, the rows at constant offsets from it, eight rows' reads in flight
 			auto seg = [&](int jt, int cnt_rows, bool edge) {
 #ifndef MM2C_COOP_ROWS_CXX
-				if constexpr (!TAB)
+				if constexpr (!TAB) {
 					if (!d1 && asm_rows) {                       // the rows dealt a tile ahead: the hand-written blocks
 						if (!edge) coop_rows_inner(LY::BYTES + CL::CXQ + ((jt & CM) << 3), LY::BYTES + CL::CF + ((jt & CM) << 2), cnt_rows, jt, tx1v, tq1v, sp1v, spb, mdqbw_v, X.bw_v,
 						                           sent_v, avg, best_l, jb_l, cnt_l);
@@ -478,6 +478,7 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 						m_l |= (unsigned long long)(unsigned)ml << (t0 - 1 - jt);   // row r of the group is anchor jt - r: bit t0 - 1 - jt + r
 						return;
 					}
+				}
 #endif
 				const int2 *const px = (const int2 *)(cxq + ((jt & CM) << 3));
 				const int *const pf = (const int *)(cf + ((jt & CM) << 2));
