@@ -65,7 +65,8 @@ struct SeedArgs {
 	int64_t n_sort_big = 0, n_sort_huge = 0;     // reads whose capacity exceeds seed_sort_lds_cap0() / seed_sort_lds_cap(): the first workgroups of the launch order
 	int32_t debug_cut = 0;                       // development aid (MM2C_TIE_CUT): seed_ties returns early / skips parts (results are then wrong)
 	int64_t n_above[6] = {0, 0, 0, 0, 0, 0};     // reads whose capacity exceeds the lower bound of each class of seed_ties (64, then the class sizes): the grid of that class
-	int32_t tie_global_mw_below = 1536;          // the tie replay with the digits in memory: up to this many reads in that class run it on eight waves each (independent buckets of a level side by side), more on one wave each (1 020 reads of 3e5 anchors 225 -> 178 ms, 2 048 of 1e5 84 -> 98)
+	int32_t tie_global_waves = 0;                // experiments / tests: 1, 2, 4 or 8 waves per read of that class whatever their number (0: by their number)
+	int32_t tie_global_mw_below = 600;           // the tie replay with the digits in memory: up to this many reads in that class run it on eight waves each (independent buckets of a level side by side), up to 1 280 on four, up to 3 000 on two, more on one wave each
 	int32_t mw_sort = 1;                         // reads beyond seed_sort_lds_cap() anchors are sorted by sixteen waves (seed_sort_mw); 0: by one (seed_sort)
 	int64_t tie_global_above = 131072;           // the tie replay of reads longer than this keeps its digits in memory, one wave per read (many reads in flight per CU); up to it: LDS classes
 };

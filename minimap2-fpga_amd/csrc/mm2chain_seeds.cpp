@@ -150,6 +150,7 @@ mm2c_seedplan_t *mm2c_seedplan_create(int64_t n_reads, const int64_t *h_match_of
 		{ const char *ls = getenv("MM2C_LDS_SORT"); if (ls) S.lds_sort = atoi(ls) != 0; }
 		{ const char *ms = getenv("MM2C_MW_SORT"); if (ms) S.mw_sort = atoi(ms) != 0; }
 		{ const char *tm = getenv("MM2C_TIE_GLOBAL_MW_BELOW"); if (tm) S.tie_global_mw_below = atoi(tm); }
+		{ const char *tw = getenv("MM2C_TIE_GLOBAL_WAVES"); if (tw) S.tie_global_waves = atoi(tw); }
 	}
 	pl->d_cnt = (int32_t *)(b + o_cnt); pl->d_oo = (int64_t *)(b + o_oo);
 	return pl;

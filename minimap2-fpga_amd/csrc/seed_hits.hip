@@ -938,10 +938,17 @@ hipError_t launch_seed_hits(const SeedArgs &A, hipStream_t st, int *n_launches, 
 		}
 		switch (c) {
 		case 5:
-			// digits in memory.  Few such reads (a batch of reads of 10^6 anchors: fewer than the GPU has CUs): eight waves per read -- the buckets of a level are independent
-			// walks, only a level of one bucket stays on one wave (255 reads of 10^6 anchors: 414 -> 224 ms, 1 020 of 3e5: 225 -> 178); many: one wave per read, eight reads per CU in flight
-			if (grid[c] <= (unsigned)A.tie_global_mw_below) hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A);
-			else hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A);
+			// digits in memory.  The buckets of a level are independent walks (only a level of one bucket stays on one wave), so a read can use several waves -- at the price of
+			// fewer reads in flight per CU: few such reads (a batch of reads of 10^6 anchors: fewer than the GPU has CUs) eight waves each, many one wave each, eight reads per CU
+			{
+				// waves per read by the number of reads in the class (ms for 1, 2, 4, 8 waves, profiles/r6_long_reads.md): 4 096 reads of 5e4 anchors 61 / 66 / 84 / 91; 2 048 of 1e5
+				// 88 / 73 / 87 / 99; 1 533 of 1.5e5 125 / 102 / 113 / 120; 1 020 of 3e5 224 / 195 / 149 / 176; 510 of 5e5 243 / 209 / 175 / 168; 255 of 1e6 414 / 387 / 249 / 226-263
+				const int w = A.tie_global_waves ? A.tie_global_waves : grid[c] <= (unsigned)A.tie_global_mw_below ? TIE_MW_WAVES : grid[c] <= 1280u ? 4 : grid[c] <= 3000u ? 2 : 1;
+				if (w >= 8) hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A);
+				else if (w == 4) hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 4>), dim3(grid[c]), dim3(256), 0, s, A);
+				else if (w == 2) hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 2>), dim3(grid[c]), dim3(128), 0, s, A);
+				else hipLaunchKernelGGL((seed_ties<0, TIE_CAP4, 1>), dim3(grid[c]), dim3(64), 0, s, A);
+			}
 			break;
 		case 4: hipLaunchKernelGGL((seed_ties<TIE_CAP4, TIE_CAP3, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;
 		case 3: hipLaunchKernelGGL((seed_ties<TIE_CAP3, TIE_CAP2, TIE_MW_WAVES>), dim3(grid[c]), dim3(64 * TIE_MW_WAVES), 0, s, A); break;

@@ -114,21 +114,22 @@ def test_reads_too_long_for_the_lds_replay():
     assert _check(reads, "long") > 1000
 
 
-def test_replay_with_the_digits_in_memory_on_eight_waves_and_on_one(monkeypatch):
-    """reads beyond 131 072 anchors replay with their digits in memory: few of them on eight waves each (the buckets of a level side by side), many on one wave each
-    (MM2C_TIE_GLOBAL_MW_BELOW moves the line); MM2C_TIE_GLOBAL_ABOVE sends shorter reads the same way.  Both forms against the oracle"""
+def test_replay_with_the_digits_in_memory_on_one_two_four_and_eight_waves(monkeypatch):
+    """reads beyond 131 072 anchors replay with their digits in memory, on one to eight waves per read by the number of such reads in the batch (the buckets of a level side by
+    side; MM2C_TIE_GLOBAL_WAVES pins the number); MM2C_TIE_GLOBAL_ABOVE sends shorter reads the same way.  Every form against the oracle"""
     rng = np.random.default_rng(78)
     reads = [_random_read(rng, 38000, 8, 3, 1 << 23, qlen=200000, dup_frac=0.2), _random_read(rng, 2500, 8, 2, 30000, qlen=40000),
              _random_read(rng, 36000, 8, 1, 1 << 25, qlen=200000, dup_frac=0.1), _random_read(rng, 9000, 6, 3, 1 << 25, qlen=90000, dup_frac=0.25)]
     sizes = [int(r[1]["n"].sum()) for r in reads]
     assert sizes[0] > 131072 and sizes[2] > 131072, sizes
     ties = {}
-    for below in ("1536", "0"):
-        monkeypatch.setenv("MM2C_TIE_GLOBAL_MW_BELOW", below)                     # read when a seed plan is made
-        ties[below] = _check(reads, f"MM2C_TIE_GLOBAL_MW_BELOW={below}")
+    for waves in ("0", "1", "2", "4", "8"):
+        monkeypatch.setenv("MM2C_TIE_GLOBAL_WAVES", waves)                        # read when a seed plan is made
+        ties[waves] = _check(reads, f"MM2C_TIE_GLOBAL_WAVES={waves}")
+    monkeypatch.setenv("MM2C_TIE_GLOBAL_WAVES", "2")
     monkeypatch.setenv("MM2C_TIE_GLOBAL_ABOVE", "5000")                           # the 9 000-match read (about 30 000 anchors) takes the same kernel
     ties["above"] = _check(reads, "MM2C_TIE_GLOBAL_ABOVE=5000")
-    assert ties["1536"] == ties["0"] == ties["above"] > 1000
+    assert len(set(ties.values())) == 1 and ties["0"] > 1000, ties
 
 
 @pytest.mark.parametrize("seed", range(3))
