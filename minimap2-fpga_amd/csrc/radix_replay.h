@@ -55,7 +55,7 @@ __device__ __forceinline__ void rp_wave_sync()
 // s_cur[d] = {cursor of d, the digit at the cursor}: the cursor of the next bucket and the digit behind the current cursor are fetched side
 // by side, one LDS round trip per step.
 template <bool LDS_DG>
-__device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, int32_t *moved, int lane, int *s_cnt, const int *s_lo)
+__device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, int32_t *moved, int lane, int *s_cnt, const int *s_lo, int *s_buf = nullptr)
 {
 	int2 *s_cur = (int2 *)s_cnt;                                             // {cursor, digit at the cursor}: read and written in one piece
 	if constexpr (LDS_DG) {
@@ -156,6 +156,42 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 	}
 	for (int d = lane; d < 256; d += 64) { const int b = s_lo[d]; s_cur[d] = int2{b - lo, (int)dg[b]}; }   // (an empty last bucket reads the byte behind the array)
 	rp_wave_sync();
+	if (s_buf) {
+		// Long reads (round 6): the walk with its results BUFFERED.  As written below, every step stores moved[destination] = source to memory and loads the digit behind
+		// its cursor; vmcnt counts loads and stores in one order, so the wait for the load was a wait for the store of the step before as well.  Here lane 0 walks RP_BUF
+		// steps at a time, leaving (destination, source) in LDS, and the 64 lanes store the pairs together; inside the walk only the digit loads are in flight
+		// (1 020 reads of 3e5 anchors 147 -> 131 ms).  The digit loads K steps deep on top of this (cursor and digit of a cell written separately, the loads in flight
+		// kept in registers): 140 ms -- the step is its own dependent instructions on one lane, about 0.18 us; not kept.
+		constexpr int RP_BUF = 256;
+		const int n = hi - lo;
+		int head = 0;
+		while (s_lo[head] == s_lo[head + 1]) ++head;
+		int c = head, head_end = s_lo[head + 1] - lo;
+		int2 pk = s_cur[c];
+		for (int sb = 0; sb < n; sb += RP_BUF) {
+			const int m = min(RP_BUF, n - sb);
+			if (lane == 0) {
+				for (int t = 0; t < m; ++t) {
+					if (c == head && pk.x == head_end) {                         // the head's queue is exhausted: the next bucket that is not takes over
+						do ++head; while (s_cur[head].x == s_lo[head + 1] - lo);
+						c = head; pk = s_cur[c]; head_end = s_lo[head + 1] - lo;
+					}
+					const int p = pk.x, d = pk.y;
+					const int nx = dg[lo + p + 1];
+					const int2 pkd = s_cur[d];
+					const int2 npk = int2{p + 1, nx};
+					s_cur[c] = npk;
+					pk = d == c ? npk : pkd;
+					*(int2 *)(s_buf + 2 * t) = int2{lo + pk.x - (d == head ? 1 : 0), lo + p};
+					c = d;
+				}
+			}
+			rp_wave_sync();
+			for (int t = lane; t < m; t += 64) { const int2 e = *(const int2 *)(s_buf + 2 * t); moved[e.x] = e.y; }
+			rp_wave_sync();
+		}
+		return;
+	}
 	if (lane != 0) return;
 	const int n = hi - lo;
 	int head = 0;
@@ -183,7 +219,7 @@ __device__ __forceinline__ void replay_walk(const uint8_t *dg, int lo, int hi, i
 template <typename IdT, bool TWO_BUCKET, bool LDS_DG>
 __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int lo, int hi,
                               IdT *id, uint8_t *dg, int32_t *moved, int32_t *fa, int32_t *fb, int lane, int *s_cur, int *s_lo,
-                              int32_t *out_list, int *out_count)
+                              int32_t *out_list, int *out_count, int *s_buf = nullptr)
 {
 	// the keys of a bucket are the keys of the same positions of the sorted array: smallest and largest differ first in the
 	// highest byte in which any two differ; the passes above that byte move nothing (one bucket each, ksort.h:117-131)
@@ -250,7 +286,7 @@ __device__ __forceinline__ void replay_bucket(const uint64_t *un_x, int un_strid
 			moved[fposA[t]] = fposB[t];
 			moved[t == 0 ? mid : fposB[t - 1] + 1] = fposA[t];
 		}
-	} else replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo);      // ksort.h:117-131
+	} else replay_walk<LDS_DG>(dg, lo, hi, moved, lane, s_cur, s_lo, LDS_DG ? nullptr : s_buf);      // ksort.h:117-131
 	rp_wave_sync();
 	// the new arrangement: position q holds the record that stood at moved[q]
 	for (int q0 = lo; q0 < hi; q0 += 512) {
@@ -302,7 +338,7 @@ __device__ __forceinline__ void replay_passes(const uint64_t *un_x, int un_strid
 // list_a / list_b: n / 64 + 2 buckets (two ints) each; s_n: two ints of LDS; s_cur: NW * 576, s_lo: NW * 257 ints of LDS.
 template <typename IdT, bool TWO_BUCKET, bool LDS_DG, int NW>
 __device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_stride, const uint64_t *sorted_x, int sorted_stride, const int32_t *tiecnt, int n, IdT *id,
-                              uint8_t *dg, int32_t *list_a, int32_t *list_b, int32_t *moved, int32_t *fa, int32_t *fb, int tid, int *s_cur, int *s_lo, int *s_n)
+                              uint8_t *dg, int32_t *list_a, int32_t *list_b, int32_t *moved, int32_t *fa, int32_t *fb, int tid, int *s_cur, int *s_lo, int *s_n, int *s_buf = nullptr /* 512 ints per wave, or none */)
 {
 	const int lane = tid & 63, wave = tid >> 6;
 	for (int i = tid; i < n; i += 64 * NW) id[i] = (IdT)i;
@@ -321,7 +357,7 @@ __device__ __forceinline__ void replay_levels(const uint64_t *un_x, int un_strid
 #endif
 		for (int k = wave; k < n_seg; k += NW)
 			replay_bucket<IdT, TWO_BUCKET, LDS_DG>(un_x, un_stride, sorted_x, sorted_stride, tiecnt, in[2 * k], in[2 * k + 1], id, dg, moved, fa, fb, lane,
-			                               s_cur + 576 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1]);
+			                               s_cur + 576 * wave, s_lo + 257 * wave, out, &s_n[cur ^ 1], s_buf ? s_buf + 512 * wave : nullptr);
 	}
 	__syncthreads();
 #ifdef MM2C_REPLAY_PROBE

@@ -671,6 +671,7 @@ __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TI
 	constexpr int SC = 576;                                                      // ints of replay tables per wave
 	__shared__ __attribute__((aligned(8))) int s_cur[SC * NW];
 	__shared__ int s_lo[257 * NW], s_n[2];
+	__shared__ __attribute__((aligned(8))) int s_wbuf[CAP ? 2 : 512 * NW];          // digits in memory: the walk's results of 256 steps, stored by all lanes together (radix_replay.h)
 	const int read = A.d_order ? A.d_order[blockIdx.x] : (int)blockIdx.x;
 	if (A.status[read] != 0 || A.has_ties[read] == 0) return;
 	const int tid = (int)threadIdx.x;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64 * NW, NW > 2 ? 1 : CAP > TIE_CAP1 ? 2 : CAP > TI
 	int32_t *lists = A.stack + 4 * (a0 / 64 + 2 * (int64_t)read);               // > 64 anchors per pending bucket: na / 64 + 2 entries per list suffice
 	int32_t *moved = w, *fa = w + na, *fb = fa + na;
 	replay_levels<uint32_t, true, CAP != 0, NW>((const uint64_t *)un, 2, (const uint64_t *)out, 2, A.tiecnt + a0, na, id, dg, lists, lists + 2 * (na / 64 + 2),
-	                                             moved, fa, fb, tid, s_cur, s_lo, s_n);
+	                                             moved, fa, fb, tid, s_cur, s_lo, s_n, CAP ? (int *)nullptr : s_wbuf);
 	if (A.debug_cut == 2) return;
 	if (fix) {
 		// place[i] = where the anchor at sorted position i stands in the arrangement; inside a run of equal x the anchor with the k-th smallest
