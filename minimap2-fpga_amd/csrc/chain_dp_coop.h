@@ -50,6 +50,9 @@ constexpr int COOP_NEVER = 0x7fffffff;      // candidate count of an anchor that
 // {x, q} (8 bytes) and f (4 bytes) in two rings of their own, written by wave 0 when the anchor's tile is final; a row reads them with ONE LDS address for all lanes (a
 // broadcast read: no bank conflict, no scalar side), f only when some lane passed the filters.  32 tiles cover everything phase A deals (NX - 1 + COOP_FAR_TILES = 19 tiles back), so
 // no candidate of phase A comes from memory any more.
+#ifndef MM2C_COOP_PUSH2
+#define MM2C_COOP_PUSH2 1
+#endif
 constexpr int COOP_NC = 32;
 constexpr int COOP_ST_MAX = (2 * 64 * 64 * 4 + COOP_NC * 64 * 12) / 8;   // = 7 168: anchors of a task whose window starts the kernel makes itself (their x in the LDS of the tables and candidate rings)
 template <int W> struct CoopLds { static constexpr int KEYS = 0, CNTS = 2 * 64 * 8, MASKS = CNTS + 2 * 64 * 4, PAIRS = MASKS + 2 * 2 * 64 * 8, CXQ = PAIRS + 2 * 64 * 64 * 4,
@@ -645,7 +648,33 @@ chain_dp_coop(KParams P, int64_t n_tasks, const int64_t *__restrict__ offsets, c
 			bool all_done = false;
 #if MM2C_COOP_PROBE != 3 && MM2C_COOP_PROBE != 4
 			if (cnt == 64 && tents == ~0ull) {
-				if (key32_ok) {
+				if constexpr (MM2C_COOP_PUSH2 != 0 && W == 16) {
+					// Two sweeps over the table instead of one that carries (score, origin) together.  With sixteen waves the tile waits for THIS chain -- anchor k + 1 cannot be
+					// pushed before anchor k is final -- so the chain carries the score alone: read a lane, add, maximum (three dependent instructions a push; with the origin
+					// packed into the same word it is six: mask, add the code, select against SENT).  A row of SENT needs no select: SENT + f stays below every score (f >= 0).
+					// The origins come from a second sweep with every f final, whose rows do not wait for one another: the nearest candidate whose score + f EQUALS the
+					// maximum (chain.c:226 is strict and the reference scans nearest first: of equal scores the nearest wins), none if the anchor's own span holds the maximum
+					// (p = -1 only loses to a HIGHER score), the older tiles' best if no candidate of this tile reaches it.  No bound on the scores (the packed form needs
+					// |score| < 2^23).  255 reads of 10^6 anchors 107.1 -> 102.7 ms; with eight waves (two workgroups per CU) the walk is not what a tile waits for and the
+					// second sweep only adds instructions (113.9 against 113.1 ms): they keep the one sweep below.
+					const int S0 = (int)(acc >> 32);
+					const bool from_span = (int)(unsigned)acc == -1;
+					int F = S0;
+#pragma unroll 4
+					for (int k = 0; k < 63; ++k) {               // (anchor 63 has nobody after it)
+						const int row_k = s_pair[k * 64 + lane];
+						F = max(F, row_k + rdlane(F, 63 - k));
+					}
+					int org = -1;
+					for (int k0 = 0; k0 < 63; k0 += 7) {         // seven rows' reads in flight (63 = 9 x 7)
+						int r[7];
+#pragma unroll
+						for (int u = 0; u < 7; ++u) r[u] = s_pair[(k0 + u) * 64 + lane];
+#pragma unroll
+						for (int u = 0; u < 7; ++u) org = r[u] + rdlane(F, 63 - k0 - u) == F ? k0 + u : org;
+					}
+					acc = mk_key(F, (from_span && F == S0) ? -1 : org >= 0 ? i0 + org : from_span ? -1 : jo_l);
+				} else if (key32_ok) {
 					// Scores of a task of fewer than 2^15 anchors stay below 2^23 in size when a chain gains at most 255 per anchor (the 8-bit span of chain.c:189; key32_ok
 					// rules out a larger q_span_override and a negative gap_scale, under which a link can ADD its gap cost), so score and origin fit ONE word:
 					// score << 7 | code, code 0 = the older tiles' best, 1 + k = candidate k of this tile, 127 = the span itself (p = -1).  A signed maximum then is the whole
