@@ -1096,11 +1096,14 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 	if (L.coop_waves <= 1 && G.plan_cut && G.seg_min > 0) {
 		// long reads are chains of loci: cut them at empty windows into independent pieces (one wave each) on the device.  Only tasks of
 		// plan_cut_min anchors or more (they make the tail of the batch); a batch without any runs exactly as before.
+		// (a plan of few very long tasks -- the regime of the cooperative kernel -- cuts no piece shorter than 1/64 of its longest task: every kernel of the run is launched
+		// over the pieces the cut MAY make, and 255 tasks of 10^6 anchors at 256 anchors a piece were 10^6 workgroups per launch, four of five launches with nothing to do)
+		const int seg_min = (pl->n_tasks <= mm2c::COOP_ROUTE_MAX_PIECES && longest >= 65536) ? (int)std::max<int64_t>(G.seg_min, longest / 64) : (int)G.seg_min;
 		int64_t extra = 0;
-		for (size_t k = 0; k < pl->sizes_desc.size() && pl->sizes_desc[k] >= G.plan_cut_min; ++k) extra += pl->sizes_desc[k] / G.seg_min;
+		for (size_t k = 0; k < pl->sizes_desc.size() && pl->sizes_desc[k] >= G.plan_cut_min; ++k) extra += pl->sizes_desc[k] / seg_min;
 		const int64_t max_pieces = pl->n_tasks + extra;
 		if (extra > 0 && max_pieces <= (int64_t)INT32_MAX) {
-			if (!pl->d_cut || pl->cut.max_pieces != max_pieces || pl->cut.seg_min != G.seg_min) {
+			if (!pl->d_cut || pl->cut.max_pieces != max_pieces || pl->cut.seg_min != seg_min) {
 				dev_free(pl->d_cut); pl->d_cut = nullptr;
 				const size_t mp = (size_t)max_pieces;
 				size_t at = 0;
@@ -1109,7 +1112,7 @@ int mm2c_plan_run_device(mm2c_plan_t *pl, const void *d_anchors, const float *d_
 				             o_pb = take(mp * 4), o_avg = take(mp * 4), o_cls = take(mp);
 				HIP_TRY(dev_alloc((void **)&pl->d_cut, at));
 				char *b = pl->d_cut;
-				pl->cut.max_pieces = max_pieces; pl->cut.seg_min = G.seg_min;
+				pl->cut.max_pieces = max_pieces; pl->cut.seg_min = seg_min;
 				pl->cut.d_count = (int32_t *)(b + o_cnt); pl->cut.d_status = (int32_t *)(b + o_stat); pl->cut.d_has_cut = (int32_t *)(b + o_hc);
 				pl->cut.d_start = (int64_t *)(b + o_start); pl->cut.d_end = (int64_t *)(b + o_end);
 				pl->cut.d_pbase = (int32_t *)(b + o_pb); pl->cut.d_avg = (float *)(b + o_avg); pl->cut.d_cls = (uint8_t *)(b + o_cls);
