@@ -175,6 +175,29 @@ def test_window_starts_made_inside_the_sixteen_wave_kernel(preset):
         mm2chain.tune("coop_plans", 2); mm2chain.tune("fuse_st", 1); mm2chain.tune("single_launch", 1)
 
 
+@pytest.mark.parametrize("loci", [31, 32, 33, 70])
+def test_single_launch_pass_with_its_metadata_in_the_arguments_and_in_the_arena(loci):
+    """a per-read call whose read hits many loci: the host cuts it into one piece per locus, and the pass runs as one launch -- up to 32 pieces with the piece offsets, avg
+    and p bases in the kernel's arguments, beyond that read from the pinned arena by every workgroup.  Both sides of the line, against the oracle, and the p[] of later
+    pieces (task-relative through the p base)"""
+    import mm2chain
+    from mm2chain import params
+    P = params.map_ont()
+    t = np.concatenate(_multi_locus(20 + loci, 1, loci, 300))
+    avg = ob.avg_qspan(t)
+    f_ref, p_ref, _ = ob.chain_fpv(P, t, avg)
+    for single in (1, 0):
+        mm2chain.tune("single_launch", single)
+        try:
+            for rep in range(2):
+                f, p = mm2chain.chain_task(P, t, avg)
+                assert_same(f, p, f_ref, p_ref, None, f"{loci} loci, single_launch {single}, run {rep}: {mm2chain.last_host_variant()}")
+        finally:
+            mm2chain.tune("single_launch", 1)
+    assert int(p_ref.max()) > 300 * (loci - 1) - 1                                                 # (a predecessor inside the last locus: index relative to the task)
+    assert "st=kernel" in mm2chain.last_host_variant(), mm2chain.last_host_variant()
+
+
 def test_prepass_of_long_tasks_by_segments_and_by_task_alike():
     """plans with a task of 65 536 anchors or more run the window-start prepass with a block per 32 768 anchors of a task (the segments add up the task's sums, the last to
     arrive writes avg and the ring class); "seg_prepass" 0 keeps a block per task.  Both against the oracle, twice each (the words of the sums must be zero again after a
